@@ -1,0 +1,401 @@
+"""cuda-raytracing_amd -- MI355X-native raycast hot path behind the reference's host API.
+
+Python here is plumbing only: ctypes bindings of the two in-tree libraries
+(``librt_hip.so`` = HIP kernels + C-ABI ``include/rt_hip.h``; ``librt_host.so`` = host C++
+API mirror + C facade ``include/rt_host.h``) and small helpers used by ``bench.py`` and the
+tests.  There is no CPU fallback: if the libraries are missing or no GPU is present, device
+calls fail loudly.
+
+The directory name is not a Python identifier; import it with
+``importlib.import_module("cuda-raytracing_amd")``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HIP_SO = os.path.join(HERE, "librt_hip.so")
+HOST_SO = os.path.join(HERE, "librt_host.so")
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class RtCameraParams(C.Structure):          # include/rt_hip.h
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("K_inv", C.c_float * 9), ("D", C.c_float * 4),
+                ("camera_pose", C.c_float * 6), ("inv_camera_pose", C.c_float * 6)]
+
+
+class RtDebugPlanes(C.Structure):
+    _fields_ = [(n, _vp) for n in ("hit_instance", "hit_triangle", "node_pops", "aabb_tests", "tri_tests", "inside_hits")]
+
+
+# every exported symbol of include/rt_hip.h and include/rt_host.h (tests check the libraries export them all)
+RT_HIP_SYMBOLS = [
+    "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
+    "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
+    "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_debug",
+    "rt_stripe_rows", "rt_render_stripes", "rt_unstripe", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
+    "rt_timer_elapsed_ms", "rt_timer_destroy"]
+RT_HOST_SYMBOLS = [
+    "rth_obj_load", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
+    "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
+    "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
+    "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance",
+    "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
+    "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
+    "rth_camera_params", "rth_q_rsqrt", "rth_atanf", "rth_normalize", "rth_invert_lre", "rth_apply_lre", "rth_euler2quat",
+    "rth_apply_quat", "rth_invert_intrinsic", "rth_last_error"]
+
+_hip = None
+_host = None
+
+
+def build(force=False, verbose=False):
+    from . import _build as _b
+    return _b.build(force=force, verbose=verbose)
+
+
+def libs():
+    """(librt_hip, librt_host) as ctypes CDLLs; raises RtError if they have not been built."""
+    global _hip, _host
+    if _hip is None:
+        for p in (HIP_SO, HOST_SO):
+            if not os.path.exists(p):
+                raise RtError("%s is missing: run __graft_entry__.build() (no CPU fallback exists)" % p)
+        _hip = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        _host = C.CDLL(HOST_SO)
+        _declare(_hip, _host)
+    return _hip, _host
+
+
+def _declare(h, s):
+    h.rt_error_string.restype = C.c_char_p
+    h.rt_error_string.argtypes = [C.c_int]
+    h.rt_device_count.argtypes = [_i]
+    h.rt_malloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+    h.rt_malloc_pitch.argtypes = [C.POINTER(_vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]
+    h.rt_free.argtypes = [_vp]
+    h.rt_memcpy_d2h.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    h.rt_memcpy_h2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    h.rt_memcpy2d_d2h.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]
+    h.rt_stream_synchronize.argtypes = [_vp]
+    h.rt_scene_info.argtypes = [_vp, C.POINTER(C.c_size_t), _i]
+    h.rt_scene_update_instance.argtypes = [_vp, C.c_int32, _vp]
+    h.rt_scene_destroy.argtypes = [_vp]
+    h.rt_render.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, C.c_int]
+    h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
+    h.rt_stripe_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i]
+    h.rt_render_stripes.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int]
+    h.rt_unstripe.argtypes = [_vp, C.c_size_t, C.c_int32, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
+    h.rt_timer_create.argtypes = [C.POINTER(_vp)]
+    h.rt_timer_start.argtypes = [_vp, _vp]
+    h.rt_timer_stop.argtypes = [_vp, _vp]
+    h.rt_timer_elapsed_ms.argtypes = [_vp, _f]
+    h.rt_timer_destroy.argtypes = [_vp]
+
+    s.rth_last_error.restype = C.c_char_p
+    for n in ("rth_obj_load", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
+              "rth_scene_device_handle"):
+        getattr(s, n).restype = _vp
+    s.rth_obj_load.argtypes = [C.c_char_p]
+    s.rth_mesh_from_triangles.argtypes = [_f, C.c_int32]
+    s.rth_mesh_single_triangle.argtypes = [_f]
+    for n in ("rth_mesh_free", "rth_mesh_num_triangles", "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_print_stats",
+              "rth_scene_free", "rth_scene_upload_to_device", "rth_scene_num_mesh_instances", "rth_scene_device_handle",
+              "rth_camera_free"):
+        getattr(s, n).argtypes = [_vp]
+    s.rth_mesh_free.restype = None
+    s.rth_scene_free.restype = None
+    s.rth_camera_free.restype = None
+    s.rth_mesh_get_triangles.argtypes = [_vp, _f]
+    s.rth_mesh_get_nodes.argtypes = [_vp, _f, _i, _i]
+    s.rth_mesh_get_leaf_indices.argtypes = [_vp, _i]
+    s.rth_scene_add_material.argtypes = [_vp, _f, _vp, C.c_int32, C.c_int32, C.c_size_t]
+    s.rth_scene_add_material_ppm.argtypes = [_vp, _f, C.c_char_p]
+    s.rth_scene_add_mesh.argtypes = [_vp, _vp]
+    s.rth_scene_add_mesh_instance.argtypes = [_vp, C.c_int32, C.c_int32, _f, _f]
+    s.rth_scene_update_mesh_instance.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _f, _f]
+    s.rth_instance_build.argtypes = [_f, _f, _f]
+    s.rth_camera_create.argtypes = [C.c_int32, C.c_int32, _f, _f]
+    s.rth_camera_set_pose.argtypes = [_vp, _f]
+    s.rth_camera_set_stream.argtypes = [_vp, _vp]
+    s.rth_camera_render_scene.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
+    s.rth_camera_render_scene_stripes.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int]
+    s.rth_camera_params.argtypes = [_vp, _vp]
+    s.rth_q_rsqrt.restype = C.c_float
+    s.rth_q_rsqrt.argtypes = [C.c_float]
+    s.rth_atanf.restype = C.c_float
+    s.rth_atanf.argtypes = [C.c_float]
+
+
+def _fa(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f)
+
+
+def check(rc, what="rt call"):
+    if rc != 0:
+        h, s = libs()
+        msg = h.rt_error_string(rc).decode() if rc > 0 or rc >= -4 else "?"
+        extra = s.rth_last_error().decode()
+        raise RtError("%s failed: %d (%s) %s" % (what, rc, msg, extra))
+
+
+def device_count():
+    h, _ = libs()
+    n = C.c_int32(0)
+    rc = h.rt_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+# ------------------------------------------------------------------------------------------------
+# Thin object wrappers over the C facade.  Names and call order follow the reference's kernel.cu
+# main(): load meshes, add materials / meshes / instances, upload_to_device, camera.render_scene.
+# ------------------------------------------------------------------------------------------------
+
+class Mesh:
+    """MeshPrimitive (host triangles + BVH)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RtError("mesh creation failed: " + libs()[1].rth_last_error().decode())
+        self.h = handle
+
+    @classmethod
+    def load_obj(cls, path):                          # OBJLoader::load
+        return cls(libs()[1].rth_obj_load(os.fsencode(path)))
+
+    @classmethod
+    def from_triangles(cls, tris18):                  # MeshPrimitive(std::vector<TrianglePrimitive>)
+        t = _fa(tris18).reshape(-1, 18)
+        return cls(libs()[1].rth_mesh_from_triangles(_fp(t), t.shape[0]))
+
+    @classmethod
+    def single_triangle(cls, abc9):                   # TrianglePrimitive(a, b, c)
+        return cls(libs()[1].rth_mesh_single_triangle(_fp(_fa(abc9))))
+
+    @property
+    def num_triangles(self):
+        return libs()[1].rth_mesh_num_triangles(self.h)
+
+    @property
+    def num_nodes(self):
+        return libs()[1].rth_mesh_num_nodes(self.h)
+
+    @property
+    def max_level(self):
+        return libs()[1].rth_mesh_max_level(self.h)
+
+    def dump(self):
+        s = libs()[1]
+        nt, nn = self.num_triangles, self.num_nodes
+        tris = np.zeros((nt, 18), np.float32)
+        s.rth_mesh_get_triangles(self.h, _fp(tris))
+        boxes = np.zeros((nn, 6), np.float32)
+        child = np.zeros((nn, 2), np.int32)
+        lc = np.zeros(nn, np.int32)
+        total = s.rth_mesh_get_nodes(self.h, _fp(boxes), child.ctypes.data_as(_i), lc.ctypes.data_as(_i))
+        li = np.zeros(max(total, 1), np.int32)
+        s.rth_mesh_get_leaf_indices(self.h, li.ctypes.data_as(_i))
+        return dict(tris=tris, boxes=boxes, child=child, leaf_count=lc, leaf_idx=li[:total])
+
+    def close(self):
+        if self.h:
+            libs()[1].rth_mesh_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    def __init__(self):
+        self.h = libs()[1].rth_scene_create()
+        if not self.h:
+            raise RtError("scene creation failed")
+
+    def add_material(self, albedo, texture_bgr=None, ppm=None):
+        s = libs()[1]
+        a = _fa(albedo)
+        if ppm is not None:
+            check(s.rth_scene_add_material_ppm(self.h, _fp(a), os.fsencode(ppm)), "add_material(ppm)")
+        elif texture_bgr is not None:
+            t = np.ascontiguousarray(texture_bgr, np.uint8)
+            check(s.rth_scene_add_material(self.h, _fp(a), t.ctypes.data, t.shape[1], t.shape[0], t.strides[0]), "add_material")
+        else:
+            check(s.rth_scene_add_material(self.h, _fp(a), None, 0, 0, 0), "add_material")
+
+    def add_mesh(self, mesh):
+        check(libs()[1].rth_scene_add_mesh(self.h, mesh.h), "add_mesh")
+
+    def add_mesh_instance(self, mesh, material, pose=(0, 0, 0, 0, 0, 0), scale=(1, 1, 1)):
+        check(libs()[1].rth_scene_add_mesh_instance(self.h, mesh, material, _fp(_fa(pose)), _fp(_fa(scale))), "add_mesh_instance")
+
+    def upload_to_device(self):
+        check(libs()[1].rth_scene_upload_to_device(self.h), "Scene::upload_to_device")
+
+    def update_mesh_instance(self, index, mesh, material, pose, scale=(1, 1, 1)):
+        check(libs()[1].rth_scene_update_mesh_instance(self.h, index, mesh, material, _fp(_fa(pose)), _fp(_fa(scale))),
+              "Scene::update_mesh_instance")
+
+    @property
+    def device_handle(self):
+        return libs()[1].rth_scene_device_handle(self.h)
+
+    def info(self):
+        b = C.c_size_t(0)
+        d = C.c_int32(0)
+        check(libs()[0].rt_scene_info(self.device_handle, C.byref(b), C.byref(d)), "rt_scene_info")
+        return dict(device_bytes=b.value, max_stack=d.value)
+
+    def close(self):
+        if self.h:
+            libs()[1].rth_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Camera:
+    def __init__(self, width, height, K, D):
+        self.width, self.height = int(width), int(height)
+        self.h = libs()[1].rth_camera_create(self.width, self.height, _fp(_fa(K)), _fp(_fa(D)))
+        if not self.h:
+            raise RtError("camera creation failed")
+
+    def set_pose(self, pose):
+        libs()[1].rth_camera_set_pose(self.h, _fp(_fa(pose)))
+
+    def set_stream(self, stream):
+        libs()[1].rth_camera_set_stream(self.h, stream)
+
+    def params(self):
+        p = RtCameraParams()
+        libs()[1].rth_camera_params(self.h, C.addressof(p))
+        return p
+
+    def render_scene(self, scene, d_img, pitch, synchronize=False):
+        check(libs()[1].rth_camera_render_scene(self.h, scene.h, d_img, pitch, 1 if synchronize else 0), "Camera::render_scene")
+
+    def render_scene_stripes(self, scene, d_local, local_pitch, stripe_rows, rank, num_ranks, synchronize=False):
+        check(libs()[1].rth_camera_render_scene_stripes(self.h, scene.h, d_local, local_pitch, stripe_rows, rank, num_ranks,
+                                                        1 if synchronize else 0), "Camera::render_scene_stripes")
+
+    def close(self):
+        if self.h:
+            libs()[1].rth_camera_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """A device allocation made through the C-ABI (rt_malloc / rt_malloc_pitch)."""
+
+    def __init__(self, nbytes=None, width_bytes=None, height=None):
+        h = libs()[0]
+        self.ptr = _vp()
+        if nbytes is not None:
+            check(h.rt_malloc(C.byref(self.ptr), nbytes), "rt_malloc")
+            self.pitch, self.nbytes = None, nbytes
+        else:
+            pitch = C.c_size_t(0)
+            check(h.rt_malloc_pitch(C.byref(self.ptr), C.byref(pitch), width_bytes, height), "rt_malloc_pitch")
+            self.pitch, self.nbytes = pitch.value, pitch.value * height
+        self.width_bytes, self.height = width_bytes, height
+
+    def to_host(self, dtype=np.uint8):
+        h = libs()[0]
+        if self.pitch is None:
+            out = np.zeros(self.nbytes // np.dtype(dtype).itemsize, dtype)
+            check(h.rt_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None), "rt_memcpy_d2h")
+            return out
+        out = np.zeros((self.height, self.width_bytes), np.uint8)
+        check(h.rt_memcpy2d_d2h(out.ctypes.data, self.width_bytes, self.ptr, self.pitch, self.width_bytes, self.height, None),
+              "rt_memcpy2d_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            libs()[0].rt_free(self.ptr)
+            self.ptr = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def render_debug(scene, camera):
+    """One frame through rt_render_debug -> dict(img[h,w,3], hit_inst, hit_tri, pops, aabb, tris, inside)."""
+    h = libs()[0]
+    W, H = camera.width, camera.height
+    img = DeviceBuffer(width_bytes=W * 3, height=H)
+    names = ("hit_inst", "hit_tri", "pops", "aabb", "tris", "inside")
+    bufs = [DeviceBuffer(nbytes=W * H * 4) for _ in names]
+    planes = RtDebugPlanes(*[b.ptr for b in bufs])
+    p = camera.params()
+    check(h.rt_render_debug(scene.device_handle, C.byref(p), img.ptr, img.pitch, C.byref(planes), None, 1), "rt_render_debug")
+    out = dict(img=img.to_host().reshape(H, W, 3))
+    for n, b in zip(names, bufs):
+        out[n] = b.to_host(np.int32).reshape(H, W)
+        b.free()
+    img.free()
+    return out
+
+
+def render(scene, camera):
+    """One frame through Camera::render_scene -> img[h,w,3] uint8 (uchar3 .x .y .z order)."""
+    W, H = camera.width, camera.height
+    img = DeviceBuffer(width_bytes=W * 3, height=H)
+    camera.render_scene(scene, img.ptr, img.pitch, synchronize=True)
+    out = img.to_host().reshape(H, W, 3)
+    img.free()
+    return out
+
+
+class Timer:
+    """hipEvent pair on a given stream (rt_timer_*)."""
+
+    def __init__(self):
+        self.h = _vp()
+        check(libs()[0].rt_timer_create(C.byref(self.h)), "rt_timer_create")
+
+    def start(self, stream=None):
+        check(libs()[0].rt_timer_start(self.h, stream), "rt_timer_start")
+
+    def stop(self, stream=None):
+        check(libs()[0].rt_timer_stop(self.h, stream), "rt_timer_stop")
+
+    def elapsed_ms(self):
+        ms = C.c_float(0)
+        check(libs()[0].rt_timer_elapsed_ms(self.h, C.byref(ms)), "rt_timer_elapsed_ms")
+        return ms.value
+
+    def close(self):
+        if self.h:
+            libs()[0].rt_timer_destroy(self.h)
+            self.h = _vp()

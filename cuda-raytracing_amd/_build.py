@@ -1,0 +1,61 @@
+"""Build the two in-tree shared libraries of the package.
+
+  librt_hip.so   HIP kernels (gfx950) + the C-ABI of include/rt_hip.h   (hipcc)
+  librt_host.so  host C++ API mirror + its C facade include/rt_host.h   (g++, links librt_hip.so)
+
+Both are compiled with -ffp-contract=off: results must be bit-identical to the reference's
+non-contracted fp32 arithmetic.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HIP_SO = os.path.join(HERE, "librt_hip.so")
+HOST_SO = os.path.join(HERE, "librt_host.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+
+HIP_SRCS = [os.path.join(CSRC, "rt_kernels.hip")]
+HIP_DEPS = HIP_SRCS + [os.path.join(CSRC, n) for n in ("rt_math.h", "rt_device_types.h")] + \
+    [os.path.join(ROOT, "include", "rt_hip.h")]
+HOST_SRCS = [os.path.join(CSRC, "host", n) for n in ("rt_host.cpp", "rt_host_capi.cpp")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _host_deps():
+    d = list(HOST_SRCS) + [os.path.join(CSRC, "rt_math.h"), os.path.join(ROOT, "include", "rt_hip.h"),
+                           os.path.join(ROOT, "include", "rt_host.h"), HIP_SO]
+    hd = os.path.join(CSRC, "host")
+    d += [os.path.join(hd, n) for n in os.listdir(hd) if n.endswith((".h", ".hpp"))]
+    return d
+
+
+def build(force=False, verbose=False):
+    """Compile whatever is out of date.  Raises CalledProcessError on a compiler error."""
+    if force or _stale(HIP_SO, HIP_DEPS):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-o", HIP_SO] + HIP_SRCS
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    if force or _stale(HOST_SO, _host_deps()):
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-D__HIP_PLATFORM_AMD__",
+               "-I" + os.path.join(ROCM, "include"), "-o", HOST_SO] + HOST_SRCS + \
+              ["-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return HIP_SO, HOST_SO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,36 @@
+// BVHTree.hpp -- host BVH builder.  Produces, node for node, the tree that the reference's
+// recursive BVHTree::fill builds (BVHTree.hpp:203-292: 5 candidate planes per axis at (s+1)/6 of
+// the node extent, centroid partition, cost = half-area x count, strict-less axis choice with
+// ties to z, pre-order numbering), because identical topology is what makes node-visit counts
+// comparable.  The implementation is not the reference's: the tree is one flat node array over
+// one permutation of the triangle indices, and each node's 15 candidate costs come from a single
+// binning pass instead of 15 partition passes.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "TrianglePrimitive.hpp"
+
+struct BVHNode {
+    float3 min, max;
+    int child_index_a = -1, child_index_b = -1;    // -1 = leaf (BVHTree.hpp:66-67)
+    int first = 0, count = 0;                      // this node's triangles: BVHTree::order[first .. first+count)
+};
+
+class BVHTree {
+public:
+    std::vector<BVHNode> nodes;                    // nodes[0] is the root; children follow in pre-order
+    std::vector<int> order;                        // triangle indices; every leaf is a contiguous range
+
+    BVHTree() {}
+    void build(const TrianglePrimitive* triangles, int num_triangles, int max_depth = 32);   // fill(1, 32)
+    int max_level() const { return levels_; }
+    void print_stats() const;                      // same report as BVHTree.hpp:117-172
+
+private:
+    void fill(int self, int depth, int max_depth);
+    const TrianglePrimitive* tris_ = nullptr;
+    std::vector<float> centroid_;                  // [n][3]  TrianglePrimitive::center()
+    std::vector<float> tbox_;                      // [n][6]  per-triangle bounds
+    std::vector<int> scratch_;
+    int levels_ = 1;
+};

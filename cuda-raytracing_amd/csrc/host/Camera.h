@@ -1,0 +1,28 @@
+// Camera.h -- the kernel launcher of the reference (Camera.h:9-31, Camera.cu:6-41): stores K,
+// K_inv, D and the pose, and renders a Scene into a caller-owned pitched device image.
+#pragma once
+#include <cstddef>
+#include "Scene.h"
+#include "transforms.hpp"
+
+using namespace transforms;
+
+class Camera {
+public:
+    Camera(int width, int height, float3x3 K, float4 D);
+
+    lre pose;
+    int width;
+    int height;
+    float3x3 K;
+    float3x3 K_inv;
+    float4 D;
+    void* stream = nullptr;                        // hipStream_t; the reference always uses the default stream
+    int last_error = 0;
+
+    // asynchronous on `stream` unless synchronize (Camera.cu:38-39)
+    void render_scene(Scene& scene, uchar3* img_ptr, size_t pitch, bool synchronize = false);
+    // this rank's stripes of the frame into a tight local buffer (multi-GPU tiling, rt_hip.h)
+    void render_scene_stripes(Scene& scene, uchar3* local_ptr, size_t local_pitch, int stripe_rows, int rank, int num_ranks,
+                              bool synchronize = false);
+};

@@ -1,0 +1,17 @@
+// MeshPrimitive.h -- a triangle array plus its BVH (MeshPrimitive.h:27-43).  The device copy is
+// made by Scene::upload_to_device through the C-ABI, so there is no per-mesh to_device().
+#pragma once
+#include <vector>
+#include "BVHTree.hpp"
+#include "TrianglePrimitive.hpp"
+
+class MeshPrimitive {
+public:
+    explicit MeshPrimitive(std::vector<TrianglePrimitive> triangles);
+    int num_triangles;
+    BVHTree bvh_top;
+    const std::vector<TrianglePrimitive>& triangle_array() const { return triangles; }
+
+private:
+    std::vector<TrianglePrimitive> triangles;
+};

@@ -1,0 +1,18 @@
+// OBJLoader.hpp -- Wavefront OBJ -> MeshPrimitive with the reference's semantics
+// (OBJLoader.hpp:15-179): `v` and `vt` records, `f` with v, v/vt or v/vt/vn tokens, fan
+// triangulation (0, i, i+1), face normal = normalize(cross(v_i - v_0, v_{i+1} - v_0)) through the
+// fast inverse square root; `vn` is parsed and ignored.
+#pragma once
+#include <string>
+#include <vector>
+#include "MeshPrimitive.h"
+
+namespace OBJLoader {
+// Triangles of the file; returns false (and fills *error) when the file cannot be opened or a
+// face is malformed / out of range.
+bool parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error);
+// Reference behaviour: prints the progress lines, and on an unreadable file prints
+// "Could not open file" and exit(1)s (OBJLoader.hpp:23-27); malformed faces throw std::runtime_error
+// (the reference throws std::invalid_argument from stoi).
+MeshPrimitive load(std::string fp);
+}

@@ -1,0 +1,466 @@
+// rt_host.cpp -- implementation of the host C++ API (Scene / Camera / OBJLoader / MeshPrimitive /
+// BVHTree / Material).  Pure host code: talks to the GPU only through the C-ABI of
+// include/rt_hip.h.  Built with -ffp-contract=off like every file that touches rt_math.h.
+#include <cctype>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../../include/rt_hip.h"
+#include "Camera.h"
+#include "OBJLoader.hpp"
+#include "Scene.h"
+
+// ------------------------------------------------------------------------------ BVHTree
+
+namespace {
+struct Box {
+    float mn[3], mx[3];
+    Box() { for (int k = 0; k < 3; k++) { mn[k] = FLT_MAX; mx[k] = -FLT_MAX; } }       // BVHTree.hpp:73-81
+    void grow(const float* lo, const float* hi)
+    { for (int k = 0; k < 3; k++) { mn[k] = fminf(mn[k], lo[k]); mx[k] = fmaxf(mx[k], hi[k]); } }
+    void merge(const Box& o) { grow(o.mn, o.mx); }
+};
+// BVHTree::cost, BVHTree.hpp:192-201
+float box_cost(const Box& b, size_t count)
+{
+    if (count == 0) return FLT_MAX;
+    float sx = b.mx[0] - b.mn[0], sy = b.mx[1] - b.mn[1], sz = b.mx[2] - b.mn[2];
+    float half_area = sx * (sy + sz) + sy * sz;
+    return half_area * (float)count;
+}
+}  // namespace
+
+void BVHTree::build(const TrianglePrimitive* triangles, int n, int max_depth)
+{
+    tris_ = triangles;
+    nodes.clear();
+    order.resize((size_t)n);
+    centroid_.resize((size_t)n * 3);
+    tbox_.resize((size_t)n * 6);
+    scratch_.resize((size_t)n);
+    levels_ = 1;
+    for (int i = 0; i < n; i++) {
+        order[i] = i;
+        const TrianglePrimitive& t = triangles[i];
+        const float3 c = t.center();                                   // TrianglePrimitive.hpp:81-83
+        centroid_[3 * (size_t)i] = c.x; centroid_[3 * (size_t)i + 1] = c.y; centroid_[3 * (size_t)i + 2] = c.z;
+        Box b;
+        for (int k = 0; k < 3; k++) { const float v[3] = {t.vertices[k].x, t.vertices[k].y, t.vertices[k].z}; b.grow(v, v); }
+        memcpy(&tbox_[6 * (size_t)i], b.mn, 12); memcpy(&tbox_[6 * (size_t)i + 3], b.mx, 12);
+    }
+    BVHNode root;
+    root.first = 0; root.count = n;
+    nodes.push_back(root);                                             // MeshPrimitive.cpp:49-51
+    fill(0, 1, max_depth);                                             // MeshPrimitive.cpp:54
+    centroid_.clear(); centroid_.shrink_to_fit();
+    tbox_.clear(); tbox_.shrink_to_fit();
+    scratch_.clear(); scratch_.shrink_to_fit();
+}
+
+void BVHTree::fill(int self, int depth, int max_depth)
+{
+    const int first = nodes[self].first, count = nodes[self].count;
+    if (depth > levels_) levels_ = depth;
+    // bounds: vertex by vertex in list order, as BVHTree.hpp:206-209 / :175-190
+    Box nb;
+    for (int i = 0; i < count; i++) {
+        const TrianglePrimitive& t = tris_[order[first + i]];
+        for (int k = 0; k < 3; k++) { const float v[3] = {t.vertices[k].x, t.vertices[k].y, t.vertices[k].z}; nb.grow(v, v); }
+    }
+    nodes[self].min = make_float3(nb.mn[0], nb.mn[1], nb.mn[2]);
+    nodes[self].max = make_float3(nb.mx[0], nb.mx[1], nb.mx[2]);
+    if (depth >= max_depth) return;                                    // :211-215
+    if (count <= 1) return;
+
+    // evaluate_split for x, y, z (BVHTree.hpp:294-361).  Plane s of an axis sits at
+    // pos_s = min + (max - min) * ((s + 1) / 6); pos_s is non-decreasing in s, so a centroid c
+    // goes left of exactly the planes s >= bin(c) where bin = #{s : c > pos_s}.  One pass bins
+    // every triangle's box per axis; plane s then has left = bins 0..s, right = bins s+1..5.
+    float pos[3][5], eval_cost[3], eval_split[3];
+    for (int ax = 0; ax < 3; ax++)
+        for (int s = 0; s < 5; s++) {
+            float split_t = ((float)s + 1) / (5.0f + 1);
+            pos[ax][s] = nb.mn[ax] + (nb.mx[ax] - nb.mn[ax]) * (split_t);
+        }
+    Box bin_box[3][6];
+    size_t bin_cnt[3][6] = {{0}};
+    for (int i = 0; i < count; i++) {
+        const int t = order[first + i];
+        const float* tb = &tbox_[6 * (size_t)t];
+        for (int ax = 0; ax < 3; ax++) {
+            const float c = centroid_[3 * (size_t)t + ax];
+            int b = 0;
+            while (b < 5 && !(c <= pos[ax][b])) b++;                   // tri_check <= pos  (:339)
+            bin_box[ax][b].grow(tb, tb + 3);
+            bin_cnt[ax][b]++;
+        }
+    }
+    for (int ax = 0; ax < 3; ax++) {
+        float best_cost = FLT_MAX, best_split = 0.0f;
+        Box right_acc[6];                                              // right_acc[s] = union of bins s+1..5
+        size_t right_cnt[6];
+        Box acc; size_t n = 0;
+        for (int b = 5; b >= 1; b--) { acc.merge(bin_box[ax][b]); n += bin_cnt[ax][b]; right_acc[b - 1] = acc; right_cnt[b - 1] = n; }
+        Box left; size_t ln = 0;
+        for (int s = 0; s < 5; s++) {
+            left.merge(bin_box[ax][s]); ln += bin_cnt[ax][s];
+            float cost = box_cost(left, ln) + box_cost(right_acc[s], right_cnt[s]);     // :351
+            if (cost < best_cost) { best_cost = cost; best_split = pos[ax][s]; }
+        }
+        eval_cost[ax] = best_cost; eval_split[ax] = best_split;
+    }
+    int axis; float split_pos, best_cost;                              // :229-243 (strict <, ties fall to z)
+    if (eval_cost[0] < eval_cost[1] && eval_cost[0] < eval_cost[2]) { axis = 0; split_pos = eval_split[0]; best_cost = eval_cost[0]; }
+    else if (eval_cost[1] < eval_cost[0] && eval_cost[1] < eval_cost[2]) { axis = 1; split_pos = eval_split[1]; best_cost = eval_cost[1]; }
+    else { axis = 2; split_pos = eval_split[2]; best_cost = eval_cost[2]; }
+    if (best_cost >= box_cost(nb, (size_t)count)) return;              // :246
+
+    // stable partition of order[first .. first+count) by centroid <= split_pos (:253-277)
+    int nl = 0, nr = 0;
+    for (int i = 0; i < count; i++) {
+        const int t = order[first + i];
+        if (centroid_[3 * (size_t)t + axis] <= split_pos) order[first + nl++] = t; else scratch_[first + nr++] = t;
+    }
+    for (int i = 0; i < nr; i++) order[first + nl + i] = scratch_[first + i];
+    if (nl == 0 || nr == 0) return;                                    // :279 (order is unchanged in that case)
+
+    const int a = (int)nodes.size();                                   // :283-285
+    BVHNode na; na.first = first; na.count = nl;
+    nodes.push_back(na);
+    nodes[self].child_index_a = a;
+    fill(a, depth + 1, max_depth);
+    const int b = (int)nodes.size();                                   // :287-289
+    BVHNode nbn; nbn.first = first + nl; nbn.count = nr;
+    nodes.push_back(nbn);
+    nodes[self].child_index_b = b;
+    fill(b, depth + 1, max_depth);
+}
+
+void BVHTree::print_stats() const
+{
+    int count_nodes = 0, max_t = 0, min_t = 1000000, max_depth = 0, count_leaves = 0;
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const BVHNode& n = nodes[stack.back()];
+        stack.pop_back();
+        max_depth = (int)fmaxf((float)max_depth, (float)stack.size());
+        count_nodes++;
+        if (n.child_index_a == -1) {
+            if (n.count > max_t) max_t = n.count;
+            if (n.count < min_t) min_t = n.count;
+            count_leaves++;
+        } else {
+            stack.push_back(n.child_index_a);
+            stack.push_back(n.child_index_b);
+        }
+    }
+    float avg = (float)nodes[0].count / (float)count_leaves;
+    std::cout << "BVH Stats: " << std::endl;
+    std::cout << "Number of nodes: " << count_nodes << std::endl;
+    std::cout << "Max triangles per node: " << max_t << std::endl;
+    std::cout << "Min triangles per node: " << min_t << std::endl;
+    std::cout << "Max depth: " << max_depth << std::endl;
+    std::cout << "Number of leaves: " << count_leaves << std::endl;
+    std::cout << "Average triangles per leaf: " << avg << std::endl;
+}
+
+// -------------------------------------------------------------------------- MeshPrimitive
+
+MeshPrimitive::MeshPrimitive(std::vector<TrianglePrimitive> tris) : triangles(std::move(tris))
+{
+    num_triangles = (int)triangles.size();
+    bvh_top.build(triangles.data(), num_triangles, 32);
+}
+
+// ------------------------------------------------------------------------------ Material
+
+void Material::set_texture_bgr(const uint8_t* bgr, int width, int height, size_t pitch)
+{
+    texture.assign((size_t)width * 3 * (size_t)height, 0);
+    for (int y = 0; y < height; y++) memcpy(&texture[(size_t)y * width * 3], bgr + (size_t)y * pitch, (size_t)width * 3);
+    texture_width = width; texture_height = height;
+}
+
+bool Material::upload_texture(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string magic;
+    int w = 0, h = 0, maxv = 0;
+    auto next_token = [&](std::string& out) {
+        out.clear();
+        int c;
+        while ((c = f.get()) != EOF) {
+            if (c == '#') { while ((c = f.get()) != EOF && c != '\n') {} continue; }
+            if (!isspace(c)) { out.push_back((char)c); break; }
+        }
+        while ((c = f.peek()) != EOF && !isspace(c)) out.push_back((char)f.get());
+        return !out.empty();
+    };
+    std::string tok;
+    if (!next_token(magic) || magic != "P6") return false;
+    if (!next_token(tok)) return false;
+    w = atoi(tok.c_str());
+    if (!next_token(tok)) return false;
+    h = atoi(tok.c_str());
+    if (!next_token(tok)) return false;
+    maxv = atoi(tok.c_str());
+    if (w <= 0 || h <= 0 || maxv != 255) return false;
+    f.get();                                                           // single whitespace after maxval
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    f.read((char*)rgb.data(), (std::streamsize)rgb.size());
+    if ((size_t)f.gcount() != rgb.size()) return false;
+    texture.resize(rgb.size());
+    for (size_t i = 0; i < (size_t)w * h; i++) { texture[3 * i] = rgb[3 * i + 2]; texture[3 * i + 1] = rgb[3 * i + 1]; texture[3 * i + 2] = rgb[3 * i]; }
+    texture_width = w; texture_height = h;
+    return true;
+}
+
+// --------------------------------------------------------------------------------- Scene
+
+Scene::Scene() {}
+Scene::~Scene() { if (d_scene) rt_scene_destroy(d_scene); }
+void Scene::add_material(Material material) { materials.push_back(std::move(material)); }
+void Scene::add_mesh(MeshPrimitive mesh) { meshes.push_back(std::move(mesh)); }
+void Scene::add_mesh_instance(MeshInstance mesh_instance) { mesh_instances.push_back(mesh_instance); }
+
+static RtInstanceDesc to_desc(const MeshInstance& in)
+{
+    RtInstanceDesc d;
+    static_assert(sizeof(RtInstanceDesc) == sizeof(MeshInstance), "layouts must agree");
+    memcpy(&d, &in, sizeof d);
+    return d;
+}
+
+void Scene::upload_to_device()
+{
+    if (d_scene) { rt_scene_destroy(d_scene); d_scene = nullptr; }     // Scene.cpp:28-39
+    struct Flat { std::vector<float> v, n, uv, bounds; std::vector<int32_t> child, lfirst, lcount, leaf; };
+    std::vector<Flat> flat(meshes.size());
+    std::vector<RtMeshDesc> md(meshes.size());
+    for (size_t i = 0; i < meshes.size(); i++) {
+        const MeshPrimitive& m = meshes[i];
+        Flat& f = flat[i];
+        const auto& tris = m.triangle_array();
+        f.v.resize(tris.size() * 9); f.n.resize(tris.size() * 3); f.uv.resize(tris.size() * 6);
+        for (size_t t = 0; t < tris.size(); t++) {
+            for (int k = 0; k < 3; k++) {
+                f.v[9 * t + 3 * k] = tris[t].vertices[k].x; f.v[9 * t + 3 * k + 1] = tris[t].vertices[k].y; f.v[9 * t + 3 * k + 2] = tris[t].vertices[k].z;
+                f.uv[6 * t + 2 * k] = tris[t].uv_coords[k].x; f.uv[6 * t + 2 * k + 1] = tris[t].uv_coords[k].y;
+            }
+            f.n[3 * t] = tris[t].normal.x; f.n[3 * t + 1] = tris[t].normal.y; f.n[3 * t + 2] = tris[t].normal.z;
+        }
+        const auto& nodes = m.bvh_top.nodes;
+        f.bounds.resize(nodes.size() * 6); f.child.resize(nodes.size() * 2); f.lfirst.resize(nodes.size()); f.lcount.resize(nodes.size());
+        for (size_t k = 0; k < nodes.size(); k++) {
+            const BVHNode& nd = nodes[k];
+            f.bounds[6 * k] = nd.min.x; f.bounds[6 * k + 1] = nd.min.y; f.bounds[6 * k + 2] = nd.min.z;
+            f.bounds[6 * k + 3] = nd.max.x; f.bounds[6 * k + 4] = nd.max.y; f.bounds[6 * k + 5] = nd.max.z;
+            f.child[2 * k] = nd.child_index_a; f.child[2 * k + 1] = nd.child_index_b;
+            const bool leaf = nd.child_index_a == -1 && nd.child_index_b == -1;         // BVHTree.hpp:100
+            f.lfirst[k] = nd.first; f.lcount[k] = leaf ? nd.count : 0;
+        }
+        f.leaf.assign(m.bvh_top.order.begin(), m.bvh_top.order.end());
+        RtMeshDesc& d = md[i];
+        d.num_triangles = m.num_triangles;
+        d.vertices = f.v.data(); d.normals = f.n.data(); d.uvs = f.uv.data();
+        d.num_nodes = (int32_t)nodes.size();
+        d.node_bounds = f.bounds.data(); d.node_children = f.child.data();
+        d.node_leaf_first = f.lfirst.data(); d.node_leaf_count = f.lcount.data();
+        d.num_leaf_indices = (int32_t)f.leaf.size(); d.leaf_indices = f.leaf.data();
+    }
+    std::vector<RtMaterialDesc> mat(materials.size());
+    for (size_t i = 0; i < materials.size(); i++) {
+        const Material& m = materials[i];
+        RtMaterialDesc& d = mat[i];
+        memset(&d, 0, sizeof d);
+        d.roughness = m.roughness; d.albedo[0] = m.albedo.x; d.albedo[1] = m.albedo.y; d.albedo[2] = m.albedo.z;
+        d.metallic = m.metallic; d.illumination = m.illumination;
+        if (m.texture_width > 0) {
+            d.texture = m.texture.data(); d.texture_width = m.texture_width; d.texture_height = m.texture_height;
+            d.texture_pitch = (size_t)m.texture_width * 3;
+        }
+    }
+    std::vector<RtInstanceDesc> inst(mesh_instances.size());
+    for (size_t i = 0; i < mesh_instances.size(); i++) {
+        mesh_instances[i].build_inv();                                 // Scene.cpp:59
+        inst[i] = to_desc(mesh_instances[i]);
+    }
+    RtSceneDesc sd;
+    sd.num_meshes = (int32_t)md.size(); sd.meshes = md.data();
+    sd.num_materials = (int32_t)mat.size(); sd.materials = mat.data();
+    sd.num_instances = (int32_t)inst.size(); sd.instances = inst.data();
+    last_error = rt_scene_upload(&sd, &d_scene);
+    num_mesh_instances = (int)mesh_instances.size();
+    if (last_error) std::cerr << "Scene::upload_to_device: " << rt_error_string(last_error) << std::endl;
+}
+
+void Scene::update_mesh_instance(int index, MeshInstance mesh_instance)
+{
+    if (index < 0 || index >= (int)mesh_instances.size()) { last_error = RT_E_INVALID; return; }
+    mesh_instances[index] = mesh_instance;
+    mesh_instances[index].build_inv();                                 // Scene.cpp:71
+    RtInstanceDesc d = to_desc(mesh_instances[index]);
+    last_error = d_scene ? rt_scene_update_instance(d_scene, index, &d) : RT_E_INVALID;
+}
+
+// -------------------------------------------------------------------------------- Camera
+
+Camera::Camera(int width, int height, float3x3 K, float4 D) : width(width), height(height), K(K), D(D)
+{
+    K_inv = invert_intrinsic(K);                                       // Camera.cu:12
+    pose = lre();
+}
+
+static RtCameraParams camera_params(const Camera& c)
+{
+    RtCameraParams p;
+    p.width = c.width; p.height = c.height;
+    memcpy(p.K_inv, &c.K_inv, sizeof p.K_inv);
+    p.D[0] = c.D.x; p.D[1] = c.D.y; p.D[2] = c.D.z; p.D[3] = c.D.w;
+    lre inv = invert_lre(c.pose);                                      // Camera.cu:21
+    memcpy(p.camera_pose, &c.pose, sizeof p.camera_pose);
+    memcpy(p.inv_camera_pose, &inv, sizeof p.inv_camera_pose);
+    return p;
+}
+
+void Camera::render_scene(Scene& scene, uchar3* img_ptr, size_t pitch, bool synchronize)
+{
+    RtCameraParams p = camera_params(*this);
+    last_error = rt_render(scene.d_scene, &p, (uint8_t*)img_ptr, pitch, stream, synchronize ? 1 : 0);
+}
+
+void Camera::render_scene_stripes(Scene& scene, uchar3* local_ptr, size_t local_pitch, int stripe_rows, int rank, int num_ranks,
+                                  bool synchronize)
+{
+    RtCameraParams p = camera_params(*this);
+    last_error = rt_render_stripes(scene.d_scene, &p, (uint8_t*)local_ptr, local_pitch, stripe_rows, rank, num_ranks, stream,
+                                   synchronize ? 1 : 0);
+}
+
+// ----------------------------------------------------------------------------- OBJLoader
+
+namespace {
+// std::stoi semantics on a token prefix: optional sign + digits, anything after is ignored
+bool lead_int(const char* s, int& out)
+{
+    char* end = nullptr;
+    long v = strtol(s, &end, 10);
+    if (end == s) return false;
+    out = (int)v;
+    return true;
+}
+}  // namespace
+
+bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error)
+{
+    auto fail = [&](const std::string& msg) { if (error) *error = msg; return false; };
+    FILE* f = fopen(fp.c_str(), "rb");
+    if (!f) return fail("Could not open file " + fp);
+    std::string data;
+    {
+        char buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+        fclose(f);
+    }
+    std::vector<float3> vertices;
+    std::vector<float2> tex_coords;
+    std::vector<const char*> tok;
+    std::vector<size_t> face_lines;
+    // pass 1: v / vt records (vn is accepted and unused, OBJLoader.hpp:55-62); remember face lines
+    size_t pos = 0;
+    const size_t N = data.size();
+    std::vector<std::pair<size_t, size_t>> faces;      // [begin, end) of each "f" line
+    while (pos < N) {
+        size_t eol = data.find('\n', pos);
+        if (eol == std::string::npos) eol = N;
+        size_t a = pos;
+        while (a < eol && isspace((unsigned char)data[a])) a++;
+        size_t b = a;
+        while (b < eol && !isspace((unsigned char)data[b])) b++;
+        const size_t len = b - a;
+        if (len == 1 && data[a] == 'v') {
+            char* p = &data[b]; char* e;
+            float x = strtof(p, &e); if (e == p) return fail("malformed v record"); p = e;
+            float y = strtof(p, &e); if (e == p) return fail("malformed v record"); p = e;
+            float z = strtof(p, &e); if (e == p) return fail("malformed v record");
+            vertices.push_back(make_float3(x, y, z));
+        } else if (len == 2 && data[a] == 'v' && data[a + 1] == 't') {
+            char* p = &data[b]; char* e;
+            float x = strtof(p, &e); if (e == p) return fail("malformed vt record"); p = e;
+            float y = strtof(p, &e); if (e == p) return fail("malformed vt record");
+            tex_coords.push_back(make_float2(x, y));
+        } else if (len == 1 && data[a] == 'f') {
+            faces.push_back(std::make_pair(b, eol));
+        }
+        pos = eol + 1;
+    }
+    // pass 2: faces -> fan triangles (OBJLoader.hpp:90-171)
+    std::vector<int> vi, ti;
+    for (const auto& fl : faces) {
+        vi.clear(); ti.clear();
+        size_t p = fl.first;
+        while (p < fl.second) {
+            while (p < fl.second && isspace((unsigned char)data[p])) p++;
+            if (p >= fl.second) break;
+            size_t q = p;
+            while (q < fl.second && !isspace((unsigned char)data[q])) q++;
+            // token [p, q): v, v/vt or v/vt/vn
+            size_t s1 = p;
+            while (s1 < q && data[s1] != '/') s1++;
+            int v;
+            {
+                std::string head(&data[p], s1 - p);
+                if (!lead_int(head.c_str(), v)) return fail("malformed face token");
+                vi.push_back(v - 1);
+            }
+            if (s1 < q) {
+                std::string rest(&data[s1 + 1], q - s1 - 1);
+                if (!lead_int(rest.c_str(), v)) return fail("malformed face token (v//vn is not supported)");
+                ti.push_back(v - 1);
+                size_t s2 = rest.find('/');
+                if (s2 != std::string::npos && !lead_int(rest.c_str() + s2 + 1, v)) return fail("malformed face token");
+            }
+            p = q;
+        }
+        for (size_t i = 1; i + 1 < vi.size(); i++) {
+            const int ia = vi[0], ib = vi[i], ic = vi[i + 1];
+            const int nv = (int)vertices.size();
+            if (ia < 0 || ib < 0 || ic < 0 || ia >= nv || ib >= nv || ic >= nv) return fail("face vertex index out of range");
+            const float3 &A = vertices[ia], &B = vertices[ib], &C = vertices[ic];
+            float3 normal = normalize(cross(TrianglePrimitive::sub(B, A), TrianglePrimitive::sub(C, A)));   // :141-143
+            if (!ti.empty()) {
+                const int nt = (int)tex_coords.size();
+                if (ti.size() <= i + 1) return fail("face mixes v and v/vt tokens");
+                const int ta = ti[0], tb = ti[i], tc = ti[i + 1];
+                if (ta < 0 || tb < 0 || tc < 0 || ta >= nt || tb >= nt || tc >= nt) return fail("face texture index out of range");
+                triangles.push_back(TrianglePrimitive(A, B, C, normal, tex_coords[ta], tex_coords[tb], tex_coords[tc]));
+            } else {
+                triangles.push_back(TrianglePrimitive(A, B, C, normal));
+            }
+        }
+    }
+    return true;
+}
+
+MeshPrimitive OBJLoader::load(std::string fp)
+{
+    std::cout << "Loading OBJ file: " << fp << std::endl;
+    std::vector<TrianglePrimitive> triangles;
+    std::string err;
+    if (!parse(fp, triangles, &err)) {
+        if (err.rfind("Could not open file", 0) == 0) { std::cout << err << std::endl; exit(1); }
+        throw std::runtime_error("OBJLoader: " + err);
+    }
+    std::cout << "OBJ File: " << fp << std::endl;
+    std::cout << "Loaded " << triangles.size() << " triangles" << std::endl;
+    return MeshPrimitive(std::move(triangles));
+}

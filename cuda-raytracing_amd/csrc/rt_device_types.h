@@ -1,0 +1,79 @@
+// rt_device_types.h -- device-side scene layout of librt_hip.so (see DESIGN.md "Data layout in HBM").
+#pragma once
+#include <cstdint>
+#include "rt_math.h"
+
+namespace rt {
+
+// Traversal-stack entry / child reference, 32 bits:
+//   >= 0                      interior node index into Scene::inodes (scene-wide)
+//   bit 31 set                leaf: bits 0..25 = first triangle slot (scene-wide),
+//                             bits 26..30 = triangle count 0..30, or 31 = read leaf_count[slot]
+constexpr int32_t kLeafFlag = (int32_t)0x80000000u;
+constexpr int kSlotBits = 26;
+constexpr int32_t kSlotMask = (1 << kSlotBits) - 1;
+constexpr int kMaxStack = 64;
+
+// Interior node: 64 B = 4 x float4, holds BOTH children's boxes so one pop costs one 64-B
+// record instead of the reference's three 48-B d_BVHTree loads (raycast.cu:62,69,70).
+//   q0 = a.min.x a.min.y a.min.z a.max.x
+//   q1 = a.max.y a.max.z b.min.x b.min.y
+//   q2 = b.min.z b.max.x b.max.y b.max.z
+//   q3 = ref_a   ref_b   (2 spare words)
+//
+// Triangle record: 64 B = 4 x float4 in leaf ("slot") order, so a leaf is a contiguous range
+// and the per-leaf index lists of BVHTree.hpp:97-111 disappear from the traversal.
+//   t0 = v0.x v0.y v0.z n.x
+//   t1 = n.y  n.z  e0.x e0.y          e0 = v2 - v0, e1 = v1 - v0   (TrianglePrimitive.hpp:154-155)
+//   t2 = e0.z e1.x e1.y e1.z
+//   t3 = dot00 dot01 dot11 invDenom   (TrianglePrimitive.hpp:158-164: ray-independent, so
+//                                      precomputed on the host with the same fp32 operations)
+
+struct DevInstance {            // 128 B
+    Q4 q_rot;                   // euler2quat(rotation)          raycast.cu:33
+    Q4 q_pose;                  // euler2quat(pose ypr)          raycast.cu:40
+    Q4 q_inv_pose;              // euler2quat(inv_pose ypr)      raycast.cu:102
+    Q4 q_inv_rot;               // euler2quat(inv_rotation)      raycast.cu:115
+    float pose_xyz[3];
+    float inv_pose_xyz[3];
+    float scale[3];
+    float inv_scale[3];
+    int32_t root_ref;           // stack entry of the mesh root
+    int32_t material_index;
+    int32_t mesh_index;
+    int32_t exact_uv;           // mesh has uv values that could make uv.x == FLT_MAX (raycast.cu:96)
+};
+
+struct DevMaterial {            // Material.hpp:6-16 (fields the path reads)
+    float albedo[3];
+    int32_t texture_width;
+    int32_t texture_height;
+    uint32_t texture_pitch;
+    const uint8_t* texture;
+};
+
+struct RenderParams {
+    int32_t width, height;
+    float kinv[9];
+    float D[4];
+    float origin[3];
+    Q4 q_cam;                   // euler2quat(inv_camera_pose ypr), raycast.cu:185
+    const float4* inodes;
+    const float4* tris;
+    const float* tri_uv;        // [slot][3][2]
+    const int32_t* tri_id;      // [slot] -> caller's triangle index within its mesh
+    const int32_t* leaf_count;  // [slot] count of the leaf that starts at slot (only read for count > 30)
+    const DevInstance* instances;
+    const DevMaterial* materials;
+    int32_t num_instances;
+    int32_t stack_depth;        // LDS stack entries per lane
+    uint8_t* img;
+    uint64_t pitch;
+    // stripes: local row ly is frame row ((ly / stripe_rows) * num_ranks + rank) * stripe_rows + ly % stripe_rows
+    int32_t local_rows, stripe_rows, rank, num_ranks;
+    int32_t tiles_x, tiles_y;   // 16x16-pixel workgroup tiles over width x local_rows
+    // parity planes (tight [height][width], frame coordinates), any may be null
+    int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;
+};
+
+}  // namespace rt

@@ -1,0 +1,669 @@
+// rt_kernels.hip -- the raycast hot path for MI355X (gfx950, wave64) and its C-ABI (include/rt_hip.h).
+//
+// Path replaced: render<<<>>> / cast_ray (raycast.cu:146-297 / :21-142) with everything they
+// call (d_BVHTree::ray_intersects BVHTree.hpp:40-54, TrianglePrimitive::ray_intersect /
+// point_inside TrianglePrimitive.hpp:62-79,151-185, the L0 math in utils.hpp / transforms.hpp).
+// Results are bit-identical to the reference arithmetic (see rt_math.h); the memory layout and
+// the execution mapping are not the reference's -- see DESIGN.md.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (mandatory: SURVEY.md H3).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_device_types.h"
+#include "rt_math.h"
+
+using namespace rt;
+
+// =====================================================================================
+//                                      device code
+// =====================================================================================
+
+namespace {
+
+constexpr int kBlock = 256;     // 4 waves; one 16x16-pixel tile = 2x2 wave tiles of 8x8 pixels
+
+struct Hit {
+    float min;                  // HitInfo::min, raycast.cu:12
+    int32_t slot;               // triangle slot of the accepted hit
+    int32_t instance;
+    float u, v;                 // barycentrics of the accepted hit (uv is interpolated once, at shade time)
+    float2 uv;                  // used only by the exact-uv variant
+};
+
+// d_BVHTree::ray_intersects, BVHTree.hpp:40-54
+__device__ __forceinline__ float slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                      V3 o, V3 dinv)
+{
+    float tminx = (mnx - o.x) * dinv.x, tminy = (mny - o.y) * dinv.y, tminz = (mnz - o.z) * dinv.z;
+    float tmaxx = (mxx - o.x) * dinv.x, tmaxy = (mxy - o.y) * dinv.y, tmaxz = (mxz - o.z) * dinv.z;
+    float t1x = fminf(tminx, tmaxx), t1y = fminf(tminy, tmaxy), t1z = fminf(tminz, tmaxz);
+    float t2x = fmaxf(tminx, tmaxx), t2y = fmaxf(tminy, tmaxy), t2z = fmaxf(tminz, tmaxz);
+    float dst_far = fminf(fminf(t2x, t2y), t2z);
+    float dst_near = fmaxf(fmaxf(t1x, t1y), t1z);
+    bool hit = dst_far >= dst_near && dst_far > 0.0f;
+    return hit ? dst_near : FLT_MAX;
+}
+
+// Primary ray direction of pixel (x, y): raycast.cu:159-188
+__device__ __forceinline__ V3 camera_direction(const RenderParams& p, int x, int y)
+{
+    float fx = (float)x, fy = (float)y;
+    // apply_matrix(K_inv, (x, y, 1)), utils.hpp:134-140
+    float a = p.kinv[0] * fx + p.kinv[1] * fy + p.kinv[2] * 1.0f;
+    float b = p.kinv[3] * fx + p.kinv[4] * fy + p.kinv[5] * 1.0f;
+    float c = p.kinv[6] * fx + p.kinv[7] * fy + p.kinv[8] * 1.0f;
+    float radius = sqrtf(a * a + b * b);
+    float theta = atanf_fdlibm(radius);
+    // raycast.cu:172 -- float products, double sum, double outer product, narrowed to float
+    float thetad = (float)((double)theta * (1.0 + (double)(p.D[0] * theta) + (double)(p.D[1] * theta * theta)
+                   + (double)(p.D[2] * theta * theta * theta) + (double)(p.D[3] * theta * theta * theta * theta)));
+    float scale = thetad / radius;
+    V3 d = normalize(v3(scale * a, scale * b, c));
+    d = v3(d.x, d.z, -d.y);                                     // raycast.cu:182
+    d = apply_quat(p.q_cam, d);                                 // raycast.cu:185
+    return normalize(d);                                        // raycast.cu:188
+}
+
+template <bool DEBUG>
+struct Counters {
+    int pops = 0, aabb = 0, tris = 0, inside = 0;
+};
+template <>
+struct Counters<false> {};
+
+// One instance of raycast.cu:26-139.  `stack` points at this lane's column of the LDS stack
+// (entries kBlock ints apart, so a wave's accesses are conflict-free).
+template <bool DEBUG>
+__device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
+                                               V3 org, V3 dir, int* stack, Hit& hit, Counters<DEBUG>& cnt)
+{
+    // ray -> mesh space, raycast.cu:33-51
+    V3 rd = apply_quat(in.q_rot, dir);
+    rd.x *= in.inv_scale[0]; rd.y *= in.inv_scale[1]; rd.z *= in.inv_scale[2];
+    V3 ro = apply_quat(in.q_pose, v3(org.x - in.pose_xyz[0], org.y - in.pose_xyz[1], org.z - in.pose_xyz[2]));
+    ro.x *= in.inv_scale[0]; ro.y *= in.inv_scale[1]; ro.z *= in.inv_scale[2];
+    V3 dinv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);        // Ray.hpp:21
+    const bool exact_uv = in.exact_uv != 0;
+
+    int sp = 0;
+    int32_t cur = in.root_ref;                                  // raycast.cu:58 (kept in a register)
+    bool have = true;
+    while (true) {
+        if (!have) {
+            if (sp == 0) break;
+            cur = stack[(--sp) * kBlock];                       // raycast.cu:61
+        }
+        have = false;
+        if constexpr (DEBUG) cnt.pops++;
+        if (cur >= 0) {
+            // interior node: both children's boxes in one 64-B record (raycast.cu:66-79)
+            const float4* n = p.inodes + (size_t)cur * 4;
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            float da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ro, dinv);
+            float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ro, dinv);
+            int32_t ra = __float_as_int(q3.x), rb = __float_as_int(q3.y);
+            if constexpr (DEBUG) cnt.aabb += 2;
+            bool pa = da < hit.min, pb = db < hit.min;
+            // Push order of raycast.cu:72-79; the entry that would be pushed last is the one the
+            // next iteration pops, so it stays in `cur` instead of going through the stack.
+            int32_t first, second; bool pf, ps;
+            if (da < db) { first = rb; pf = pb; second = ra; ps = pa; }
+            else         { first = ra; pf = pa; second = rb; ps = pb; }
+            if (ps) {
+                if (pf) stack[(sp++) * kBlock] = first;
+                cur = second; have = true;
+            } else if (pf) {
+                cur = first; have = true;
+            }
+        } else {
+            // leaf: contiguous slots (raycast.cu:83-137)
+            int slot = cur & kSlotMask;
+            int count = (cur >> kSlotBits) & 31;
+            if (count == 31) count = p.leaf_count[slot];
+            for (int i = 0; i < count; i++, slot++) {
+                const float4* t = p.tris + (size_t)slot * 4;
+                float4 t0 = t[0], t1 = t[1];
+                if constexpr (DEBUG) cnt.tris++;
+                V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
+                // TrianglePrimitive::ray_intersect, TrianglePrimitive.hpp:62-79
+                float denom = dot(rd, nrm);
+                if ((double)fabsf(denom) < 1e-6) continue;
+                float tt = dot(v0 - ro, nrm) / denom;
+                if (tt < 0.0f) continue;
+                V3 pt = ro + tt * rd;
+                if (pt.x == FLT_MAX) continue;                  // raycast.cu:91
+                // TrianglePrimitive::point_inside, TrianglePrimitive.hpp:151-185
+                float4 t2 = t[2], t3 = t[3];
+                V3 e0 = v3(t1.z, t1.w, t2.x), e1 = v3(t2.y, t2.z, t2.w);
+                V3 e2 = pt - v0;
+                float dot02 = dot(e0, e2), dot12 = dot(e1, e2);
+                float u = (t3.z * dot02 - t3.y * dot12) * t3.w;
+                float v = (t3.x * dot12 - t3.y * dot02) * t3.w;
+                if (!((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f))) continue;
+                float2 uv = make_float2(0.0f, 0.0f);
+                if (exact_uv) {                                 // raycast.cu:96 can only fail for absurd uv data
+                    const float* q = p.tri_uv + (size_t)slot * 6;
+                    float w = 1.0f - u - v;
+                    uv.x = (w * q[0] + v * q[2]) + u * q[4];
+                    uv.y = (w * q[1] + v * q[3]) + u * q[5];
+                    if (!(uv.x != FLT_MAX)) continue;
+                }
+                if constexpr (DEBUG) cnt.inside++;
+                // raycast.cu:98-104
+                V3 loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
+                loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
+                float distance = magnitude(loc - org);
+                // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
+                if (denom < 0 && (hit.min == FLT_MAX || distance < hit.min)) {
+                    hit.min = distance;
+                    hit.slot = slot; hit.instance = inst_index; hit.u = u; hit.v = v; hit.uv = uv;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint8_t to_u8(float f) { return (uint8_t)(int)f; }
+
+// raycast.cu:207-294
+__device__ __forceinline__ void shade(const RenderParams& p, const Hit& hit, uint8_t* px)
+{
+    if (hit.min == FLT_MAX) {                                   // sky, raycast.cu:208-216
+        px[0] = 255; px[1] = 204; px[2] = 153;
+        return;
+    }
+    const DevInstance& in = p.instances[hit.instance];
+    const DevMaterial& m = p.materials[in.material_index];
+    float cx, cy, cz;
+    if (m.texture_width > 0) {                                  // raycast.cu:224-240
+        float2 uv = hit.uv;
+        if (!in.exact_uv) {
+            const float* q = p.tri_uv + (size_t)hit.slot * 6;
+            float w = 1.0f - hit.u - hit.v;
+            uv.x = (w * q[0] + hit.v * q[2]) + hit.u * q[4];
+            uv.y = (w * q[1] + hit.v * q[3]) + hit.u * q[5];
+        }
+        int tex_x = (int)(uv.x * (float)m.texture_width);
+        int tex_y = (int)((1.0 - (double)uv.y) * (double)(float)m.texture_height);
+        tex_x = (int)fmaxf((float)(tex_x % m.texture_width), 0.0f);
+        tex_y = (int)fmaxf((float)(tex_y % m.texture_height), 0.0f);
+        const uint8_t* tc = m.texture + (size_t)tex_y * m.texture_pitch + 3 * (size_t)tex_x;
+        cx = 1.0f * ((float)tc[0] * 0.0039215f);
+        cy = 1.0f * ((float)tc[1] * 0.0039215f);
+        cz = 1.0f * ((float)tc[2] * 0.0039215f);
+    } else {                                                    // raycast.cu:241-245
+        cx = 1.0f * m.albedo[0]; cy = 1.0f * m.albedo[1]; cz = 1.0f * m.albedo[2];
+    }
+    const float illumination = 1.0f;                            // raycast.cu:282-290
+    px[0] = to_u8(illumination * cx * 255.0f);                  // raycast.cu:292-294
+    px[1] = to_u8(illumination * cy * 255.0f);
+    px[2] = to_u8(illumination * cz * 255.0f);
+}
+
+template <bool DEBUG>
+__global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
+{
+    extern __shared__ int lds_stack[];                          // [stack_depth][kBlock]
+
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the
+    // k-th contiguous eighth of the tile list -- neighbouring tiles (same BVH subtrees) share an L2.
+    const int ntiles = p.tiles_x * p.tiles_y;
+    int b = blockIdx.x;
+    const int per = ntiles >> 3, body = per << 3;
+    int tile = (b < body) ? (b & 7) * per + (b >> 3) : b;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (x >= p.width || ly >= p.local_rows) return;
+    const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
+
+    const V3 org = v3(p.origin[0], p.origin[1], p.origin[2]);
+    const V3 dir = camera_direction(p, x, y);
+
+    Hit hit;
+    hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
+    Counters<DEBUG> cnt;
+    int* stack = lds_stack + tid;
+    for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
+        trace_instance<DEBUG>(p, p.instances[i], i, org, dir, stack, hit, cnt);
+
+    uint8_t px[3];
+    shade(p, hit, px);
+    uint8_t* out = p.img + (size_t)ly * p.pitch + 3 * (size_t)x;
+    out[0] = px[0]; out[1] = px[1]; out[2] = px[2];
+
+    if constexpr (DEBUG) {
+        size_t o = (size_t)y * p.width + x;
+        if (p.hit_instance) p.hit_instance[o] = hit.instance;
+        if (p.hit_triangle) p.hit_triangle[o] = hit.slot >= 0 ? p.tri_id[hit.slot] : -1;
+        if (p.node_pops) p.node_pops[o] = cnt.pops;
+        if (p.aabb_tests) p.aabb_tests[o] = cnt.aabb;
+        if (p.tri_tests) p.tri_tests[o] = cnt.tris;
+        if (p.inside_hits) p.inside_hits[o] = cnt.inside;
+    }
+}
+
+// rows of a rank-major gathered buffer back into frame order (rt_unstripe)
+__global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pitch, int max_local_rows,
+                                uint8_t* __restrict__ dst, size_t pitch, int row_bytes, int height,
+                                int stripe_rows, int num_ranks)
+{
+    const int y = blockIdx.y;
+    if (y >= height) return;
+    const int stripe = y / stripe_rows, rank = stripe % num_ranks;
+    const int ly = (stripe / num_ranks) * stripe_rows + y % stripe_rows;
+    const uint8_t* s = src + ((size_t)rank * max_local_rows + ly) * local_pitch;
+    uint8_t* d = dst + (size_t)y * pitch;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+}  // namespace
+
+// =====================================================================================
+//                                  host side of the C-ABI
+// =====================================================================================
+
+struct RtScene {
+    int device = 0;
+    float4* d_inodes = nullptr;
+    float4* d_tris = nullptr;
+    float* d_tri_uv = nullptr;
+    int32_t* d_tri_id = nullptr;
+    int32_t* d_leaf_count = nullptr;
+    DevInstance* d_instances = nullptr;
+    DevMaterial* d_materials = nullptr;
+    std::vector<uint8_t*> d_textures;
+    std::vector<DevInstance> instances;          // host mirror (for update_instance)
+    std::vector<int32_t> mesh_root_ref;          // per mesh
+    std::vector<int32_t> mesh_exact_uv;
+    int32_t num_materials = 0;
+    int32_t max_stack = 1;
+    size_t device_bytes = 0;
+};
+
+struct RtTimer { hipEvent_t start, stop; };
+
+#define RT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+namespace {
+
+DevInstance make_dev_instance(const RtInstanceDesc& d, const RtScene& s)
+{
+    DevInstance o;
+    memset(&o, 0, sizeof o);
+    o.q_rot = euler2quat(v3(d.rotation[0], d.rotation[1], d.rotation[2]));
+    o.q_pose = euler2quat(v3(d.pose[3], d.pose[4], d.pose[5]));
+    o.q_inv_pose = euler2quat(v3(d.inv_pose[3], d.inv_pose[4], d.inv_pose[5]));
+    o.q_inv_rot = euler2quat(v3(d.inv_rotation[0], d.inv_rotation[1], d.inv_rotation[2]));
+    for (int k = 0; k < 3; k++) {
+        o.pose_xyz[k] = d.pose[k]; o.inv_pose_xyz[k] = d.inv_pose[k];
+        o.scale[k] = d.scale[k]; o.inv_scale[k] = d.inv_scale[k];
+    }
+    o.root_ref = s.mesh_root_ref[d.mesh_index];
+    o.exact_uv = s.mesh_exact_uv[d.mesh_index];
+    o.material_index = d.material_index;
+    o.mesh_index = d.mesh_index;
+    return o;
+}
+
+bool instance_ok(const RtInstanceDesc& d, const RtScene& s)
+{
+    return d.mesh_index >= 0 && d.mesh_index < (int)s.mesh_root_ref.size() &&
+           d.material_index >= 0 && d.material_index < s.num_materials;
+}
+
+template <class T>
+int upload(T** dptr, const std::vector<T>& h, size_t& total)
+{
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    RT_HIP(hipMalloc((void**)dptr, bytes));
+    if (!h.empty()) RT_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    total += bytes;
+    return 0;
+}
+
+int32_t leaf_ref(int64_t slot, int count) { return kLeafFlag | ((count <= 30 ? count : 31) << kSlotBits) | (int32_t)slot; }
+
+void fill_params(RenderParams& p, const RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch)
+{
+    memset(&p, 0, sizeof p);
+    p.width = cam->width; p.height = cam->height;
+    memcpy(p.kinv, cam->K_inv, sizeof p.kinv);
+    memcpy(p.D, cam->D, sizeof p.D);
+    p.origin[0] = cam->camera_pose[0]; p.origin[1] = cam->camera_pose[1]; p.origin[2] = cam->camera_pose[2];
+    p.q_cam = euler2quat(v3(cam->inv_camera_pose[3], cam->inv_camera_pose[4], cam->inv_camera_pose[5]));
+    p.inodes = s->d_inodes; p.tris = s->d_tris; p.tri_uv = s->d_tri_uv; p.tri_id = s->d_tri_id;
+    p.leaf_count = s->d_leaf_count;
+    p.instances = s->d_instances; p.materials = s->d_materials;
+    p.num_instances = (int32_t)s->instances.size();
+    p.stack_depth = s->max_stack;
+    p.img = d_img; p.pitch = pitch;
+    p.local_rows = cam->height; p.stripe_rows = cam->height > 0 ? cam->height : 1; p.rank = 0; p.num_ranks = 1;
+}
+
+int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
+{
+    if (p.width <= 0 || p.local_rows < 0) return RT_E_INVALID;
+    if (p.local_rows == 0) return RT_OK;
+    p.tiles_x = (p.width + 15) / 16;
+    p.tiles_y = (p.local_rows + 15) / 16;
+    const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(kBlock);
+    if (debug) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, p);
+    else       hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, stream, p);
+    RT_HIP(hipGetLastError());
+    if (synchronize) RT_HIP(hipStreamSynchronize(stream));
+    return RT_OK;
+}
+
+bool camera_ok(const RtCameraParams* cam) { return cam && cam->width > 0 && cam->height > 0; }
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(int* count)
+{
+    if (!count) return RT_E_INVALID;
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e == hipErrorNoDevice) { *count = 0; return RT_OK; }
+    return (int)e;
+}
+int rt_set_device(int device) { RT_HIP(hipSetDevice(device)); return RT_OK; }
+int rt_malloc(void** dptr, size_t bytes) { if (!dptr) return RT_E_INVALID; RT_HIP(hipMalloc(dptr, bytes ? bytes : 1)); return RT_OK; }
+int rt_malloc_pitch(void** dptr, size_t* pitch, size_t width_bytes, size_t height)
+{
+    if (!dptr || !pitch) return RT_E_INVALID;
+    RT_HIP(hipMallocPitch(dptr, pitch, width_bytes, height));
+    return RT_OK;
+}
+int rt_free(void* dptr) { RT_HIP(hipFree(dptr)); return RT_OK; }
+int rt_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
+{
+    RT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return RT_OK;
+}
+int rt_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    RT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    RT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return RT_OK;
+}
+int rt_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t height, void* stream)
+{
+    RT_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return RT_OK;
+}
+int rt_stream_synchronize(void* stream) { RT_HIP(hipStreamSynchronize((hipStream_t)stream)); return RT_OK; }
+int rt_device_synchronize(void) { RT_HIP(hipDeviceSynchronize()); return RT_OK; }
+
+const char* rt_error_string(int code)
+{
+    switch (code) {
+    case RT_OK: return "ok";
+    case RT_E_INVALID: return "rt: invalid argument";
+    case RT_E_NOMEM: return "rt: out of host memory";
+    case RT_E_DEPTH: return "rt: BVH deeper than the traversal stack";
+    case RT_E_NODEVICE: return "rt: no HIP device";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "rt: unknown error";
+    }
+}
+
+int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
+{
+    if (!desc || !out || desc->num_meshes < 0 || desc->num_materials < 0 || desc->num_instances < 0) return RT_E_INVALID;
+    if ((desc->num_meshes && !desc->meshes) || (desc->num_materials && !desc->materials) ||
+        (desc->num_instances && !desc->instances)) return RT_E_INVALID;
+    *out = nullptr;
+    RtScene* s = new (std::nothrow) RtScene;
+    if (!s) return RT_E_NOMEM;
+    int rc = RT_OK;
+    std::vector<float4> inodes, tris;
+    std::vector<float> tri_uv;
+    std::vector<int32_t> tri_id, leaf_count;
+    try {
+        for (int mi = 0; mi < desc->num_meshes && rc == RT_OK; mi++) {
+            const RtMeshDesc& m = desc->meshes[mi];
+            if (m.num_triangles < 0 || m.num_nodes < 1 || m.num_leaf_indices < 0 || !m.node_bounds || !m.node_children ||
+                !m.node_leaf_first || !m.node_leaf_count ||
+                (m.num_triangles && (!m.vertices || !m.normals || !m.uvs)) || (m.num_leaf_indices && !m.leaf_indices)) {
+                rc = RT_E_INVALID; break;
+            }
+            const int64_t node_base = (int64_t)inodes.size() / 4, slot_base = (int64_t)tri_id.size();
+            if (slot_base + m.num_leaf_indices > kSlotMask) { rc = RT_E_INVALID; break; }
+            // pass 1: entry of every node (interior -> running interior index, leaf -> slot range), levels
+            std::vector<int32_t> entry((size_t)m.num_nodes), level((size_t)m.num_nodes, 0);
+            int64_t n_int = 0, n_slot = 0;
+            int max_level = 1;
+            level[0] = 1;
+            for (int i = 0; i < m.num_nodes && rc == RT_OK; i++) {
+                const int a = m.node_children[2 * i], b = m.node_children[2 * i + 1];
+                if (level[i] == 0) { rc = RT_E_INVALID; break; }          // unreachable or child before parent
+                if (a > 0) {                                               // interior test of raycast.cu:66
+                    if (a <= i || b <= i || a >= m.num_nodes || b >= m.num_nodes || level[a] || level[b] || a == b) { rc = RT_E_INVALID; break; }
+                    level[a] = level[b] = level[i] + 1;
+                    max_level = std::max(max_level, level[i] + 1);
+                    entry[i] = (int32_t)(node_base + n_int++);
+                } else {
+                    const int first = m.node_leaf_first[i], count = m.node_leaf_count[i];
+                    if (count < 0 || first < 0 || (int64_t)first + count > m.num_leaf_indices) { rc = RT_E_INVALID; break; }
+                    entry[i] = leaf_ref(slot_base + n_slot, count);
+                    n_slot += count;
+                }
+            }
+            if (rc != RT_OK) break;
+            if (max_level > kMaxStack) { rc = RT_E_DEPTH; break; }
+            s->max_stack = std::max(s->max_stack, max_level);
+            // pass 2: emit records
+            bool exact_uv = false;
+            inodes.resize(inodes.size() + (size_t)n_int * 4);
+            for (int i = 0; i < m.num_nodes && rc == RT_OK; i++) {
+                const int a = m.node_children[2 * i], b = m.node_children[2 * i + 1];
+                if (a > 0) {
+                    const float* A = m.node_bounds + 6 * (size_t)a;
+                    const float* B = m.node_bounds + 6 * (size_t)b;
+                    float4* q = &inodes[(size_t)entry[i] * 4];
+                    q[0] = make_float4(A[0], A[1], A[2], A[3]);
+                    q[1] = make_float4(A[4], A[5], B[0], B[1]);
+                    q[2] = make_float4(B[2], B[3], B[4], B[5]);
+                    q[3] = make_float4(i2f(entry[a]), i2f(entry[b]), 0.0f, 0.0f);
+                } else {
+                    const int first = m.node_leaf_first[i], count = m.node_leaf_count[i];
+                    for (int k = 0; k < count; k++) {
+                        const int t = m.leaf_indices[first + k];
+                        if (t < 0 || t >= m.num_triangles) { rc = RT_E_INVALID; break; }
+                        const float* v = m.vertices + 9 * (size_t)t;
+                        const float* nn = m.normals + 3 * (size_t)t;
+                        const float* uv = m.uvs + 6 * (size_t)t;
+                        V3 v0 = v3(v[0], v[1], v[2]), v1 = v3(v[3], v[4], v[5]), v2 = v3(v[6], v[7], v[8]);
+                        V3 e0 = v2 - v0, e1 = v1 - v0;                      // TrianglePrimitive.hpp:154-155
+                        float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1);
+                        float inv = 1.0f / (d00 * d11 - d01 * d01);        // TrianglePrimitive.hpp:164
+                        tris.push_back(make_float4(v0.x, v0.y, v0.z, nn[0]));
+                        tris.push_back(make_float4(nn[1], nn[2], e0.x, e0.y));
+                        tris.push_back(make_float4(e0.z, e1.x, e1.y, e1.z));
+                        tris.push_back(make_float4(d00, d01, d11, inv));
+                        for (int c = 0; c < 6; c++) {
+                            tri_uv.push_back(uv[c]);
+                            if (!(fabsf(uv[c]) < 1e37f)) exact_uv = true;  // also catches NaN / inf
+                        }
+                        tri_id.push_back(t);
+                        leaf_count.push_back(k == 0 ? count : 0);
+                    }
+                }
+            }
+            s->mesh_root_ref.push_back(entry[0]);
+            s->mesh_exact_uv.push_back(exact_uv ? 1 : 0);
+        }
+        if (rc == RT_OK) {
+            s->num_materials = desc->num_materials;
+            for (int i = 0; i < desc->num_instances; i++)
+                if (!instance_ok(desc->instances[i], *s)) { rc = RT_E_INVALID; break; }
+            for (int i = 0; i < desc->num_materials; i++) {
+                const RtMaterialDesc& m = desc->materials[i];
+                if (m.texture && (m.texture_width <= 0 || m.texture_height <= 0 || m.texture_pitch < (size_t)m.texture_width * 3)) { rc = RT_E_INVALID; break; }
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        rc = RT_E_NOMEM;
+    }
+    if (rc != RT_OK) { delete s; return rc; }
+
+    // ---- device upload ----
+    auto fail = [&](int code) { rt_scene_destroy(s); return code; };
+    hipError_t he = hipGetDevice(&s->device);
+    if (he != hipSuccess) return fail(he == hipErrorNoDevice ? RT_E_NODEVICE : (int)he);
+    if ((rc = upload(&s->d_inodes, inodes, s->device_bytes))) return fail(rc);
+    if ((rc = upload(&s->d_tris, tris, s->device_bytes))) return fail(rc);
+    if ((rc = upload(&s->d_tri_uv, tri_uv, s->device_bytes))) return fail(rc);
+    if ((rc = upload(&s->d_tri_id, tri_id, s->device_bytes))) return fail(rc);
+    if ((rc = upload(&s->d_leaf_count, leaf_count, s->device_bytes))) return fail(rc);
+    std::vector<DevMaterial> mats((size_t)desc->num_materials);
+    for (int i = 0; i < desc->num_materials; i++) {
+        const RtMaterialDesc& m = desc->materials[i];
+        DevMaterial& d = mats[i];
+        memset(&d, 0, sizeof d);
+        d.albedo[0] = m.albedo[0]; d.albedo[1] = m.albedo[1]; d.albedo[2] = m.albedo[2];
+        if (m.texture && m.texture_width > 0) {
+            // tight device copy (the reference uses cudaMallocPitch + GpuMat::upload, Material.hpp:35-41)
+            const size_t row = (size_t)m.texture_width * 3, bytes = row * (size_t)m.texture_height;
+            uint8_t* dt = nullptr;
+            he = hipMalloc((void**)&dt, bytes);
+            if (he != hipSuccess) return fail((int)he);
+            s->d_textures.push_back(dt);
+            he = hipMemcpy2D(dt, row, m.texture, m.texture_pitch, row, (size_t)m.texture_height, hipMemcpyHostToDevice);
+            if (he != hipSuccess) return fail((int)he);
+            s->device_bytes += bytes;
+            d.texture = dt; d.texture_width = m.texture_width; d.texture_height = m.texture_height; d.texture_pitch = (uint32_t)row;
+        }
+    }
+    if ((rc = upload(&s->d_materials, mats, s->device_bytes))) return fail(rc);
+    for (int i = 0; i < desc->num_instances; i++) s->instances.push_back(make_dev_instance(desc->instances[i], *s));
+    if ((rc = upload(&s->d_instances, s->instances, s->device_bytes))) return fail(rc);
+    *out = s;
+    return RT_OK;
+}
+
+int rt_scene_update_instance(RtScene* s, int32_t index, const RtInstanceDesc* instance)
+{
+    if (!s || !instance || index < 0 || index >= (int)s->instances.size() || !instance_ok(*instance, *s)) return RT_E_INVALID;
+    s->instances[index] = make_dev_instance(*instance, *s);
+    RT_HIP(hipMemcpy(s->d_instances + index, &s->instances[index], sizeof(DevInstance), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_scene_destroy(RtScene* s)
+{
+    if (!s) return RT_OK;
+    (void)hipFree(s->d_inodes); (void)hipFree(s->d_tris); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
+    (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
+    for (uint8_t* t : s->d_textures) (void)hipFree(t);
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_info(const RtScene* s, size_t* device_bytes, int32_t* max_stack)
+{
+    if (!s) return RT_E_INVALID;
+    if (device_bytes) *device_bytes = s->device_bytes;
+    if (max_stack) *max_stack = s->max_stack;
+    return RT_OK;
+}
+
+int rt_render(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, void* stream, int synchronize)
+{
+    if (!s || !camera_ok(cam) || !d_img || pitch < (size_t)cam->width * 3) return RT_E_INVALID;
+    RenderParams p;
+    fill_params(p, s, cam, d_img, pitch);
+    return launch(p, false, (hipStream_t)stream, synchronize);
+}
+
+int rt_render_debug(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch,
+                    const RtDebugPlanes* planes, void* stream, int synchronize)
+{
+    if (!s || !camera_ok(cam) || !d_img || !planes || pitch < (size_t)cam->width * 3) return RT_E_INVALID;
+    RenderParams p;
+    fill_params(p, s, cam, d_img, pitch);
+    p.hit_instance = planes->hit_instance; p.hit_triangle = planes->hit_triangle; p.node_pops = planes->node_pops;
+    p.aabb_tests = planes->aabb_tests; p.tri_tests = planes->tri_tests; p.inside_hits = planes->inside_hits;
+    return launch(p, true, (hipStream_t)stream, synchronize);
+}
+
+int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t* rows)
+{
+    if (!rows || height < 0 || stripe_rows <= 0 || num_ranks <= 0 || rank < 0 || rank >= num_ranks) return RT_E_INVALID;
+    int32_t n = 0;
+    for (int32_t s0 = rank; (int64_t)s0 * stripe_rows < height; s0 += num_ranks)
+        n += std::min(stripe_rows, height - s0 * stripe_rows);
+    *rows = n;
+    return RT_OK;
+}
+
+int rt_render_stripes(RtScene* s, const RtCameraParams* cam, uint8_t* d_local, size_t local_pitch,
+                      int32_t stripe_rows, int32_t rank, int32_t num_ranks, void* stream, int synchronize)
+{
+    int32_t rows = 0;
+    if (!s || !camera_ok(cam) || !d_local || local_pitch < (size_t)cam->width * 3) return RT_E_INVALID;
+    int rc = rt_stripe_rows(cam->height, stripe_rows, rank, num_ranks, &rows);
+    if (rc) return rc;
+    RenderParams p;
+    fill_params(p, s, cam, d_local, local_pitch);
+    p.local_rows = rows; p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
+    return launch(p, false, (hipStream_t)stream, synchronize);
+}
+
+int rt_unstripe(const uint8_t* d_gathered, size_t local_pitch, int32_t max_local_rows, uint8_t* d_img, size_t pitch,
+                int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void* stream)
+{
+    if (!d_gathered || !d_img || width <= 0 || height <= 0 || stripe_rows <= 0 || num_ranks <= 0 ||
+        local_pitch < (size_t)width * 3 || pitch < (size_t)width * 3) return RT_E_INVALID;
+    dim3 grid(4, (unsigned)height), block(256);
+    hipLaunchKernelGGL(unstripe_kernel, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, max_local_rows,
+                       d_img, pitch, width * 3, height, stripe_rows, num_ranks);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_timer_create(RtTimer** t)
+{
+    if (!t) return RT_E_INVALID;
+    RtTimer* r = new (std::nothrow) RtTimer;
+    if (!r) return RT_E_NOMEM;
+    hipError_t e = hipEventCreate(&r->start);
+    if (e == hipSuccess) e = hipEventCreate(&r->stop);
+    if (e != hipSuccess) { delete r; return (int)e; }
+    *t = r;
+    return RT_OK;
+}
+int rt_timer_start(RtTimer* t, void* stream) { if (!t) return RT_E_INVALID; RT_HIP(hipEventRecord(t->start, (hipStream_t)stream)); return RT_OK; }
+int rt_timer_stop(RtTimer* t, void* stream) { if (!t) return RT_E_INVALID; RT_HIP(hipEventRecord(t->stop, (hipStream_t)stream)); return RT_OK; }
+int rt_timer_elapsed_ms(RtTimer* t, float* ms)
+{
+    if (!t || !ms) return RT_E_INVALID;
+    RT_HIP(hipEventSynchronize(t->stop));
+    RT_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+    return RT_OK;
+}
+int rt_timer_destroy(RtTimer* t)
+{
+    if (!t) return RT_OK;
+    (void)hipEventDestroy(t->start); (void)hipEventDestroy(t->stop);
+    delete t;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+/*
+ * rt_hip.h -- C-ABI of librt_hip.so: the MI355X (gfx950) raycast hot path.
+ *
+ * This is the drop-in boundary for the reference's per-pixel raycast.  The reference has no
+ * FFI layer; its boundary is the host C++ that uploads the scene and launches the one
+ * kernel.  Each entry point below names the reference interface it replaces (paths relative
+ * to AFIDclan/cuda-raytracing CudaRaytracer/).  Plain pointers and sizes only; no C++ or
+ * torch types; every function returns 0 on success, a positive hipError_t, or a negative
+ * RT_E_* code, and never throws.  The caller owns image buffers; the library owns scene
+ * buffers.  All `stream` arguments are a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum {
+    RT_OK = 0,
+    RT_E_INVALID = -1,      /* bad argument (null pointer, size, index out of range) */
+    RT_E_NOMEM = -2,
+    RT_E_DEPTH = -3,        /* BVH deeper than the 32-entry traversal stack of raycast.cu:54 */
+    RT_E_NODEVICE = -4
+};
+
+/* One mesh as the reference uploads it: MeshPrimitive::to_device (MeshPrimitive.cpp:17-36) sends
+ * the TrianglePrimitive array (TrianglePrimitive.hpp:8-11) and BVHTree::compile_tree
+ * (BVHTree.hpp:364-383) the d_BVHTree array (BVHTree.hpp:18-26) plus one index list per leaf
+ * (BVHTree.hpp:97-111).  Here the same data arrives flattened; the library re-lays it out for
+ * the GPU (see DESIGN.md "Data layout in HBM").  All pointers are HOST pointers. */
+typedef struct RtMeshDesc {
+    int32_t num_triangles;
+    const float *vertices;          /* [num_triangles][3][3]  TrianglePrimitive::vertices      */
+    const float *normals;           /* [num_triangles][3]     TrianglePrimitive::normal        */
+    const float *uvs;               /* [num_triangles][3][2]  TrianglePrimitive::uv_coords     */
+    int32_t num_nodes;              /* node 0 is the root (MeshPrimitive.cpp:51)               */
+    const float *node_bounds;       /* [num_nodes][6]  min.xyz, max.xyz (d_BVHTree::min/max)   */
+    const int32_t *node_children;   /* [num_nodes][2]  child_index_a/b; -1,-1 for a leaf       */
+    const int32_t *node_leaf_first; /* [num_nodes]     offset of the leaf's list in leaf_indices */
+    const int32_t *node_leaf_count; /* [num_nodes]     d_BVHTree::count_triangles (0 if interior) */
+    int32_t num_leaf_indices;
+    const int32_t *leaf_indices;    /* concatenated d_BVHTree::triangle_indices lists          */
+} RtMeshDesc;
+
+/* Material (Material.hpp:6-16).  texture = host BGR bytes (as cv::imread gives them,
+ * Material.hpp:32) or NULL; texture_width == 0 selects the albedo path (raycast.cu:224). */
+typedef struct RtMaterialDesc {
+    float roughness;
+    float albedo[3];
+    float metallic;
+    float illumination;
+    const uint8_t *texture;
+    int32_t texture_width, texture_height;
+    size_t texture_pitch;
+} RtMaterialDesc;
+
+/* MeshInstance (MeshInstance.hpp:6-18), same field order and meaning; the inverse fields are
+ * what MeshInstance::build_inv (MeshInstance.hpp:39-46) produces. */
+typedef struct RtInstanceDesc {
+    int32_t mesh_index;
+    int32_t material_index;
+    float pose[6];           /* lre: x y z yaw pitch roll (transforms.hpp:10-14) */
+    float inv_pose[6];
+    float rotation[3];
+    float inv_rotation[3];
+    float scale[3];
+    float inv_scale[3];
+} RtInstanceDesc;
+
+typedef struct RtSceneDesc {
+    int32_t num_meshes;     const RtMeshDesc *meshes;
+    int32_t num_materials;  const RtMaterialDesc *materials;
+    int32_t num_instances;  const RtInstanceDesc *instances;
+} RtSceneDesc;
+
+/* The by-value arguments of render<<<>>> (raycast.h:13, Camera.cu:23-36). */
+typedef struct RtCameraParams {
+    int32_t width, height;
+    float K_inv[9];          /* row-major float3x3, invert_intrinsic(K) (utils.hpp:142) */
+    float D[4];
+    float camera_pose[6];    /* lre */
+    float inv_camera_pose[6];/* invert_lre(camera_pose), Camera.cu:21 */
+} RtCameraParams;
+
+/* Optional per-pixel parity planes, tight [height][width] int32 DEVICE buffers, any may be NULL.
+ * hit_* are -1 on a miss; counts follow raycast.cu:61 (pops), :69-70 (aabb tests), :86
+ * (triangle tests), :96 (inside hits). */
+typedef struct RtDebugPlanes {
+    int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;
+} RtDebugPlanes;
+
+typedef struct RtScene RtScene;
+
+/* ---- device / memory plumbing (replaces the cudaMallocPitch / cudaMemcpy / cudaFree /
+ *      cudaDeviceSynchronize calls of kernel.cu:247-253,279,299) ------------------------------ */
+int rt_abi_version(void);
+int rt_device_count(int *count);
+int rt_set_device(int device);
+int rt_malloc(void **dptr, size_t bytes);
+int rt_malloc_pitch(void **dptr, size_t *pitch, size_t width_bytes, size_t height);
+int rt_free(void *dptr);
+int rt_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int rt_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int rt_memcpy2d_d2h(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t height, void *stream);
+int rt_stream_synchronize(void *stream);
+int rt_device_synchronize(void);
+const char *rt_error_string(int code);
+
+/* ---- scene (replaces Scene::upload_to_device, Scene.cpp:25-65, and everything it calls) ---- */
+int rt_scene_upload(const RtSceneDesc *desc, RtScene **out);
+/* Scene::update_mesh_instance (Scene.cpp:67-74): re-upload one instance */
+int rt_scene_update_instance(RtScene *scene, int32_t index, const RtInstanceDesc *instance);
+int rt_scene_destroy(RtScene *scene);
+/* bytes of device memory the scene holds, and the traversal-stack depth it needs */
+int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);
+
+/* ---- render (replaces Camera::render_scene -> render<<<grid, block>>>, Camera.cu:18-41,
+ *      raycast.cu:146-297).  d_img is a caller-owned DEVICE buffer of `height` rows of `pitch`
+ *      bytes, 3 bytes per pixel in uchar3 .x .y .z order (raycast.cu:292-294).  Asynchronous on
+ *      `stream` unless synchronize != 0 (Camera.cu:38-39). ------------------------------------- */
+int rt_render(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch, void *stream, int synchronize);
+/* same frame plus the parity planes */
+int rt_render_debug(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch,
+                    const RtDebugPlanes *planes, void *stream, int synchronize);
+
+/* ---- frame tiling across GPUs (no counterpart in the reference: it is single-GPU).  The frame
+ *      is cut into stripes of `stripe_rows` rows; stripe s belongs to rank s % num_ranks.  A rank
+ *      renders its stripes into a tight local buffer (rows packed in stripe order, pitch =
+ *      local_pitch); rt_stripe_rows() gives that buffer's row count for any rank. ------------- */
+int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t *rows);
+int rt_render_stripes(RtScene *scene, const RtCameraParams *cam, uint8_t *d_local, size_t local_pitch,
+                      int32_t stripe_rows, int32_t rank, int32_t num_ranks, void *stream, int synchronize);
+/* after a gather of every rank's local buffer (each padded to max_local_rows rows of local_pitch
+ * bytes, rank-major) place the rows back into frame order */
+int rt_unstripe(const uint8_t *d_gathered, size_t local_pitch, int32_t max_local_rows,
+                uint8_t *d_img, size_t pitch, int32_t width, int32_t height,
+                int32_t stripe_rows, int32_t num_ranks, void *stream);
+
+/* ---- timing on the stream the kernels run on (hipEvent) ---------------------------------- */
+typedef struct RtTimer RtTimer;
+int rt_timer_create(RtTimer **t);
+int rt_timer_start(RtTimer *t, void *stream);
+int rt_timer_stop(RtTimer *t, void *stream);
+int rt_timer_elapsed_ms(RtTimer *t, float *ms);   /* synchronises on the stop event */
+int rt_timer_destroy(RtTimer *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

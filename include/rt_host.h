@@ -1,0 +1,80 @@
+/*
+ * rt_host.h -- C facade over the host C++ API (Scene / Camera / OBJLoader / MeshPrimitive /
+ * MeshInstance / Material in cuda-raytracing_amd/csrc/host/), for hosts that cannot include
+ * C++ headers (the Python tests and bench.py bind it with ctypes).  Each function names the
+ * reference call it stands for.  Returns 0 / a handle on success; errors are negative RT_E_*
+ * or positive hipError_t codes as in rt_hip.h.  No exceptions cross this boundary.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RthMesh RthMesh;       /* MeshPrimitive */
+typedef struct RthScene RthScene;     /* Scene */
+typedef struct RthCamera RthCamera;   /* Camera */
+
+/* OBJLoader::load(fp) (OBJLoader.hpp:15); NULL on failure, message via rth_last_error() */
+RthMesh *rth_obj_load(const char *path);
+/* MeshPrimitive(std::vector<TrianglePrimitive>) (MeshPrimitive.h:31); tris18 = n x {v0 v1 v2 normal uv0 uv1 uv2} */
+RthMesh *rth_mesh_from_triangles(const float *tris18, int32_t n);
+/* TrianglePrimitive(a, b, c) (TrianglePrimitive.hpp:15): one triangle, normal from the winding */
+RthMesh *rth_mesh_single_triangle(const float *abc9);
+void rth_mesh_free(RthMesh *m);
+int32_t rth_mesh_num_triangles(const RthMesh *m);
+int32_t rth_mesh_num_nodes(const RthMesh *m);
+int32_t rth_mesh_max_level(const RthMesh *m);
+void rth_mesh_get_triangles(const RthMesh *m, float *out18);
+/* boxes [n][6], child [n][2], leaf_count [n] (0 for interior); returns the total of leaf_count */
+int32_t rth_mesh_get_nodes(const RthMesh *m, float *boxes, int32_t *child, int32_t *leaf_count);
+void rth_mesh_get_leaf_indices(const RthMesh *m, int32_t *out);
+/* BVHTree::print_stats (BVHTree.hpp:117) to stdout */
+void rth_mesh_print_stats(const RthMesh *m);
+
+RthScene *rth_scene_create(void);                                                  /* Scene() */
+void rth_scene_free(RthScene *s);
+/* Scene::add_material (Scene.h:19); texture = BGR bytes or NULL */
+int32_t rth_scene_add_material(RthScene *s, const float *albedo3, const uint8_t *texture_bgr, int32_t w, int32_t h, size_t pitch);
+/* Material::upload_texture(path) (Material.hpp:29) then add_material; binary PPM only */
+int32_t rth_scene_add_material_ppm(RthScene *s, const float *albedo3, const char *ppm_path);
+/* Scene::add_mesh (copies the mesh, as the by-value reference call does) */
+int32_t rth_scene_add_mesh(RthScene *s, const RthMesh *m);
+/* Scene::add_mesh_instance(MeshInstance(mesh, material, pose, scale)) */
+int32_t rth_scene_add_mesh_instance(RthScene *s, int32_t mesh, int32_t material, const float *pose6, const float *scale3);
+int rth_scene_upload_to_device(RthScene *s);                                       /* Scene::upload_to_device */
+int rth_scene_update_mesh_instance(RthScene *s, int32_t index, int32_t mesh, int32_t material, const float *pose6, const float *scale3);
+int32_t rth_scene_num_mesh_instances(const RthScene *s);
+/* the RtScene* behind the Scene (for rt_render_debug etc.), NULL before upload */
+void *rth_scene_device_handle(RthScene *s);
+/* MeshInstance::build_inv (MeshInstance.hpp:39): out26 = pose6 inv_pose6 rotation3 inv_rotation3 scale3 inv_scale3 (minus ids) */
+void rth_instance_build(const float *pose6, const float *scale3, float *out24);
+
+RthCamera *rth_camera_create(int32_t width, int32_t height, const float *K9, const float *D4);   /* Camera(w, h, K, D) */
+void rth_camera_free(RthCamera *c);
+void rth_camera_set_pose(RthCamera *c, const float *pose6);                        /* camera.pose = ... */
+void rth_camera_set_stream(RthCamera *c, void *stream);
+/* Camera::render_scene(scene, img_ptr, pitch, synchronize) (Camera.h:25) */
+int rth_camera_render_scene(RthCamera *c, RthScene *s, void *d_img, size_t pitch, int synchronize);
+int rth_camera_render_scene_stripes(RthCamera *c, RthScene *s, void *d_local, size_t local_pitch,
+                                    int32_t stripe_rows, int32_t rank, int32_t num_ranks, int synchronize);
+/* the RtCameraParams (rt_hip.h) the camera would launch with: 1 + 1 + 9 + 4 + 6 + 6 words */
+void rth_camera_params(const RthCamera *c, void *out_RtCameraParams);
+
+/* host math with the reference's names, for parity tests (utils.hpp / transforms.hpp) */
+float rth_q_rsqrt(float x);
+float rth_atanf(float x);                       /* the restated atanf the kernels use */
+void rth_normalize(const float *v3, float *out3);
+void rth_invert_lre(const float *l6, float *out6);
+void rth_apply_lre(const float *l6, const float *v3, float *out3);
+void rth_euler2quat(const float *e3, float *out4);
+void rth_apply_quat(const float *q4, const float *v3, float *out3);
+void rth_invert_intrinsic(const float *K9, float *out9);
+
+const char *rth_last_error(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

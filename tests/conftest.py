@@ -1,0 +1,62 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rt():
+    """The product package with both libraries built (hipcc cross-compiles without a GPU)."""
+    mod = importlib.import_module("cuda-raytracing_amd")
+    mod.build()
+    mod.libs()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    return importlib.import_module("cuda-raytracing_amd.scenes")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import orc as _orc
+    _orc.build_oracle()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def oracle(orc):
+    return orc.oracle()
+
+
+@pytest.fixture(scope="session")
+def cache_dir():
+    d = os.path.join(ROOT, ".scene_cache")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+@pytest.fixture(scope="session")
+def blob70k(scenes, cache_dir):
+    p = os.path.join(cache_dir, "blob70k.obj")
+    if not os.path.exists(p):
+        scenes.write_blob_obj(p, 188, 187)
+    return p
+
+
+@pytest.fixture(scope="session")
+def blob5k(scenes, cache_dir):
+    p = os.path.join(cache_dir, "blob5k.obj")
+    if not os.path.exists(p):
+        scenes.write_blob_obj(p, 50, 51)
+    return p

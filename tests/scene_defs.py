@@ -1,0 +1,95 @@
+"""Scene definitions shared by the parity tests: each builds the SAME scene on the oracle
+(tests/orc.py) and on the product (cuda-raytracing_amd) from one description."""
+import numpy as np
+
+
+def checker_texture(w=64, h=48, seed=7):
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    t[::8, :, :] = 255
+    return t
+
+
+def random_triangles(n, seed, spread=1.0, size=0.25, uv=True):
+    """n random triangles as [n,18] (normal via the 3-vertex constructor of the oracle)."""
+    import orc
+    o = orc.oracle()
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-spread, spread, (n, 1, 3)).astype(np.float32)
+    v = (c + rng.uniform(-size, size, (n, 3, 3))).astype(np.float32)
+    out = np.zeros((n, 18), np.float32)
+    for i in range(n):
+        out[i] = o.tri_from_vertices(v[i].ravel())
+    if uv:
+        out[:, 12:18] = rng.uniform(0, 1, (n, 6)).astype(np.float32)
+    return out
+
+
+class SceneDesc:
+    """materials: list of (albedo, texture or None); meshes: list of ('obj', path) | ('tris', array[n,18]) |
+    ('tri3', abc9); instances: list of (mesh, material, pose6, scale3)."""
+
+    def __init__(self, materials, meshes, instances):
+        self.materials, self.meshes, self.instances = materials, meshes, instances
+
+    def build_oracle(self, orc):
+        o = orc.oracle()
+        s = orc.OracleScene(o)
+        for albedo, tex in self.materials:
+            s.add_material(albedo, tex)
+        self.oracle_meshes = []
+        for kind, arg in self.meshes:
+            if kind == "obj":
+                m = o.obj_load(arg)
+            elif kind == "tris":
+                m = o.mesh_from_triangles(arg)
+            else:
+                m = o.mesh_single_triangle(arg)
+            assert m, "oracle mesh build failed"
+            self.oracle_meshes.append(m)
+            s.add_mesh(m)
+        for mesh, mat, pose, scale in self.instances:
+            s.add_instance(mesh, mat, pose, scale)
+        return s
+
+    def build_product(self, rt):
+        s = rt.Scene()
+        for albedo, tex in self.materials:
+            s.add_material(albedo, texture_bgr=tex)
+        self.product_meshes = []
+        for kind, arg in self.meshes:
+            if kind == "obj":
+                m = rt.Mesh.load_obj(arg)
+            elif kind == "tris":
+                m = rt.Mesh.from_triangles(arg)
+            else:
+                m = rt.Mesh.single_triangle(arg)
+            self.product_meshes.append(m)
+            s.add_mesh(m)
+        for mesh, mat, pose, scale in self.instances:
+            s.add_mesh_instance(mesh, mat, pose, scale)
+        return s
+
+
+def c1_scene(scenes):
+    return SceneDesc([(scenes.C1["albedo"], None)], [("tri3", [-1, 0, -1, 1, 0, -1, 0, 0, 1])], [(0, 0, (0,) * 6, (1, 1, 1))])
+
+
+def blob_scene(scenes, path, albedo=None):
+    return SceneDesc([(albedo or scenes.C2["albedo"], None)], [("obj", path)], [(0, 0, (0,) * 6, (1, 1, 1))])
+
+
+def multi_instance_scene(scenes, blob_path):
+    """Two meshes, three instances with rotation + non-uniform scale, a textured material and an
+    albedo material (exercises raycast.cu:33-51, :98-122, :224-245)."""
+    tex = checker_texture()
+    tris = random_triangles(300, seed=11, spread=0.8, size=0.3)
+    return SceneDesc(
+        [((0.9, 0.5, 0.2), None), ((1.0, 1.0, 1.0), tex), ((0.2, 0.7, 0.4), None)],
+        [("obj", blob_path), ("tris", tris)],
+        [(0, 1, (0.2, 0.5, -0.1, 0.7, 0.3, -0.4), (0.6, 1.1, 0.8)),
+         (1, 0, (-1.5, 1.0, 0.3, -0.2, 0.1, 0.9), (1.3, 0.7, 1.0)),
+         (0, 2, (1.6, 1.5, 0.4, 0.0, 0.0, 0.0), (0.5, 0.5, 0.5))])
+
+
+MULTI_CAMERA = dict(width=320, height=200, pose=(0.1, -3.0, 0.4, 0.15, -0.05, 0.1))

@@ -1,0 +1,152 @@
+"""GPU parity: the HIP path (through the C-ABI, driven by the host C++ API) against the CPU oracle
+on the same scene, camera and pixels.  Bit-exact: RGB bytes, hit (instance, triangle) ids,
+node-pop / AABB-test / triangle-test / inside-hit counts per pixel."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import scene_defs as sd
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+PLANES = ("hit_inst", "hit_tri", "pops", "aabb", "tris", "inside")
+
+
+def _camera(rt, scenes, width, height, K, pose):
+    cam = rt.Camera(width, height, K, scenes.D_REF)
+    cam.set_pose(pose)
+    return cam
+
+
+def _compare(rt, orc, desc, width, height, K, D, pose, threads=8):
+    so = desc.build_oracle(orc)
+    ref = so.render(width, height, K, D, pose, threads=threads)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(width, height, K, D)
+    cam.set_pose(pose)
+    dbg = rt.render_debug(sp, cam)
+    img = rt.render(sp, cam)
+    assert np.array_equal(img, dbg["img"]), "debug and production kernels disagree"
+    nbad = int((img != ref["img"]).any(axis=2).sum())
+    assert nbad == 0, "%d pixels differ from the oracle" % nbad
+    for n in PLANES:
+        bad = int((dbg[n] != ref[n]).sum())
+        assert bad == 0, "%s: %d pixels differ from the oracle" % (n, bad)
+    so.close()
+    return img, ref
+
+
+def test_c1_single_triangle(rt, orc, scenes):
+    """BASELINE.json configs[0]; frame hash and hit count recorded in SURVEY.md section 4."""
+    c = scenes.C1
+    img, ref = _compare(rt, orc, sd.c1_scene(scenes), c["width"], c["height"], c["K"], c["D"], c["cam_pose"])
+    assert ref["stats"]["hits"] == 1870
+    assert orc.fnv1a64(img) == "6b05ef62c4ffefb7"
+    assert tuple(img[128, 128]) == (255, 204, 153)          # NaN ray at the principal point renders sky (H5)
+
+
+@pytest.mark.parametrize("cam", ["far", "mid", "near"])
+def test_blob5k_small(rt, orc, scenes, blob5k, cam):
+    _compare(rt, orc, sd.blob_scene(scenes, blob5k), 480, 270, scenes.scaled_K(480), scenes.D_REF, scenes.C2_CAMERAS[cam])
+
+
+@pytest.mark.parametrize("cam,fnv", [("far", "1987bc58fc5f9ed0"), ("mid", "a85de3d252fa5a4f"), ("near", "c78e8858fb3f7613")])
+def test_c2_blob70k_1080p(rt, orc, scenes, blob70k, cam, fnv):
+    """BASELINE.json configs[1] at full size: every pixel against the oracle, and the frame hash
+    against the one SURVEY.md 8(d) recorded from the reference's own render()."""
+    c = scenes.C2
+    img, _ = _compare(rt, orc, sd.blob_scene(scenes, blob70k), c["width"], c["height"], scenes.scaled_K(c["width"]),
+                      c["D"], scenes.C2_CAMERAS[cam], threads=16)
+    assert orc.fnv1a64(img) == fnv
+
+
+def test_multi_instance_textured(rt, orc, scenes, blob5k):
+    m = sd.MULTI_CAMERA
+    _compare(rt, orc, sd.multi_instance_scene(scenes, blob5k), m["width"], m["height"], scenes.scaled_K(m["width"]),
+             scenes.D_REF, m["pose"])
+
+
+def test_ragged_sizes(rt, orc, scenes, blob5k):
+    """Widths/heights that are not multiples of the 16x16 tile, down to 1x1."""
+    for w, h in [(1, 1), (17, 9), (250, 131)]:
+        _compare(rt, orc, sd.blob_scene(scenes, blob5k), w, h, scenes.scaled_K(w), scenes.D_REF, scenes.C2_CAMERAS["mid"])
+
+
+def test_large_leaves_and_duplicates(rt, orc, scenes):
+    """Coincident triangles cannot be split by centroid: leaves with > 30 triangles (leaf_count lookup path)
+    and equal-distance candidates (first visited wins, raycast.cu:109)."""
+    base = sd.random_triangles(6, seed=3, spread=0.5, size=0.6)
+    tris = np.concatenate([np.repeat(base[:1], 40, axis=0), np.repeat(base[1:2], 33, axis=0), base[2:]])
+    d = sd.SceneDesc([((0.3, 0.6, 0.9), None)], [("tris", tris)], [(0, 0, (0,) * 6, (1, 1, 1))])
+    _compare(rt, orc, d, 160, 120, scenes.scaled_K(160), scenes.D_REF, (0.0, -2.5, 0.0, 0, 0, 0))
+
+
+def test_exact_uv_path(rt, orc, scenes):
+    """uv values near FLT_MAX switch the kernel to the per-candidate uv test of raycast.cu:96."""
+    tris = sd.random_triangles(50, seed=5, spread=0.6, size=0.5)
+    tris[::3, 12] = 3.0e38
+    tris[1::7, 14] = np.float32(np.finfo(np.float32).max)
+    d = sd.SceneDesc([((0.8, 0.8, 0.1), None)], [("tris", tris)], [(0, 0, (0,) * 6, (1, 1, 1))])
+    _compare(rt, orc, d, 160, 120, scenes.scaled_K(160), scenes.D_REF, (0.0, -2.5, 0.0, 0, 0, 0))
+
+
+def test_empty_and_missing(rt, orc, scenes):
+    """Empty mesh, and a scene with no instances: all sky."""
+    d = sd.SceneDesc([((1, 1, 1), None)], [("tris", np.zeros((0, 18), np.float32))], [(0, 0, (0,) * 6, (1, 1, 1))])
+    img, _ = _compare(rt, orc, d, 64, 48, scenes.scaled_K(64), scenes.D_REF, (0, -3, 0, 0, 0, 0))
+    assert (img == np.array([255, 204, 153], np.uint8)).all()
+    d2 = sd.SceneDesc([((1, 1, 1), None)], [("tris", np.zeros((0, 18), np.float32))], [])
+    img, _ = _compare(rt, orc, d2, 64, 48, scenes.scaled_K(64), scenes.D_REF, (0, -3, 0, 0, 0, 0))
+    assert (img == np.array([255, 204, 153], np.uint8)).all()
+
+
+def test_update_mesh_instance(rt, orc, scenes, blob5k):
+    """Scene::update_mesh_instance (Scene.cpp:67-74): re-pose one instance, render again."""
+    desc = sd.multi_instance_scene(scenes, blob5k)
+    m = sd.MULTI_CAMERA
+    K = scenes.scaled_K(m["width"])
+    so = desc.build_oracle(orc)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = _camera(rt, scenes, m["width"], m["height"], K, m["pose"])
+    new_pose, new_scale = (0.4, 0.2, 0.0, -0.3, 0.2, 0.5), (0.9, 0.8, 1.2)
+    so.update_instance(0, 0, 2, new_pose, new_scale)
+    sp.update_mesh_instance(0, 0, 2, new_pose, new_scale)
+    ref = so.render(m["width"], m["height"], K, scenes.D_REF, m["pose"], threads=8)
+    dbg = rt.render_debug(sp, cam)
+    assert np.array_equal(dbg["img"], ref["img"])
+    for n in PLANES:
+        assert np.array_equal(dbg[n], ref[n]), n
+
+
+def test_stripes_equal_full_frame(rt, orc, scenes, blob5k):
+    """Frame tiling: for 1, 2, 3, 4, 8 virtual ranks the un-striped gather equals the 1-GPU frame byte for byte."""
+    import ctypes as C
+    h = rt.libs()[0]
+    W, H = 322, 203
+    sp = sd.blob_scene(scenes, blob5k).build_product(rt)
+    sp.upload_to_device()
+    cam = _camera(rt, scenes, W, H, scenes.scaled_K(W), scenes.C2_CAMERAS["mid"])
+    full = rt.render(sp, cam)
+    for nr, stripe in [(1, 16), (2, 16), (3, 8), (4, 16), (8, 16), (8, 7)]:
+        rows = []
+        for r in range(nr):
+            n = C.c_int32(0)
+            rt.check(h.rt_stripe_rows(H, stripe, r, nr, C.byref(n)))
+            rows.append(n.value)
+        assert sum(rows) == H
+        maxr = max(rows)
+        pitch = W * 3
+        gathered = rt.DeviceBuffer(nbytes=nr * maxr * pitch)
+        for r in range(nr):
+            cam.render_scene_stripes(sp, gathered.ptr.value + r * maxr * pitch, pitch, stripe, r, nr, synchronize=True)
+        out = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+        rt.check(h.rt_unstripe(gathered.ptr, pitch, maxr, out.ptr, out.pitch, W, H, stripe, nr, None))
+        rt.check(h.rt_device_synchronize())
+        got = out.to_host().reshape(H, W, 3)
+        assert np.array_equal(got, full), "stripes nr=%d stripe=%d" % (nr, stripe)
+        gathered.free()
+        out.free()
