@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the raycast hot path on MI355X.
+
+One "step" = one frame of the workload BASELINE.json's metric is quoted on (configs[1]): the
+69 936-triangle synthetic "bunny-class" OBJ, 1920x1080, 1 primary ray per pixel (the reference
+casts exactly one ray per pixel: raycast.cu:204), scene resident in HBM before timing starts.
+
+  python bench.py [--gpus N --steps K --warmup W] [--camera far|mid|near] [--no-cpu-baseline]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the scene is replicated, the frame
+is cut into 16-row stripes dealt round-robin to the ranks (rt_render_stripes), and every frame
+ends with an RCCL gather of the stripes to rank 0 plus rt_unstripe -- total work is fixed, so
+"scaling" is "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch                      # imported BEFORE librt_hip.so so both share one HIP runtime
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+rt = importlib.import_module("cuda-raytracing_amd")
+scenes = importlib.import_module("cuda-raytracing_amd.scenes")
+tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STRIPE_ROWS = 16
+
+
+def algorithmic_bytes(st):
+    """bytes = 24*N_aabb + 8*N_interior_pops + 8*N_leaf_pops + 52*N_tri_tests
+    + 24*N_inside_hits + 3*rays, N_interior_pops = N_aabb / 2."""
+    interior = st["aabb"] // 2
+    leaf = st["pops"] - interior
+    return 24 * st["aabb"] + 8 * interior + 8 * leaf + 52 * st["tris"] + 24 * st["inside"] + 3 * st["rays"]
+
+
+def scene_path():
+    d = os.path.join(ROOT, ".scene_cache")
+    os.makedirs(d, exist_ok=True)
+    p = os.path.join(d, "blob70k.obj")
+    if not os.path.exists(p):
+        scenes.write_blob_obj(p, *scenes.blob_dims_for(scenes.C2["n_tris"]))
+    return p
+
+
+def cpu_baseline(obj, W, H, K, D, pose, gpu_stats):
+    """The oracle (oracle/rt_oracle.c, kind "port") timed on this host: one full frame of the same
+    workload, single-threaded and on all cores (row bands).  Also cross-checks the GPU's counters."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    orc.build_oracle()
+    o = orc.oracle()
+    m = o.obj_load(obj)
+    s = orc.OracleScene(o)
+    s.add_material(scenes.C2["albedo"])
+    s.add_mesh(m)
+    s.add_instance(0, 0)
+    rows1 = max(8, H // 8)                                 # 1/8 of the frame, centred, single thread
+    y0 = (H - rows1) // 2
+    t = time.perf_counter()
+    s.render(W, H, K, D, pose, y0=y0, y1=y0 + rows1, planes=False, threads=1)
+    t1 = time.perf_counter() - t
+    cores = min(os.cpu_count() or 1, 32)
+    reps, tn = 0, 0.0
+    full = None
+    while tn < 10.0 and reps < 20:                         # ~10 s of all-core work
+        t = time.perf_counter()
+        full = s.render(W, H, K, D, pose, planes=False, threads=cores)
+        tn += time.perf_counter() - t
+        reps += 1
+    st = full["stats"]
+    counters_match = all(int(st[k]) == int(gpu_stats[k]) for k in ("pops", "aabb", "tris", "inside"))
+    s.close()
+    return {"value": round(W * H * reps / tn / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d full %dx%d frames of the same scene/camera, row bands over %d threads" % (reps, W, H, cores),
+            "value_1core": round(W * rows1 / t1 / 1e6, 3), "sample_1core": "%d centre rows, 1 thread" % rows1,
+            "gpu_counters_match_oracle": bool(counters_match)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
+    ap.add_argument("--width", type=int, default=scenes.C2["width"])
+    ap.add_argument("--height", type=int, default=scenes.C2["height"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rt.build()
+    rt.libs()
+    W, H = args.width, args.height
+    K, D, pose = scenes.scaled_K(W), scenes.D_REF, scenes.C2_CAMERAS[args.camera]
+    obj = scene_path() if rank == 0 else None
+    if world > 1:
+        dist.barrier()
+        obj = scene_path()
+
+    # ---- scene: the reference's call sequence (kernel.cu:166-243) through the host C++ API ----
+    mesh = rt.Mesh.load_obj(obj)
+    scene = rt.Scene()
+    scene.add_material(scenes.C2["albedo"])
+    scene.add_mesh(mesh)
+    scene.add_mesh_instance(0, 0)
+    scene.upload_to_device()
+    cam = rt.Camera(W, H, K, D)
+    cam.set_pose(pose)
+    stream = torch.cuda.current_stream().cuda_stream
+    cam.set_stream(stream)
+
+    pitch = W * 3
+    frame = torch.empty((H, pitch), dtype=torch.uint8, device=dev)
+    hlib = rt.libs()[0]
+    if world > 1:
+        rows = []
+        for r in range(world):
+            n = C.c_int32(0)
+            rt.check(hlib.rt_stripe_rows(H, STRIPE_ROWS, r, world, C.byref(n)))
+            rows.append(n.value)
+        max_rows = max(rows)
+        local = [torch.zeros((max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world, max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
+
+    timer = rt.Timer()
+
+    def render_local(b):
+        cam.render_scene_stripes(scene, local[b].data_ptr(), pitch, STRIPE_ROWS, rank, world)
+
+    def unstripe(b):
+        rt.check(hlib.rt_unstripe(gathered[b].data_ptr(), pitch, max_rows, frame.data_ptr(), pitch, W, H, STRIPE_ROWS, world,
+                                  torch.cuda.current_stream().cuda_stream))
+
+    pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe) if world > 1 else None
+
+    def step(i):
+        if world == 1:
+            cam.render_scene(scene, frame.data_ptr(), pitch)
+        else:
+            pipe.step(i)
+
+    def sync():
+        if world > 1:
+            pipe.drain()
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- kernel-only duration with hipEvents on the launch stream (roofline numerator) ----
+    kernel_ms = None
+    if rank == 0:
+        n = max(10, min(args.steps, 100))
+        sync_local = torch.cuda.synchronize
+        sync_local()
+        timer.start(stream)
+        for _ in range(n):
+            if world == 1:
+                cam.render_scene(scene, frame.data_ptr(), pitch)
+            else:
+                cam.render_scene_stripes(scene, local[0].data_ptr(), pitch, STRIPE_ROWS, rank, world)
+        timer.stop(stream)
+        kernel_ms = timer.elapsed_ms() / n
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        # ---- per-frame work counters from the debug kernel (same traversal, extra stores) ----
+        dbg = rt.render_debug(scene, cam)
+        st = {"rays": W * H, "pops": int(dbg["pops"].sum()), "aabb": int(dbg["aabb"].sum()), "tris": int(dbg["tris"].sum()),
+              "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
+        frame_host = frame.cpu().numpy().reshape(H, W, 3)
+        frame_ok = bool(np.array_equal(frame_host, dbg["img"]))
+        alg_bytes = algorithmic_bytes(st)
+        share = 1.0 / world                                 # rank 0's stripes ~ 1/N of the frame's work
+        achieved = alg_bytes * share / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("%s_%dx%d" % (args.camera, W, H), {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/sec + ms/frame, 70k-tri OBJ at 1920x1080 1spp; 1/2/4/8 MI355X",
+            "value": round(W * H * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"
+                                   % (W, H, args.camera, str(tuple(pose[:3]))),
+                       "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
+                                      % (STRIPE_ROWS, world, ", RCCL gather to rank 0" if world > 1 else ""),
+                       "coverage": round(st["hits"] / st["rays"], 4),
+                       "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
+                       "algorithmic_bytes_per_ray": round(alg_bytes / st["rays"], 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "render_kernel<false>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes * share)},
+            "frame_matches_debug_kernel": frame_ok,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(obj, W, H, K, D, pose, st)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

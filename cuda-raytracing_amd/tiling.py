@@ -1,0 +1,81 @@
+"""Frame tiling across ranks: stripe bookkeeping and the per-frame gather.  The same code drives
+bench.py on N GPUs (backend nccl = RCCL, device tensors) and the world_size-2 gloo test on CPU."""
+import numpy as np
+
+
+def stripe_rows(height, stripe, rank, world):
+    """Rows rank `rank` owns: stripes s with s % world == rank (mirror of rt_stripe_rows)."""
+    n = 0
+    s = rank
+    while s * stripe < height:
+        n += min(stripe, height - s * stripe)
+        s += world
+    return n
+
+
+def frame_rows_of(height, stripe, rank, world):
+    """Frame row index of every local row of `rank`, in local order."""
+    rows = []
+    s = rank
+    while s * stripe < height:
+        rows.extend(range(s * stripe, min((s + 1) * stripe, height)))
+        s += world
+    return np.asarray(rows, np.int64)
+
+
+def unstripe_host(gathered, height, stripe, world):
+    """gathered[world, max_rows, pitch] (rank-major, padded) -> frame[height, pitch]; host mirror of rt_unstripe."""
+    out = np.zeros((height, gathered.shape[2]), gathered.dtype)
+    for r in range(world):
+        fr = frame_rows_of(height, stripe, r, world)
+        out[fr] = gathered[r, :len(fr)]
+    return out
+
+
+def gather_stripes(local, gathered, rank, dst=0):
+    """One frame's exchange step: every rank's padded local stripe buffer to rank `dst`.
+    local: [max_rows, pitch] uint8 tensor; gathered: [world, max_rows, pitch] on dst, None elsewhere."""
+    import torch.distributed as dist
+    if rank == dst:
+        dist.gather(local, list(gathered.unbind(0)), dst=dst)
+    else:
+        dist.gather(local, None, dst=dst)
+
+
+class StripePipeline:
+    """Double-buffered frame loop for N ranks: while frame i's stripes are being gathered (on the
+    collective's own stream), frame i+1 is already rendering.  render_fn(b) renders this rank's stripes
+    into local buffer b; unstripe_fn(b) (rank `dst` only) turns gathered buffer b into the frame.
+    Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, rank, world, local, gathered, render_fn, unstripe_fn, dst=0):
+        self.rank, self.world, self.dst = rank, world, dst
+        self.local, self.gathered = local, gathered
+        self.render_fn, self.unstripe_fn = render_fn, unstripe_fn
+        self.pending = [None, None]
+        self.frames_done = 0
+
+    def _finish(self, b):
+        work = self.pending[b]
+        if work is None:
+            return
+        work.wait()                       # stream-ordered for nccl: later work on the current stream waits for the gather
+        if self.rank == self.dst:
+            self.unstripe_fn(b)
+        self.pending[b] = None
+        self.frames_done += 1
+
+    def step(self, i):
+        import torch.distributed as dist
+        b = i & 1
+        self._finish(b)                   # buffer b was last used by frame i-2
+        self.render_fn(b)
+        if self.rank == self.dst:
+            self.pending[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=self.dst, async_op=True)
+        else:
+            self.pending[b] = dist.gather(self.local[b], None, dst=self.dst, async_op=True)
+        self._finish(b ^ 1)               # frame i-1: its gather overlapped this frame's render
+
+    def drain(self):
+        self._finish(0)
+        self._finish(1)

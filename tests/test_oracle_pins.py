@@ -1,0 +1,189 @@
+"""The oracle (oracle/rt_oracle.c) against everything that pins it:
+  * golden vectors generated from the REFERENCE's own headers (tests/golden/make_golden.py, via
+    oracle/_ref/libref_probe.so) -- L0 math, AABB slab, triangle tests, BVH topology, OBJ loading;
+  * the known-answer values and full-frame hashes SURVEY.md recorded from the reference's render();
+  * when oracle/_ref is present (build container), the reference code itself on fresh random inputs."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def same(a, b):
+    return np.array_equal(bits(a), bits(b))
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(GOLDEN, "l0_math.npz"))
+
+
+@pytest.fixture(scope="module")
+def pins():
+    return json.load(open(os.path.join(GOLDEN, "pins.json")))
+
+
+def test_rsqrt_kat(oracle, pins):
+    k = pins["rsqrt_kat_hex"]
+    got = ["%08x" % int(bits([oracle.q_rsqrt(x)])[0]) for x in k["inputs"]]
+    assert got == k["bits"]
+
+
+def test_l0_math_golden(oracle, g):
+    o = oracle
+    assert same([o.q_rsqrt(float(v)) for v in g["rsqrt_in"]], g["rsqrt_out"])
+    assert same(np.stack([o.normalize(v) for v in g["vec_in"]]), g["normalize_out"])
+    assert same([o.magnitude(v) for v in g["vec_in"]], g["magnitude_out"])
+    P, V = g["pose_in"], g["pose_vec_in"]
+    assert same(np.stack([o.invert_lre(p) for p in P]), g["invert_lre_out"])
+    assert same(np.stack([o.lre2homo(p) for p in P]), g["lre2homo_out"])
+    assert same(np.stack([o.euler2quat(p[3:]) for p in P]), g["euler2quat_out"])
+    assert same(np.stack([o.apply_lre(p, v) for p, v in zip(P, V)]), g["apply_lre_out"])
+    assert same(np.stack([o.apply_euler(p[3:], v) for p, v in zip(P, V)]), g["apply_euler_out"])
+    assert same(np.stack([o.invert_intrinsic(k) for k in g["K_in"]]), g["invert_intrinsic_out"])
+
+
+def test_survey_kats(oracle):
+    """SURVEY.md section 4 known-answer rows."""
+    o = oracle
+    np.testing.assert_allclose(o.normalize([3, 4, 12]), [0.230371147, 0.30716154, 0.92148459], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(o.invert_lre([1, 2, 3, 0.3, -0.2, 0.1]),
+                               [-0.0251887739, -1.56620836, -3.3979938, -0.322609663, 0.160027221, -0.156419501], rtol=2e-7)
+    np.testing.assert_allclose(o.apply_lre([1, 2, 3, 0.3, -0.2, 0.1], [0.5, -1.5, 2.5]), [0.672042012, -3.3225069, -1.12218881], rtol=2e-7)
+    np.testing.assert_allclose(o.invert_lre([-1, -4, 2, 0, 0, 0]), [1, 4, -2, 0, 0, 0], atol=0)
+
+
+def test_aabb_and_triangle_golden(oracle, g):
+    o = oracle
+    A = g["aabb_in"]
+    got = np.array([o.aabb(a[0:3], a[3:6], a[6:9], a[9:12]) for a in A], np.float32)
+    assert same(got, g["aabb_out"])
+    assert (got == np.float32(3.4028234663852886e38)).sum() > 20          # misses are present
+    # 3-vertex constructor: vertices + normal (the reference leaves uv_coords uninitialised, so only 12 floats are pinned)
+    built = np.stack([o.tri_from_vertices(a) for a in g["tri_abc_in"]])
+    assert same(built[:, :12], g["tri_from_vertices_out"][:, :12])
+    T, R = g["tri_from_vertices_out"], g["tri_ray_in"]
+    tt = np.stack([o.tri_test(t, r[:3], r[3:]) for t, r in zip(T, R)])
+    assert same(tt, g["tri_test_out"])
+    inside = (tt[:, 3] != np.float32(3.4028234663852886e38)).sum()
+    assert 20 < inside < len(T)                                             # both outcomes exercised
+    assert same(np.stack([o.tri_center(t) for t in T]), g["tri_center_out"])
+
+
+def _mesh_equal(d, e):
+    for k in ("boxes", "tris"):
+        if k in e:
+            assert same(d[k], e[k]), k
+    for k in ("child", "leaf_count", "leaf_idx"):
+        assert np.array_equal(d[k], e[k]), k
+
+
+def test_bvh_topology_golden(oracle, scenes, blob5k, pins):
+    assert hashlib.sha256(open(blob5k, "rb").read()).hexdigest() == pins["frames"]["blob5k_obj_sha256"]
+    d = oracle.mesh_dump(oracle.obj_load(blob5k))
+    e = np.load(os.path.join(GOLDEN, "blob5k_bvh.npz"))
+    assert d["child"].shape[0] == pins["blob5k_num_nodes"] and d["tris"].shape[0] == pins["blob5k_num_tris"]
+    _mesh_equal(d, {k: e[k] for k in ("child", "leaf_count", "leaf_idx")})
+    assert hashlib.sha256(d["tris"].tobytes()).hexdigest() == pins["blob5k_tris_sha256"]
+    assert hashlib.sha256(d["boxes"].tobytes()).hexdigest() == pins["blob5k_boxes_sha256"]
+    assert same(d["boxes"][:64], e["boxes_head"]) and same(d["tris"][:64], e["tris_head"])
+
+
+def test_obj_loader_golden(oracle):
+    d = oracle.mesh_dump(oracle.obj_load(os.path.join(GOLDEN, "small_mixed.obj")))
+    e = np.load(os.path.join(GOLDEN, "small_mixed_mesh.npz"))
+    assert d["tris"].shape[0] == 8                                           # quad + tri + tri + pentagon + tri
+    _mesh_equal(d, e)
+
+
+def test_unsplittable_leaf_golden(oracle):
+    e = np.load(os.path.join(GOLDEN, "soup_mesh.npz"))
+    d = oracle.mesh_dump(oracle.mesh_from_triangles(e["tris_in"]))
+    _mesh_equal(d, {k: e[k] for k in ("boxes", "child", "leaf_count", "leaf_idx")})
+    assert d["leaf_count"].max() >= 35
+
+
+def test_obj_errors(oracle, tmp_path):
+    assert not oracle.obj_load(str(tmp_path / "missing.obj"))
+    p = tmp_path / "vn_only.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    assert not oracle.obj_load(str(p))                                       # stoi("/1") throws in the reference (H11)
+    q = tmp_path / "range.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nf 1 2 3\n")
+    assert not oracle.obj_load(str(q))
+
+
+def test_c1_frame_pin(orc, scenes, pins):
+    """BASELINE.json configs[0]: the reference's own CPU-runnable case; hash from SURVEY.md section 4."""
+    import scene_defs as sd
+    c = scenes.C1
+    s = sd.c1_scene(scenes).build_oracle(orc)
+    out = s.render(c["width"], c["height"], c["K"], c["D"], c["cam_pose"])
+    pin = pins["frames"]["C1_256x256"]
+    assert out["stats"]["hits"] == pin["hit_pixels"]
+    assert orc.fnv1a64(out["img"]) == pin["fnv1a64"]
+    hit = out["hit_tri"] >= 0
+    ys, xs = np.nonzero(hit)
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (97, 159, 98, 159)
+    assert (out["img"][hit] == np.array([25, 51, 229], np.uint8)).all()
+    assert tuple(out["img"][128, 128]) == (255, 204, 153)
+    s.close()
+
+
+@pytest.mark.parametrize("cam", ["far", "mid", "near"])
+def test_c2_frame_pins(orc, scenes, blob70k, pins, cam):
+    """BASELINE.json configs[1] at full size: oracle frame hash == the hash SURVEY.md 8(d) recorded
+    from the reference's render() on the byte-identical OBJ."""
+    import scene_defs as sd
+    assert hashlib.sha256(open(blob70k, "rb").read()).hexdigest() == pins["frames"]["blob70k_obj_sha256"]
+    s = sd.blob_scene(scenes, blob70k).build_oracle(orc)
+    c = scenes.C2
+    out = s.render(c["width"], c["height"], scenes.scaled_K(c["width"]), c["D"], scenes.C2_CAMERAS[cam], planes=False, threads=8)
+    assert orc.fnv1a64(out["img"]) == pins["frames"]["C2_%s_1920x1080" % cam]["fnv1a64"]
+    s.close()
+
+
+def test_blob70k_bvh_stats(orc, oracle, blob70k, pins):
+    st = oracle.mesh_stats(oracle.obj_load(blob70k))
+    p = pins["frames"]["blob70k_bvh"]
+    assert (st["nodes"], st["leaves"], st["max_tris"], st["max_depth"]) == (p["nodes"], p["leaves"], p["max_tris_per_leaf"], p["print_stats_max_depth"])
+
+
+# ---- live comparison with the reference's own code (only where oracle/_ref was built) -----------------
+
+def test_oracle_vs_reference_live(orc, oracle):
+    r = orc.ref_probe()
+    if r is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(99)
+    for _ in range(300):
+        p = np.concatenate([rng.uniform(-5, 5, 3), rng.uniform(-3.2, 3.2, 3)]).astype(np.float32)
+        v = rng.normal(0, 2, 3).astype(np.float32)
+        assert same(oracle.invert_lre(p), r.invert_lre(p))
+        assert same(oracle.apply_lre(p, v), r.apply_lre(p, v))
+        assert same(oracle.normalize(v), r.normalize(v))
+        bmin = rng.uniform(-2, 1, 3).astype(np.float32)
+        bmax = (bmin + rng.uniform(0, 2, 3)).astype(np.float32)
+        o3, d3 = rng.uniform(-4, 4, 3).astype(np.float32), rng.normal(0, 1, 3).astype(np.float32)
+        assert same(oracle.aabb(bmin, bmax, o3, d3), r.aabb(bmin, bmax, o3, d3))
+        t = oracle.tri_from_vertices(rng.uniform(-1, 1, 9).astype(np.float32))
+        assert same(t[:12], r.tri_from_vertices(t[:9])[:12])
+        assert same(oracle.tri_test(t, o3, d3), r.tri_test(t, o3, d3))
+
+
+def test_oracle_bvh_vs_reference_live(orc, oracle):
+    r = orc.ref_probe()
+    if r is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    import scene_defs as sd
+    for seed, n in [(1, 1), (2, 2), (3, 17), (4, 900)]:
+        tris = sd.random_triangles(n, seed=seed)
+        _mesh_equal(oracle.mesh_dump(oracle.mesh_from_triangles(tris)), r.mesh_dump(r.mesh_from_triangles(tris)))

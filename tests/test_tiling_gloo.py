@@ -1,0 +1,118 @@
+"""N > 1 path on CPU: two gloo ranks render their stripes (with the oracle standing in for the GPU
+kernel -- the stripe bookkeeping and the gather protocol are what is under test), gather to rank 0
+with the same helper bench.py uses over RCCL, un-stripe, and compare with the full frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, blob, H, W, stripe, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import orc
+    import scene_defs as sd
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    scenes = importlib.import_module("cuda-raytracing_amd.scenes")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = sd.blob_scene(scenes, blob).build_oracle(orc)
+    K, D, pose = scenes.scaled_K(W), scenes.D_REF, scenes.C2_CAMERAS["mid"]
+    rows = tiling.frame_rows_of(H, stripe, rank, world)
+    max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+    local = torch.zeros((max_rows, W * 3), dtype=torch.uint8)
+    # each rank renders only its own stripes
+    for a in range(0, len(rows), stripe):
+        y0 = int(rows[a])
+        y1 = int(rows[min(a + stripe, len(rows)) - 1]) + 1
+        img = s.render(W, H, K, D, pose, y0=y0, y1=y1, planes=False)["img"]
+        local[a:a + (y1 - y0)] = torch.from_numpy(img[y0:y1].reshape(y1 - y0, W * 3))
+    gathered = torch.zeros((world, max_rows, W * 3), dtype=torch.uint8) if rank == 0 else None
+    tiling.gather_stripes(local, gathered, rank, dst=0)
+    if rank == 0:
+        frame = tiling.unstripe_host(gathered.numpy(), H, stripe, world)
+        full = s.render(W, H, K, D, pose, planes=False)["img"].reshape(H, W * 3)
+        np.save(out_path, np.array([int(np.array_equal(frame, full)), int((frame != full).sum())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _pipeline_worker(rank, world, port, blob, H, W, stripe, nframes, out_path):
+    """bench.py's N > 1 frame loop (tiling.StripePipeline) over gloo; every frame uses a different camera so a
+    buffer mix-up between in-flight frames cannot go unnoticed."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import orc
+    import scene_defs as sd
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    scenes = importlib.import_module("cuda-raytracing_amd.scenes")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = sd.blob_scene(scenes, blob).build_oracle(orc)
+    K, D = scenes.scaled_K(W), scenes.D_REF
+    poses = [(0.02 * f, -1.6 - 0.1 * f, 0.2, 0.01 * f, 0, 0) for f in range(nframes)]
+    rows = tiling.frame_rows_of(H, stripe, rank, world)
+    max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+    local = [torch.zeros((max_rows, W * 3), dtype=torch.uint8) for _ in range(2)]
+    gathered = [torch.zeros((world, max_rows, W * 3), dtype=torch.uint8) if rank == 0 else None for _ in range(2)]
+    frames, state = [], {"frame": 0}
+
+    def render_fn(b):
+        img = s.render(W, H, K, D, poses[state["frame"]], planes=False)["img"].reshape(H, W * 3)
+        local[b][:len(rows)] = torch.from_numpy(img[rows])
+        state["frame"] += 1
+
+    def unstripe_fn(b):
+        frames.append(tiling.unstripe_host(gathered[b].numpy(), H, stripe, world).copy())
+
+    pipe = tiling.StripePipeline(rank, world, local, gathered, render_fn, unstripe_fn)
+    for i in range(nframes):
+        pipe.step(i)
+    pipe.drain()
+    assert pipe.frames_done == nframes
+    if rank == 0:
+        ok = len(frames) == nframes
+        for f in range(nframes):
+            full = s.render(W, H, K, D, poses[f], planes=False)["img"].reshape(H, W * 3)
+            ok = ok and np.array_equal(frames[f], full)
+        np.save(out_path, np.array([int(ok), len(frames)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def test_two_rank_frame_pipeline(blob5k, tmp_path):
+    out = str(tmp_path / "pipe.npy")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), blob5k, 60, 96, 8, 5, out), nprocs=2, join=True)
+    ok, n = np.load(out)
+    assert ok == 1 and n == 5
+
+
+@pytest.mark.parametrize("world,stripe,H", [(2, 16, 90), (2, 7, 45)])
+def test_two_rank_stripes_gather(blob5k, tmp_path, world, stripe, H):
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(world, port, blob5k, H, 160, stripe, out), nprocs=world, join=True)
+    ok, nbad = np.load(out)
+    assert ok == 1, "%d bytes differ" % nbad
