@@ -27,7 +27,11 @@ using namespace rt;
 
 namespace {
 
-constexpr int kBlock = 256;     // 4 waves; one 16x16-pixel tile = 2x2 wave tiles of 8x8 pixels
+#ifndef RT_BLOCK
+#define RT_BLOCK 256
+#endif
+constexpr int kBlock = RT_BLOCK;  // 256: 4 waves, one 16x16-pixel tile = 2x2 wave tiles of 8x8 pixels; 64: one 8x8 tile
+constexpr int kTile = kBlock == 256 ? 16 : 8;
 
 struct Hit {
     float min;                  // HitInfo::min, raycast.cu:12
@@ -78,93 +82,156 @@ struct Counters {
 template <>
 struct Counters<false> {};
 
-// One instance of raycast.cu:26-139.  `stack` points at this lane's column of the LDS stack
-// (entries kBlock ints apart, so a wave's accesses are conflict-free).
+// Ray in mesh space (raycast.cu:33-51) plus what the leaf code needs of the instance.
+struct MeshRay {
+    V3 ro, rd, dinv;
+};
+
+__device__ __forceinline__ MeshRay to_mesh_space(const DevInstance& in, V3 org, V3 dir)
+{
+    MeshRay r;
+    r.rd = apply_quat(in.q_rot, dir);
+    r.rd.x *= in.inv_scale[0]; r.rd.y *= in.inv_scale[1]; r.rd.z *= in.inv_scale[2];
+    r.ro = apply_quat(in.q_pose, v3(org.x - in.pose_xyz[0], org.y - in.pose_xyz[1], org.z - in.pose_xyz[2]));
+    r.ro.x *= in.inv_scale[0]; r.ro.y *= in.inv_scale[1]; r.ro.z *= in.inv_scale[2];
+    r.dinv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);  // Ray.hpp:21
+    return r;
+}
+
+// One interior node (raycast.cu:66-79) from its already fetched 64-B record: tests both children, pushes the
+// far one if it passes `dist < hit.min`, and leaves in `cur` the entry the reference would pop next (the entry
+// pushed last never goes through the stack).  Returns false when nothing was pushed.
 template <bool DEBUG>
+__device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, float4 q3, const MeshRay& r, float hit_min,
+                                               int32_t& cur, int* stack, int& sp, Counters<DEBUG>& cnt)
+{
+    float da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.ro, r.dinv);
+    float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ro, r.dinv);
+    int32_t ra = __float_as_int(q3.x), rb = __float_as_int(q3.y);
+    if constexpr (DEBUG) cnt.aabb += 2;
+    bool pa = da < hit_min, pb = db < hit_min;
+    int32_t first, second; bool pf, ps;                         // push order of raycast.cu:72-79
+    if (da < db) { first = rb; pf = pb; second = ra; ps = pa; }
+    else         { first = ra; pf = pa; second = rb; ps = pb; }
+    if (ps) {
+        if (pf) stack[(sp++) * kBlock] = first;
+        cur = second;
+        return true;
+    }
+    if (pf) { cur = first; return true; }
+    return false;
+}
+
+// One leaf (raycast.cu:83-137): contiguous triangle slots.  The caller already fetched the whole 64-B record
+// of the first slot into t0..t3 (the scene keeps one padding record after the last slot so that fetch is
+// always in bounds, even for an empty leaf).
+template <bool DEBUG>
+__device__ __forceinline__ void leaf_step(const RenderParams& p, const DevInstance& in, int inst_index, const MeshRay& r,
+                                          V3 org, int32_t cur, Hit& hit, Counters<DEBUG>& cnt,
+                                          float4 t0, float4 t1, float4 t2, float4 t3)
+{
+    const bool exact_uv = in.exact_uv != 0;
+    int slot = cur & kSlotMask;
+    int count = (cur >> kSlotBits) & 31;
+    if (count == 31) count = p.leaf_count[slot];
+    for (int i = 0; i < count; i++, slot++) {
+        const float4* t = p.tris + (size_t)slot * 4;
+        if (i > 0) { t0 = t[0]; t1 = t[1]; t2 = t[2]; t3 = t[3]; }
+        if constexpr (DEBUG) cnt.tris++;
+        V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
+        // TrianglePrimitive::ray_intersect, TrianglePrimitive.hpp:62-79
+        float denom = dot(r.rd, nrm);
+        // `abs(denom) < 1e-6` compares in double; 0x358637be is the smallest float whose double value is >= 1e-6,
+        // so this float compare selects exactly the same floats (tests/test_host_logic.py checks the boundary).
+        if (fabsf(denom) < __int_as_float(0x358637be)) continue;
+        // A candidate is only ever accepted when same_dir = denom < 0 (raycast.cu:107-109); for denom >= 0 (or NaN)
+        // the rest of the test has no observable effect, so the production kernel stops here.  The debug kernel
+        // goes on because the inside-hit count of raycast.cu:96 is one of the parity planes.
+        if (!DEBUG && !(denom < 0.0f)) continue;
+        float tt = dot(v0 - r.ro, nrm) / denom;
+        if (tt < 0.0f) continue;
+        V3 pt = r.ro + tt * r.rd;
+        if (pt.x == FLT_MAX) continue;                          // raycast.cu:91
+        // TrianglePrimitive::point_inside, TrianglePrimitive.hpp:151-185
+        V3 e0 = v3(t1.z, t1.w, t2.x), e1 = v3(t2.y, t2.z, t2.w);
+        V3 e2 = pt - v0;
+        float dot02 = dot(e0, e2), dot12 = dot(e1, e2);
+        float u = (t3.z * dot02 - t3.y * dot12) * t3.w;
+        float v = (t3.x * dot12 - t3.y * dot02) * t3.w;
+        if (!((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f))) continue;
+        float2 uv = make_float2(0.0f, 0.0f);
+        if (exact_uv) {                                         // raycast.cu:96 can only fail for absurd uv data
+            const float* q = p.tri_uv + (size_t)slot * 6;
+            float w = 1.0f - u - v;
+            uv.x = (w * q[0] + v * q[2]) + u * q[4];
+            uv.y = (w * q[1] + v * q[3]) + u * q[5];
+            if (!(uv.x != FLT_MAX)) continue;
+        }
+        if constexpr (DEBUG) cnt.inside++;
+        // raycast.cu:98-104
+        V3 loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
+        loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
+        float distance = magnitude(loc - org);
+        // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
+        if (denom < 0 && (hit.min == FLT_MAX || distance < hit.min)) {
+            hit.min = distance;
+            hit.slot = slot; hit.instance = inst_index; hit.u = u; hit.v = v; hit.uv = uv;
+        }
+    }
+}
+
+// One instance of raycast.cu:26-139.  `stack` points at this lane's column of the LDS stack (entries kBlock
+// ints apart, so a wave's accesses are conflict-free).
+//
+// Interior nodes and triangles are both 64-B records, so every lane issues the same four 16-B loads from a
+// selected base ("unified fetch") and the wave waits for memory once per iteration, whatever mix of interior
+// and leaf entries its lanes hold.  Each lane still visits exactly the reference's sequence of nodes.
+// PROF = diagnostic copy with s_memtime stamps per phase (RT_TRACE_FILE); its frames are never timed.
+template <bool DEBUG, bool PROF>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, int* stack, Hit& hit, Counters<DEBUG>& cnt)
 {
-    // ray -> mesh space, raycast.cu:33-51
-    V3 rd = apply_quat(in.q_rot, dir);
-    rd.x *= in.inv_scale[0]; rd.y *= in.inv_scale[1]; rd.z *= in.inv_scale[2];
-    V3 ro = apply_quat(in.q_pose, v3(org.x - in.pose_xyz[0], org.y - in.pose_xyz[1], org.z - in.pose_xyz[2]));
-    ro.x *= in.inv_scale[0]; ro.y *= in.inv_scale[1]; ro.z *= in.inv_scale[2];
-    V3 dinv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);        // Ray.hpp:21
-    const bool exact_uv = in.exact_uv != 0;
-
+    const MeshRay r = to_mesh_space(in, org, dir);
     int sp = 0;
     int32_t cur = in.root_ref;                                  // raycast.cu:58 (kept in a register)
     bool have = true;
+    unsigned long long c_pop = 0, c_mem = 0, c_int = 0, c_leaf = 0, n_it = 0, n_int = 0, n_leaf = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     while (true) {
+        if constexpr (PROF) t0 = __builtin_amdgcn_s_memtime();
         if (!have) {
             if (sp == 0) break;
             cur = stack[(--sp) * kBlock];                       // raycast.cu:61
         }
-        have = false;
         if constexpr (DEBUG) cnt.pops++;
-        if (cur >= 0) {
-            // interior node: both children's boxes in one 64-B record (raycast.cu:66-79)
-            const float4* n = p.inodes + (size_t)cur * 4;
-            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-            float da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ro, dinv);
-            float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ro, dinv);
-            int32_t ra = __float_as_int(q3.x), rb = __float_as_int(q3.y);
-            if constexpr (DEBUG) cnt.aabb += 2;
-            bool pa = da < hit.min, pb = db < hit.min;
-            // Push order of raycast.cu:72-79; the entry that would be pushed last is the one the
-            // next iteration pops, so it stays in `cur` instead of going through the stack.
-            int32_t first, second; bool pf, ps;
-            if (da < db) { first = rb; pf = pb; second = ra; ps = pa; }
-            else         { first = ra; pf = pa; second = rb; ps = pb; }
-            if (ps) {
-                if (pf) stack[(sp++) * kBlock] = first;
-                cur = second; have = true;
-            } else if (pf) {
-                cur = first; have = true;
-            }
-        } else {
-            // leaf: contiguous slots (raycast.cu:83-137)
-            int slot = cur & kSlotMask;
-            int count = (cur >> kSlotBits) & 31;
-            if (count == 31) count = p.leaf_count[slot];
-            for (int i = 0; i < count; i++, slot++) {
-                const float4* t = p.tris + (size_t)slot * 4;
-                float4 t0 = t[0], t1 = t[1];
-                if constexpr (DEBUG) cnt.tris++;
-                V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
-                // TrianglePrimitive::ray_intersect, TrianglePrimitive.hpp:62-79
-                float denom = dot(rd, nrm);
-                if ((double)fabsf(denom) < 1e-6) continue;
-                float tt = dot(v0 - ro, nrm) / denom;
-                if (tt < 0.0f) continue;
-                V3 pt = ro + tt * rd;
-                if (pt.x == FLT_MAX) continue;                  // raycast.cu:91
-                // TrianglePrimitive::point_inside, TrianglePrimitive.hpp:151-185
-                float4 t2 = t[2], t3 = t[3];
-                V3 e0 = v3(t1.z, t1.w, t2.x), e1 = v3(t2.y, t2.z, t2.w);
-                V3 e2 = pt - v0;
-                float dot02 = dot(e0, e2), dot12 = dot(e1, e2);
-                float u = (t3.z * dot02 - t3.y * dot12) * t3.w;
-                float v = (t3.x * dot12 - t3.y * dot02) * t3.w;
-                if (!((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f))) continue;
-                float2 uv = make_float2(0.0f, 0.0f);
-                if (exact_uv) {                                 // raycast.cu:96 can only fail for absurd uv data
-                    const float* q = p.tri_uv + (size_t)slot * 6;
-                    float w = 1.0f - u - v;
-                    uv.x = (w * q[0] + v * q[2]) + u * q[4];
-                    uv.y = (w * q[1] + v * q[3]) + u * q[5];
-                    if (!(uv.x != FLT_MAX)) continue;
-                }
-                if constexpr (DEBUG) cnt.inside++;
-                // raycast.cu:98-104
-                V3 loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
-                loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
-                float distance = magnitude(loc - org);
-                // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
-                if (denom < 0 && (hit.min == FLT_MAX || distance < hit.min)) {
-                    hit.min = distance;
-                    hit.slot = slot; hit.instance = inst_index; hit.u = u; hit.v = v; hit.uv = uv;
-                }
+        const bool interior = cur >= 0;
+        const float4* rec = interior ? p.inodes + (size_t)cur * 4 : p.tris + (size_t)(cur & kSlotMask) * 4;
+        if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t1 = __builtin_amdgcn_s_memtime(); }
+        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        if constexpr (PROF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t2 = __builtin_amdgcn_s_memtime();
+            n_it++; n_int += __ballot(interior) != 0; n_leaf += __ballot(!interior) != 0;
+        }
+        if (interior) have = interior_apply<DEBUG>(r0, r1, r2, r3, r, hit.min, cur, stack, sp, cnt);
+        if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t3 = __builtin_amdgcn_s_memtime(); }
+        if (!interior) {
+            leaf_step<DEBUG>(p, in, inst_index, r, org, cur, hit, cnt, r0, r1, r2, r3);
+            have = false;
+        }
+        if constexpr (PROF) {
+            __builtin_amdgcn_s_waitcnt(0);
+            c_pop += t1 - t0; c_mem += t2 - t1; c_int += t3 - t2; c_leaf += __builtin_amdgcn_s_memtime() - t3;
+        }
+    }
+    if constexpr (PROF) {
+        if (p.trace) {                                          // the longest-lived lane's view of the wave
+            unsigned long long v[7] = {c_pop, c_mem, c_int, c_leaf, n_it, n_int, n_leaf};
+            unsigned long long best = n_it;
+            for (int o = 32; o > 0; o >>= 1) { unsigned long long x = __shfl_xor(best, o); best = x > best ? x : best; }
+            const unsigned long long owner = __ballot(n_it == best);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)owner) - 1) {
+                unsigned long long* t = p.trace + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + 4;
+                for (int k = 0; k < 7; k++) t[k] += v[k];
             }
         }
     }
@@ -207,34 +274,19 @@ __device__ __forceinline__ void shade(const RenderParams& p, const Hit& hit, uin
     px[2] = to_u8(illumination * cz * 255.0f);
 }
 
-template <bool DEBUG>
-__global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
+// One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
+// (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
+template <bool DEBUG, bool PROF>
+__device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly, int y, int* stack)
 {
-    extern __shared__ int lds_stack[];                          // [stack_depth][kBlock]
-
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the
-    // k-th contiguous eighth of the tile list -- neighbouring tiles (same BVH subtrees) share an L2.
-    const int ntiles = p.tiles_x * p.tiles_y;
-    int b = blockIdx.x;
-    const int per = ntiles >> 3, body = per << 3;
-    int tile = (b < body) ? (b & 7) * per + (b >> 3) : b;
-    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int ly = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (x >= p.width || ly >= p.local_rows) return;
-    const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
-
     const V3 org = v3(p.origin[0], p.origin[1], p.origin[2]);
     const V3 dir = camera_direction(p, x, y);
 
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
     Counters<DEBUG> cnt;
-    int* stack = lds_stack + tid;
     for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
-        trace_instance<DEBUG>(p, p.instances[i], i, org, dir, stack, hit, cnt);
+        trace_instance<DEBUG, PROF>(p, p.instances[i], i, org, dir, stack, hit, cnt);
 
     uint8_t px[3];
     shade(p, hit, px);
@@ -249,6 +301,37 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
         if (p.aabb_tests) p.aabb_tests[o] = cnt.aabb;
         if (p.tri_tests) p.tri_tests[o] = cnt.tris;
         if (p.inside_hits) p.inside_hits[o] = cnt.inside;
+    }
+}
+
+template <bool DEBUG, bool PROF>
+__global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
+{
+    extern __shared__ int lds_stack[];                          // [stack_depth][kBlock]
+
+    // Workgroup b renders tile b (row-major) unless an explicit order is given.  Consecutive workgroups are
+    // dealt round-robin to the 8 XCDs, so every XCD sees tiles from the whole frame: measured faster than giving
+    // each XCD one contiguous band (better load balance; the working set is L1/L2 resident either way).
+    const int tile = p.tile_list ? p.tile_list[blockIdx.x] : (int)blockIdx.x;
+    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+
+    // a wave64 is an 8x8-pixel block: neighbouring rays walk the same nodes (L1 hits, little divergence)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int x = tx * kTile + (wave & 1) * 8 + (lane & 7);
+    const int ly = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    unsigned long long t_start = 0;
+    if (p.trace) t_start = wall_clock64();
+    if (x < p.width && ly < p.local_rows) {
+        // stripes: local row -> frame row (identity when num_ranks == 1)
+        const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
+        render_pixel<DEBUG, PROF>(p, x, ly, y, lds_stack + tid);
+    }
+    if (p.trace && lane == 0) {                                 // diagnostic: per-wave lifetime (RT_TRACE_FILE)
+        unsigned long long* t = p.trace + ((size_t)blockIdx.x * (kBlock / 64) + wave) * 16;
+        t[0] = t_start; t[1] = wall_clock64();
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        t[2] = ((unsigned long long)xcc << 32) | hw; t[3] = (unsigned long long)tile;
     }
 }
 
@@ -354,13 +437,24 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
 {
     if (p.width <= 0 || p.local_rows < 0) return RT_E_INVALID;
     if (p.local_rows == 0) return RT_OK;
-    p.tiles_x = (p.width + 15) / 16;
-    p.tiles_y = (p.local_rows + 15) / 16;
+    p.tiles_x = (p.width + kTile - 1) / kTile;
+    p.tiles_y = (p.local_rows + kTile - 1) / kTile;
     const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(kBlock);
-    if (debug) hipLaunchKernelGGL(render_kernel<true>, grid, block, lds, stream, p);
-    else       hipLaunchKernelGGL(render_kernel<false>, grid, block, lds, stream, p);
+    const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
+    const size_t trace_n = (size_t)grid.x * (kBlock / 64) * 16;
+    if (trace_file) { RT_HIP(hipMalloc((void**)&p.trace, trace_n * 8)); RT_HIP(hipMemset(p.trace, 0, trace_n * 8)); }
+    if (trace_file && getenv("RT_TRACE_PROF")) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, stream, p);
+    else if (debug) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, stream, p);
     RT_HIP(hipGetLastError());
+    if (trace_file) {
+        std::vector<unsigned long long> h(trace_n);
+        RT_HIP(hipStreamSynchronize(stream));
+        RT_HIP(hipMemcpy(h.data(), p.trace, trace_n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(p.trace);
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
+    }
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
 }
@@ -528,6 +622,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     hipError_t he = hipGetDevice(&s->device);
     if (he != hipSuccess) return fail(he == hipErrorNoDevice ? RT_E_NODEVICE : (int)he);
     if ((rc = upload(&s->d_inodes, inodes, s->device_bytes))) return fail(rc);
+    for (int k = 0; k < 4; k++) tris.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));     // padding record (see leaf_step)
     if ((rc = upload(&s->d_tris, tris, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_tri_uv, tri_uv, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_tri_id, tri_id, s->device_bytes))) return fail(rc);

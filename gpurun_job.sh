@@ -1,5 +1,3 @@
-set -e
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
+python tools/kbench.py --iters 100 --check 2>&1 | grep -v "^Loading\|^OBJ\|^Loaded\|^scene"
 timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_r01_v1.json

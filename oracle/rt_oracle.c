@@ -628,6 +628,12 @@ typedef struct {                                    /* raycast.cu:10-18 + bookke
     int pops, aabb_tests, tri_tests, inside_hits, max_stack;
 } hit_t;
 
+/* optional per-ray step recorder (analysis tooling): one byte per node pop, 0 = interior,
+ * k >= 1 = leaf with k-1 triangle tests (capped at 254) */
+static __thread uint8_t *g_rec = NULL;
+static __thread int g_rec_n = 0, g_rec_cap = 0;
+static void rec_step(int v) { if (g_rec && g_rec_n < g_rec_cap) g_rec[g_rec_n] = (uint8_t)(v > 255 ? 255 : v); if (g_rec) g_rec_n++; }
+
 /* raycast.cu:21-142 */
 static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
 {
@@ -661,6 +667,7 @@ static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
                 float dist_a = aabb_ray_intersects(na->bmin, na->bmax, &r_ray);
                 float dist_b = aabb_ray_intersects(nb->bmin, nb->bmax, &r_ray);
                 hit.aabb_tests += 2;
+                rec_step(0);
                 if (dist_a < dist_b) {                                   /* :72-79 */
                     if (dist_b < hit.min) stack[stack_index++] = cur->child_b;
                     if (dist_a < hit.min) stack[stack_index++] = cur->child_a;
@@ -670,6 +677,7 @@ static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
                 }
             } else {
                 int i;
+                rec_step(1 + cur->count);
                 for (i = 0; i < cur->count; i++) {                       /* :85-136 */
                     int index = cur->idx[i];
                     const tri_t *tri = &mesh->tris[index];
@@ -811,6 +819,24 @@ int orc_render(const OrcScene *sc, int width, int height, const float *K9, const
     }
     if (stats8) { int i; for (i = 0; i < 6; i++) stats8[i] += st[i]; if (st[6] > stats8[6]) stats8[6] = st[6]; }
     return 0;
+}
+
+/* step sequence of the ray of pixel (x, y): returns the number of node pops, writes min(n, cap) bytes */
+int orc_trace_steps(const OrcScene *sc, int width, int height, const float *K9, const float *D4, const float *cam_pose6,
+                    int x, int y, uint8_t *out, int cap)
+{
+    camera_t cam; m33 K; ray_t r;
+    memcpy(&K, K9, sizeof K);
+    cam.width = width; cam.height = height;
+    cam.K_inv = invert_intrinsic(&K);
+    cam.D.x = D4[0]; cam.D.y = D4[1]; cam.D.z = D4[2]; cam.D.w = D4[3];
+    memcpy(&cam.camera_pose, cam_pose6, sizeof(lre_t));
+    cam.inv_camera_pose = invert_lre(cam.camera_pose);
+    r = camera_ray(&cam, x, y);
+    g_rec = out; g_rec_n = 0; g_rec_cap = cap;
+    (void)cast_ray(&r, sc);
+    g_rec = NULL;
+    return g_rec_n;
 }
 
 /* camera-space ray direction of one pixel, for ray-generation parity tests */

@@ -111,6 +111,19 @@ def test_atanf_restatement_matches_libm(rt):
     assert same([s.rth_atanf(-float(x)) for x in xs[::50]], [libm.atanf(-float(x)) for x in xs[::50]])
 
 
+def test_plane_epsilon_float_threshold():
+    """TrianglePrimitive.hpp:66 compares abs(denom) < 1e-6 in double; the kernel compares in float against
+    0x358637be.  Both select exactly the same floats."""
+    thr = np.array([0x358637be], np.uint32).view(np.float32)[0]
+    u = np.arange(0x358637be - 5000, 0x358637be + 5000, dtype=np.uint32)
+    x = u.view(np.float32)
+    assert np.array_equal(x.astype(np.float64) < 1e-6, x < thr)
+    wide = np.linspace(0, 0x7f800000, 200001).astype(np.uint32).view(np.float32)
+    assert np.array_equal(wide.astype(np.float64) < 1e-6, wide < thr)
+    src = open(os.path.join(ROOT, "cuda-raytracing_amd", "csrc", "rt_kernels.hip")).read()
+    assert "0x358637be" in src
+
+
 def test_host_bvh_and_obj_vs_oracle(rt, oracle, blob5k):
     _mesh_equal(rt.Mesh.load_obj(blob5k).dump(), oracle.mesh_dump(oracle.obj_load(blob5k)))
     p = os.path.join(GOLDEN, "small_mixed.obj")

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of the three C2 cameras (hipEvent, no torch): quick A/B tool for kernel work.
+   python tools/kbench.py [--iters 100] [--width 1920 --height 1080] [--check]"""
+import argparse
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rt = importlib.import_module("cuda-raytracing_amd")
+scenes = importlib.import_module("cuda-raytracing_amd.scenes")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="blob70k", choices=["blob70k", "blob5k", "atrium"])
+    ap.add_argument("--check", action="store_true", help="compare the frame hash with the debug kernel's")
+    a = ap.parse_args()
+    rt.build()
+    cache = os.path.join(ROOT, ".scene_cache")
+    os.makedirs(cache, exist_ok=True)
+    obj = os.path.join(cache, a.scene + ".obj")
+    if not os.path.exists(obj):
+        {"blob70k": lambda p: scenes.write_blob_obj(p, 188, 187), "blob5k": lambda p: scenes.write_blob_obj(p, 50, 51),
+         "atrium": scenes.write_atrium_obj}[a.scene](obj)
+    mesh = rt.Mesh.load_obj(obj)
+    scene = rt.Scene()
+    scene.add_material(scenes.C2["albedo"])
+    scene.add_mesh(mesh)
+    scene.add_mesh_instance(0, 0)
+    scene.upload_to_device()
+    print("scene", a.scene, "tris", mesh.num_triangles, "nodes", mesh.num_nodes, scene.info())
+    W, H = a.width, a.height
+    cams = {"atrium": {"inside": scenes.C4["cam_pose"]}}.get(a.scene, scenes.C2_CAMERAS)
+    img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    t = rt.Timer()
+    for name, pose in cams.items():
+        cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+        cam.set_pose(pose)
+        for _ in range(5):
+            cam.render_scene(scene, img.ptr, img.pitch)
+        t.start()
+        for _ in range(a.iters):
+            cam.render_scene(scene, img.ptr, img.pitch)
+        t.stop()
+        ms = t.elapsed_ms() / a.iters
+        line = "%-6s %.4f ms  %.1f Mrays/s" % (name, ms, W * H / ms / 1e3)
+        if a.check:
+            import numpy as np
+            dbg = rt.render_debug(scene, cam)
+            got = img.to_host().reshape(H, W, 3)
+            line += "  match_debug=%s pops/ray=%.2f" % (bool(np.array_equal(got, dbg["img"])), dbg["pops"].mean())
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()

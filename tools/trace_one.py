@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Diagnostic: render one frame per C2 camera with RT_TRACE_FILE set and dump per-wave lifetimes."""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+rt = importlib.import_module("cuda-raytracing_amd")
+scenes = importlib.import_module("cuda-raytracing_amd.scenes")
+out = sys.argv[1]
+mesh = rt.Mesh.load_obj(os.path.join(ROOT, ".scene_cache", "blob70k.obj"))
+scene = rt.Scene(); scene.add_material(scenes.C2["albedo"]); scene.add_mesh(mesh); scene.add_mesh_instance(0, 0); scene.upload_to_device()
+W, H = 1920, 1080
+img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+for name, pose in scenes.C2_CAMERAS.items():
+    cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF); cam.set_pose(pose)
+    for _ in range(3): cam.render_scene(scene, img.ptr, img.pitch, synchronize=True)
+    os.environ["RT_TRACE_FILE"] = os.path.join(out, "trace_%s.bin" % name)
+    cam.render_scene(scene, img.ptr, img.pitch, synchronize=True)
+    del os.environ["RT_TRACE_FILE"]
+    t = np.fromfile(os.path.join(out, "trace_%s.bin" % name), np.uint64).reshape(-1, 16)
+    t = t[t[:, 1] > 0]
+    st, en = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+    t0 = st.min(); dur = (en - st) / 100.0; span = (en.max() - t0) / 100.0
+    print(name, "waves", len(t), "span %.1f us" % span, "wave dur mean %.2f p50 %.2f p99 %.2f max %.2f us" % (dur.mean(), np.median(dur), np.percentile(dur, 99), dur.max()),
+          "sum dur %.0f us -> avg concurrency %.0f" % (dur.sum(), dur.sum() / span))
+    # concurrency over time in 10 slices
+    edges = np.linspace(0, span, 11)
+    conc = [(((st - t0) / 100.0 < b) & ((en - t0) / 100.0 > a)).sum() for a, b in zip(edges[:-1], edges[1:])]
+    print("   waves alive per tenth:", conc)
+    # experiment: re-render with tiles ordered by measured block duration (longest first)
+    blk = t[:, 3].astype(np.int64); nb = int(blk.max()) + 1
+    bd = np.zeros(nb); np.maximum.at(bd, blk, dur)
+    order = np.argsort(-bd, kind="stable").astype(np.int32)
+    lf = os.path.join(out, "order_%s.bin" % name); order.tofile(lf)
+    tm = rt.Timer()
+    def timeit(n=50):
+        for _ in range(3): cam.render_scene(scene, img.ptr, img.pitch)
+        tm.start()
+        for _ in range(n): cam.render_scene(scene, img.ptr, img.pitch)
+        tm.stop(); return tm.elapsed_ms() / n
+    base = timeit()
+    os.environ["RT_TILE_LIST"] = lf
+    srt = timeit()
+    del os.environ["RT_TILE_LIST"]
+    print("   kernel ms: natural order %.4f, heavy-first order %.4f" % (base, srt))
+    if t[:, 8].max() > 0:
+        heavy = np.argsort(dur)[-5:]
+        for w in heavy:
+            cp, cm, ci, cl, nit, nint, nleaf = [int(v) for v in t[w, 4:11]]
+            print("   heavy wave: dur %.1f us iters %d (int %d leaf %d) cycles: pop %d mem %d int %d leaf %d  per-iter %.0f" % (dur[w], nit, nint, nleaf, cp, cm, ci, cl, (cp+cm+ci+cl)/max(nit,1)))
+        tot = t[:, 4:11].astype(np.float64).sum(0)
+        print("   all waves: iters %.3g int %.3g leaf %.3g; cycle shares pop %.2f mem %.2f int %.2f leaf %.2f; cyc/iter %.0f" % (tot[4], tot[5], tot[6], *(tot[:4]/tot[:4].sum()), tot[:4].sum()/tot[4]))
+    late = np.argsort(en)[-5:]
+    print("   last finishers: start %s end %s dur %s tile %s" % (((st[late]-t0)/100.0).round(1), ((en[late]-t0)/100.0).round(1), dur[late].round(1), t[late,3]))
