@@ -7,10 +7,16 @@ casts exactly one ray per pixel: raycast.cu:204), scene resident in HBM before t
 
   python bench.py [--gpus N --steps K --warmup W] [--camera far|mid|near] [--no-cpu-baseline]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the scene is replicated, the frame
-is cut into 16-row stripes dealt round-robin to the ranks (rt_render_stripes), and every frame
-ends with an RCCL gather of the stripes to rank 0 plus rt_unstripe -- total work is fixed, so
-"scaling" is "strong".  Rank 0 prints ONE JSON line.
+Frames are issued in groups of --frames-per-launch F (default 4) through Camera::render_scene_batch /
+rt_render_batch: one launch renders F complete frames into F buffers, so the last long rays of one frame
+overlap the bulk of the next (the reference's own loop issues two renders per synchronise,
+kernel.cu:277-279).  K steps = K frames = K/F launches; F = 1 gives one launch per frame.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the scene is replicated, every frame is
+cut into 16-row stripes dealt round-robin to the ranks (rt_render_stripes_batch), and every group of F
+frames ends with ONE RCCL gather of the stripes to rank 0 plus rt_unstripe per frame; the gather of
+group i overlaps the render of group i+1.  Total work is fixed, so "scaling" is "strong".
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -93,6 +99,7 @@ def main():
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
     ap.add_argument("--width", type=int, default=scenes.C2["width"])
     ap.add_argument("--height", type=int, default=scenes.C2["height"])
+    ap.add_argument("--frames-per-launch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -132,9 +139,15 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     cam.set_stream(stream)
 
+    import math
+    F = max(1, min(args.frames_per_launch, 8))
+    F = math.gcd(F, args.steps) if args.steps > 0 else F        # K frames in exactly K / F launches
+    if args.warmup % F:
+        args.warmup += F - args.warmup % F
     pitch = W * 3
-    frame = torch.empty((H, pitch), dtype=torch.uint8, device=dev)
+    frames = torch.empty((F, H, pitch), dtype=torch.uint8, device=dev)      # rank 0: the finished frames of one group
     hlib = rt.libs()[0]
+    poses = [pose] * F
     if world > 1:
         rows = []
         for r in range(world):
@@ -142,23 +155,30 @@ def main():
             rt.check(hlib.rt_stripe_rows(H, STRIPE_ROWS, r, world, C.byref(n)))
             rows.append(n.value)
         max_rows = max(rows)
-        local = [torch.zeros((max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world, max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
+        # per buffer: F frames x this rank's (padded) stripe rows
+        local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
 
     timer = rt.Timer()
 
+    def render_group_single():
+        cam.render_scene_batch(scene, poses, [frames[f].data_ptr() for f in range(F)], pitch)
+
     def render_local(b):
-        cam.render_scene_stripes(scene, local[b].data_ptr(), pitch, STRIPE_ROWS, rank, world)
+        cam.render_scene_stripes_batch(scene, poses, tiling.batch_local_ptrs(local[b].data_ptr(), F, max_rows, pitch), pitch,
+                                       STRIPE_ROWS, rank, world)
 
     def unstripe(b):
-        rt.check(hlib.rt_unstripe(gathered[b].data_ptr(), pitch, max_rows, frame.data_ptr(), pitch, W, H, STRIPE_ROWS, world,
-                                  torch.cuda.current_stream().cuda_stream))
+        st = torch.cuda.current_stream().cuda_stream
+        for f in range(F):
+            src, rank_stride = tiling.batch_unstripe_args(gathered[b].data_ptr(), f, F, max_rows, pitch)
+            rt.check(hlib.rt_unstripe(src, pitch, rank_stride, frames[f].data_ptr(), pitch, W, H, STRIPE_ROWS, world, st))
 
     pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe) if world > 1 else None
 
-    def step(i):
+    def step_group(i):
         if world == 1:
-            cam.render_scene(scene, frame.data_ptr(), pitch)
+            render_group_single()
         else:
             pipe.step(i)
 
@@ -168,12 +188,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    for i in range(args.warmup // F):
+        step_group(i)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for i in range(args.steps // F):
+        step_group(i)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -184,17 +204,25 @@ def main():
     # ---- kernel-only duration with hipEvents on the launch stream (roofline numerator) ----
     kernel_ms = None
     if rank == 0:
-        n = max(10, min(args.steps, 100))
-        sync_local = torch.cuda.synchronize
-        sync_local()
+        n = max(10, min(args.steps // F, 100))
+        torch.cuda.synchronize()
         timer.start(stream)
         for _ in range(n):
             if world == 1:
-                cam.render_scene(scene, frame.data_ptr(), pitch)
+                render_group_single()
             else:
-                cam.render_scene_stripes(scene, local[0].data_ptr(), pitch, STRIPE_ROWS, rank, world)
+                render_local(0)
         timer.stop(stream)
-        kernel_ms = timer.elapsed_ms() / n
+        kernel_ms = timer.elapsed_ms() / n                      # one launch = F frames (this rank's stripes of them)
+        # latency of a single-frame launch, for reference
+        one = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+        torch.cuda.synchronize()
+        timer.start(stream)
+        for _ in range(20):
+            cam.render_scene(scene, one.ptr, one.pitch)
+        timer.stop(stream)
+        single_ms = timer.elapsed_ms() / 20
+        one.free()
     if world > 1:
         dist.barrier()
 
@@ -203,16 +231,16 @@ def main():
         dbg = rt.render_debug(scene, cam)
         st = {"rays": W * H, "pops": int(dbg["pops"].sum()), "aabb": int(dbg["aabb"].sum()), "tris": int(dbg["tris"].sum()),
               "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
-        frame_host = frame.cpu().numpy().reshape(H, W, 3)
-        frame_ok = bool(np.array_equal(frame_host, dbg["img"]))
-        alg_bytes = algorithmic_bytes(st)
-        share = 1.0 / world                                 # rank 0's stripes ~ 1/N of the frame's work
+        frames_host = frames.cpu().numpy().reshape(F, H, W, 3)
+        frame_ok = bool(all(np.array_equal(frames_host[f], dbg["img"]) for f in range(F)))
+        alg_bytes = algorithmic_bytes(st)                   # per frame
+        share = F / world                                   # one launch = F frames; rank 0's stripes ~ 1/N of each
         achieved = alg_bytes * share / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("%s_%dx%d" % (args.camera, W, H), {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tp)).get("%s_%dx%d_f%d" % (args.camera, W, H, F), {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -224,14 +252,15 @@ def main():
             "config": {"workload": "C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"
                                    % (W, H, args.camera, str(tuple(pose[:3]))),
                        "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
-                                      % (STRIPE_ROWS, world, ", RCCL gather to rank 0" if world > 1 else ""),
+                                      % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per %d frames" % F if world > 1 else ""),
+                       "frames_per_launch": F, "single_frame_launch_ms": round(single_ms, 4),
                        "coverage": round(st["hits"] / st["rays"], 4),
                        "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
                        "algorithmic_bytes_per_ray": round(alg_bytes / st["rays"], 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "render_kernel<false>", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes * share)},
+                         "kernel": "render_kernel<false,false>", "kernel_ms": round(kernel_ms, 4),
+                         "frames_per_launch": F, "algorithmic_bytes_per_launch": int(alg_bytes * share)},
             "frame_matches_debug_kernel": frame_ok,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -41,8 +41,8 @@ class RtDebugPlanes(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_debug",
-    "rt_stripe_rows", "rt_render_stripes", "rt_unstripe", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
+    "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
+    "rt_render_debug", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
     "rth_obj_load", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
@@ -51,6 +51,7 @@ RT_HOST_SYMBOLS = [
     "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance",
     "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
+    "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch",
     "rth_camera_params", "rth_q_rsqrt", "rth_atanf", "rth_normalize", "rth_invert_lre", "rth_apply_lre", "rth_euler2quat",
     "rth_apply_quat", "rth_invert_intrinsic", "rth_last_error"]
 
@@ -94,7 +95,7 @@ def _declare(h, s):
     h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
     h.rt_stripe_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i]
     h.rt_render_stripes.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int]
-    h.rt_unstripe.argtypes = [_vp, C.c_size_t, C.c_int32, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
+    h.rt_unstripe.argtypes = [_vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
     h.rt_timer_create.argtypes = [C.POINTER(_vp)]
     h.rt_timer_start.argtypes = [_vp, _vp]
     h.rt_timer_stop.argtypes = [_vp, _vp]
@@ -129,6 +130,9 @@ def _declare(h, s):
     s.rth_camera_set_stream.argtypes = [_vp, _vp]
     s.rth_camera_render_scene.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
     s.rth_camera_render_scene_stripes.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int]
+    s.rth_camera_render_scene_batch.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int]
+    s.rth_camera_render_scene_stripes_batch.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
+                                                        C.c_int32, C.c_int]
     s.rth_camera_params.argtypes = [_vp, _vp]
     s.rth_q_rsqrt.restype = C.c_float
     s.rth_q_rsqrt.argtypes = [C.c_float]
@@ -298,6 +302,21 @@ class Camera:
     def render_scene_stripes(self, scene, d_local, local_pitch, stripe_rows, rank, num_ranks, synchronize=False):
         check(libs()[1].rth_camera_render_scene_stripes(self.h, scene.h, d_local, local_pitch, stripe_rows, rank, num_ranks,
                                                         1 if synchronize else 0), "Camera::render_scene_stripes")
+
+    def render_scene_batch(self, scene, poses, d_imgs, pitch, synchronize=False):
+        """frames along a camera path in one launch: poses[i] -> d_imgs[i] (device pointers)"""
+        n = len(poses)
+        P = _fa(np.asarray(poses, np.float32).reshape(n, 6))
+        ptrs = (_vp * n)(*[int(x) if not isinstance(x, _vp) else x.value for x in d_imgs])
+        check(libs()[1].rth_camera_render_scene_batch(self.h, scene.h, _fp(P), ptrs, pitch, n, 1 if synchronize else 0),
+              "Camera::render_scene_batch")
+
+    def render_scene_stripes_batch(self, scene, poses, d_locals, local_pitch, stripe_rows, rank, num_ranks, synchronize=False):
+        n = len(poses)
+        P = _fa(np.asarray(poses, np.float32).reshape(n, 6))
+        ptrs = (_vp * n)(*[int(x) if not isinstance(x, _vp) else x.value for x in d_locals])
+        check(libs()[1].rth_camera_render_scene_stripes_batch(self.h, scene.h, _fp(P), ptrs, local_pitch, n, stripe_rows, rank,
+                                                              num_ranks, 1 if synchronize else 0), "Camera::render_scene_stripes_batch")
 
     def close(self):
         if self.h:

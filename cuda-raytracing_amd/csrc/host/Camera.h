@@ -22,6 +22,11 @@ public:
 
     // asynchronous on `stream` unless synchronize (Camera.cu:38-39)
     void render_scene(Scene& scene, uchar3* img_ptr, size_t pitch, bool synchronize = false);
+    // `count` frames (<= RT_MAX_BATCH) along a camera path in one launch: frame i uses poses[i] (K, D, size from
+    // this camera) and goes to img_ptrs[i]; see rt_render_batch in rt_hip.h
+    void render_scene_batch(Scene& scene, const lre* poses, int count, uchar3* const* img_ptrs, size_t pitch, bool synchronize = false);
+    void render_scene_stripes_batch(Scene& scene, const lre* poses, int count, uchar3* const* local_ptrs, size_t local_pitch,
+                                    int stripe_rows, int rank, int num_ranks, bool synchronize = false);
     // this rank's stripes of the frame into a tight local buffer (multi-GPU tiling, rt_hip.h)
     void render_scene_stripes(Scene& scene, uchar3* local_ptr, size_t local_pitch, int stripe_rows, int rank, int num_ranks,
                               bool synchronize = false);

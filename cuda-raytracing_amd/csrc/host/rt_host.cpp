@@ -319,30 +319,48 @@ Camera::Camera(int width, int height, float3x3 K, float4 D) : width(width), heig
     pose = lre();
 }
 
-static RtCameraParams camera_params(const Camera& c)
+static RtCameraParams camera_params(const Camera& c, const lre& pose)
 {
     RtCameraParams p;
     p.width = c.width; p.height = c.height;
     memcpy(p.K_inv, &c.K_inv, sizeof p.K_inv);
     p.D[0] = c.D.x; p.D[1] = c.D.y; p.D[2] = c.D.z; p.D[3] = c.D.w;
-    lre inv = invert_lre(c.pose);                                      // Camera.cu:21
-    memcpy(p.camera_pose, &c.pose, sizeof p.camera_pose);
+    lre inv = invert_lre(pose);                                        // Camera.cu:21
+    memcpy(p.camera_pose, &pose, sizeof p.camera_pose);
     memcpy(p.inv_camera_pose, &inv, sizeof p.inv_camera_pose);
     return p;
 }
 
 void Camera::render_scene(Scene& scene, uchar3* img_ptr, size_t pitch, bool synchronize)
 {
-    RtCameraParams p = camera_params(*this);
+    RtCameraParams p = camera_params(*this, pose);
     last_error = rt_render(scene.d_scene, &p, (uint8_t*)img_ptr, pitch, stream, synchronize ? 1 : 0);
 }
 
 void Camera::render_scene_stripes(Scene& scene, uchar3* local_ptr, size_t local_pitch, int stripe_rows, int rank, int num_ranks,
                                   bool synchronize)
 {
-    RtCameraParams p = camera_params(*this);
+    RtCameraParams p = camera_params(*this, pose);
     last_error = rt_render_stripes(scene.d_scene, &p, (uint8_t*)local_ptr, local_pitch, stripe_rows, rank, num_ranks, stream,
                                    synchronize ? 1 : 0);
+}
+
+void Camera::render_scene_batch(Scene& scene, const lre* poses, int count, uchar3* const* img_ptrs, size_t pitch, bool synchronize)
+{
+    if (count < 1 || count > RT_MAX_BATCH || !poses || !img_ptrs) { last_error = RT_E_INVALID; return; }
+    RtCameraParams p[RT_MAX_BATCH];
+    for (int i = 0; i < count; i++) p[i] = camera_params(*this, poses[i]);
+    last_error = rt_render_batch(scene.d_scene, p, (uint8_t* const*)img_ptrs, pitch, count, stream, synchronize ? 1 : 0);
+}
+
+void Camera::render_scene_stripes_batch(Scene& scene, const lre* poses, int count, uchar3* const* local_ptrs, size_t local_pitch,
+                                        int stripe_rows, int rank, int num_ranks, bool synchronize)
+{
+    if (count < 1 || count > RT_MAX_BATCH || !poses || !local_ptrs) { last_error = RT_E_INVALID; return; }
+    RtCameraParams p[RT_MAX_BATCH];
+    for (int i = 0; i < count; i++) p[i] = camera_params(*this, poses[i]);
+    last_error = rt_render_stripes_batch(scene.d_scene, p, (uint8_t* const*)local_ptrs, local_pitch, count, stripe_rows, rank,
+                                         num_ranks, stream, synchronize ? 1 : 0);
 }
 
 // ----------------------------------------------------------------------------- OBJLoader

@@ -123,6 +123,25 @@ int rth_camera_render_scene(RthCamera* c, RthScene* s, void* d_img, size_t pitch
 int rth_camera_render_scene_stripes(RthCamera* c, RthScene* s, void* d_local, size_t local_pitch, int32_t stripe_rows, int32_t rank,
                                     int32_t num_ranks, int synchronize)
 { c->cam.render_scene_stripes(s->scene, (uchar3*)d_local, local_pitch, stripe_rows, rank, num_ranks, synchronize != 0); return c->cam.last_error; }
+int rth_camera_render_scene_batch(RthCamera* c, RthScene* s, const float* poses6, void* const* d_imgs, size_t pitch, int32_t count,
+                                  int synchronize)
+{
+    if (count < 1 || count > RT_MAX_BATCH) return RT_E_INVALID;
+    lre poses[RT_MAX_BATCH];
+    for (int i = 0; i < count; i++) poses[i] = LRE(poses6 + 6 * i);
+    c->cam.render_scene_batch(s->scene, poses, count, (uchar3* const*)d_imgs, pitch, synchronize != 0);
+    return c->cam.last_error;
+}
+int rth_camera_render_scene_stripes_batch(RthCamera* c, RthScene* s, const float* poses6, void* const* d_locals, size_t local_pitch,
+                                          int32_t count, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int synchronize)
+{
+    if (count < 1 || count > RT_MAX_BATCH) return RT_E_INVALID;
+    lre poses[RT_MAX_BATCH];
+    for (int i = 0; i < count; i++) poses[i] = LRE(poses6 + 6 * i);
+    c->cam.render_scene_stripes_batch(s->scene, poses, count, (uchar3* const*)d_locals, local_pitch, stripe_rows, rank, num_ranks,
+                                      synchronize != 0);
+    return c->cam.last_error;
+}
 void rth_camera_params(const RthCamera* c, void* out)
 {
     RtCameraParams p;

@@ -52,12 +52,20 @@ struct DevMaterial {            // Material.hpp:6-16 (fields the path reads)
     const uint8_t* texture;
 };
 
-struct RenderParams {
-    int32_t width, height;
+constexpr int kMaxBatch = 8;    // frames per launch (rt_render_batch)
+
+struct FrameParams {            // what differs between the frames of one batched launch
     float kinv[9];
     float D[4];
     float origin[3];
     Q4 q_cam;                   // euler2quat(inv_camera_pose ypr), raycast.cu:185
+    uint8_t* img;
+};
+
+struct RenderParams {
+    int32_t width, height;
+    int32_t num_frames;         // grid.y
+    FrameParams frames[kMaxBatch];
     const float4* inodes;
     const float4* tris;
     const float* tri_uv;        // [slot][3][2]
@@ -67,7 +75,6 @@ struct RenderParams {
     const DevMaterial* materials;
     int32_t num_instances;
     int32_t stack_depth;        // LDS stack entries per lane
-    uint8_t* img;
     uint64_t pitch;
     // stripes: local row ly is frame row ((ly / stripe_rows) * num_ranks + rank) * stripe_rows + ly % stripe_rows
     int32_t local_rows, stripe_rows, rank, num_ranks;

@@ -56,7 +56,7 @@ __device__ __forceinline__ float slab(float mnx, float mny, float mnz, float mxx
 }
 
 // Primary ray direction of pixel (x, y): raycast.cu:159-188
-__device__ __forceinline__ V3 camera_direction(const RenderParams& p, int x, int y)
+__device__ __forceinline__ V3 camera_direction(const FrameParams& p, int x, int y)
 {
     float fx = (float)x, fy = (float)y;
     // apply_matrix(K_inv, (x, y, 1)), utils.hpp:134-140
@@ -230,7 +230,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             for (int o = 32; o > 0; o >>= 1) { unsigned long long x = __shfl_xor(best, o); best = x > best ? x : best; }
             const unsigned long long owner = __ballot(n_it == best);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)owner) - 1) {
-                unsigned long long* t = p.trace + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + 4;
+                unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + 4;
                 for (int k = 0; k < 7; k++) t[k] += v[k];
             }
         }
@@ -277,10 +277,10 @@ __device__ __forceinline__ void shade(const RenderParams& p, const Hit& hit, uin
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
 // (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
 template <bool DEBUG, bool PROF>
-__device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly, int y, int* stack)
+__device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x, int ly, int y, int* stack)
 {
-    const V3 org = v3(p.origin[0], p.origin[1], p.origin[2]);
-    const V3 dir = camera_direction(p, x, y);
+    const V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
+    const V3 dir = camera_direction(f, x, y);
 
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
@@ -290,7 +290,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 
     uint8_t px[3];
     shade(p, hit, px);
-    uint8_t* out = p.img + (size_t)ly * p.pitch + 3 * (size_t)x;
+    uint8_t* out = f.img + (size_t)ly * p.pitch + 3 * (size_t)x;
     out[0] = px[0]; out[1] = px[1]; out[2] = px[2];
 
     if constexpr (DEBUG) {
@@ -324,10 +324,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
     if (x < p.width && ly < p.local_rows) {
         // stripes: local row -> frame row (identity when num_ranks == 1)
         const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
-        render_pixel<DEBUG, PROF>(p, x, ly, y, lds_stack + tid);
+        render_pixel<DEBUG, PROF>(p, p.frames[blockIdx.y], x, ly, y, lds_stack + tid);   // blockIdx.y = frame of the batch
     }
     if (p.trace && lane == 0) {                                 // diagnostic: per-wave lifetime (RT_TRACE_FILE)
-        unsigned long long* t = p.trace + ((size_t)blockIdx.x * (kBlock / 64) + wave) * 16;
+        unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave) * 16;
         t[0] = t_start; t[1] = wall_clock64();
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
 }
 
 // rows of a rank-major gathered buffer back into frame order (rt_unstripe)
-__global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pitch, int max_local_rows,
+__global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pitch, size_t rank_stride,
                                 uint8_t* __restrict__ dst, size_t pitch, int row_bytes, int height,
                                 int stripe_rows, int num_ranks)
 {
@@ -344,7 +344,7 @@ __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pi
     if (y >= height) return;
     const int stripe = y / stripe_rows, rank = stripe % num_ranks;
     const int ly = (stripe / num_ranks) * stripe_rows + y % stripe_rows;
-    const uint8_t* s = src + ((size_t)rank * max_local_rows + ly) * local_pitch;
+    const uint8_t* s = src + (size_t)rank * rank_stride + (size_t)ly * local_pitch;
     uint8_t* d = dst + (size_t)y * pitch;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
@@ -416,21 +416,33 @@ int upload(T** dptr, const std::vector<T>& h, size_t& total)
 
 int32_t leaf_ref(int64_t slot, int count) { return kLeafFlag | ((count <= 30 ? count : 31) << kSlotBits) | (int32_t)slot; }
 
-void fill_params(RenderParams& p, const RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch)
+bool camera_ok(const RtCameraParams* cam) { return cam && cam->width > 0 && cam->height > 0; }
+
+// count cameras (same width/height) -> the per-frame part of the launch parameters
+int fill_params(RenderParams& p, const RtScene* s, const RtCameraParams* cams, uint8_t* const* d_imgs, int count, size_t pitch)
 {
+    if (!s || !cams || !d_imgs || count < 1 || count > kMaxBatch || !camera_ok(&cams[0]) || pitch < (size_t)cams[0].width * 3) return RT_E_INVALID;
     memset(&p, 0, sizeof p);
-    p.width = cam->width; p.height = cam->height;
-    memcpy(p.kinv, cam->K_inv, sizeof p.kinv);
-    memcpy(p.D, cam->D, sizeof p.D);
-    p.origin[0] = cam->camera_pose[0]; p.origin[1] = cam->camera_pose[1]; p.origin[2] = cam->camera_pose[2];
-    p.q_cam = euler2quat(v3(cam->inv_camera_pose[3], cam->inv_camera_pose[4], cam->inv_camera_pose[5]));
+    p.width = cams[0].width; p.height = cams[0].height;
+    p.num_frames = count;
+    for (int i = 0; i < count; i++) {
+        const RtCameraParams* cam = &cams[i];
+        if (cam->width != p.width || cam->height != p.height || !d_imgs[i]) return RT_E_INVALID;
+        FrameParams& f = p.frames[i];
+        memcpy(f.kinv, cam->K_inv, sizeof f.kinv);
+        memcpy(f.D, cam->D, sizeof f.D);
+        f.origin[0] = cam->camera_pose[0]; f.origin[1] = cam->camera_pose[1]; f.origin[2] = cam->camera_pose[2];
+        f.q_cam = euler2quat(v3(cam->inv_camera_pose[3], cam->inv_camera_pose[4], cam->inv_camera_pose[5]));
+        f.img = d_imgs[i];
+    }
     p.inodes = s->d_inodes; p.tris = s->d_tris; p.tri_uv = s->d_tri_uv; p.tri_id = s->d_tri_id;
     p.leaf_count = s->d_leaf_count;
     p.instances = s->d_instances; p.materials = s->d_materials;
     p.num_instances = (int32_t)s->instances.size();
     p.stack_depth = s->max_stack;
-    p.img = d_img; p.pitch = pitch;
-    p.local_rows = cam->height; p.stripe_rows = cam->height > 0 ? cam->height : 1; p.rank = 0; p.num_ranks = 1;
+    p.pitch = pitch;
+    p.local_rows = p.height; p.stripe_rows = p.height; p.rank = 0; p.num_ranks = 1;
+    return RT_OK;
 }
 
 int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
@@ -440,9 +452,9 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
     p.tiles_x = (p.width + kTile - 1) / kTile;
     p.tiles_y = (p.local_rows + kTile - 1) / kTile;
     const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y)), block(kBlock);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kBlock);
     const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
-    const size_t trace_n = (size_t)grid.x * (kBlock / 64) * 16;
+    const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
     if (trace_file) { RT_HIP(hipMalloc((void**)&p.trace, trace_n * 8)); RT_HIP(hipMemset(p.trace, 0, trace_n * 8)); }
     if (trace_file && getenv("RT_TRACE_PROF")) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, stream, p);
     else if (debug) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);
@@ -458,8 +470,6 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
 }
-
-bool camera_ok(const RtCameraParams* cam) { return cam && cam->width > 0 && cam->height > 0; }
 
 }  // namespace
 
@@ -679,20 +689,27 @@ int rt_scene_info(const RtScene* s, size_t* device_bytes, int32_t* max_stack)
     return RT_OK;
 }
 
+int rt_render_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_imgs, size_t pitch, int32_t count,
+                    void* stream, int synchronize)
+{
+    RenderParams p;
+    int rc = fill_params(p, s, cams, d_imgs, count, pitch);
+    if (rc) return rc;
+    return launch(p, false, (hipStream_t)stream, synchronize);
+}
+
 int rt_render(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, void* stream, int synchronize)
 {
-    if (!s || !camera_ok(cam) || !d_img || pitch < (size_t)cam->width * 3) return RT_E_INVALID;
-    RenderParams p;
-    fill_params(p, s, cam, d_img, pitch);
-    return launch(p, false, (hipStream_t)stream, synchronize);
+    return rt_render_batch(s, cam, &d_img, pitch, 1, stream, synchronize);
 }
 
 int rt_render_debug(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch,
                     const RtDebugPlanes* planes, void* stream, int synchronize)
 {
-    if (!s || !camera_ok(cam) || !d_img || !planes || pitch < (size_t)cam->width * 3) return RT_E_INVALID;
+    if (!planes) return RT_E_INVALID;
     RenderParams p;
-    fill_params(p, s, cam, d_img, pitch);
+    int rc = fill_params(p, s, cam, &d_img, 1, pitch);
+    if (rc) return rc;
     p.hit_instance = planes->hit_instance; p.hit_triangle = planes->hit_triangle; p.node_pops = planes->node_pops;
     p.aabb_tests = planes->aabb_tests; p.tri_tests = planes->tri_tests; p.inside_hits = planes->inside_hits;
     return launch(p, true, (hipStream_t)stream, synchronize);
@@ -708,26 +725,31 @@ int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t nu
     return RT_OK;
 }
 
-int rt_render_stripes(RtScene* s, const RtCameraParams* cam, uint8_t* d_local, size_t local_pitch,
-                      int32_t stripe_rows, int32_t rank, int32_t num_ranks, void* stream, int synchronize)
+int rt_render_stripes_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_locals, size_t local_pitch, int32_t count,
+                            int32_t stripe_rows, int32_t rank, int32_t num_ranks, void* stream, int synchronize)
 {
-    int32_t rows = 0;
-    if (!s || !camera_ok(cam) || !d_local || local_pitch < (size_t)cam->width * 3) return RT_E_INVALID;
-    int rc = rt_stripe_rows(cam->height, stripe_rows, rank, num_ranks, &rows);
-    if (rc) return rc;
     RenderParams p;
-    fill_params(p, s, cam, d_local, local_pitch);
+    int rc = fill_params(p, s, cams, d_locals, count, local_pitch);
+    if (rc) return rc;
+    int32_t rows = 0;
+    if ((rc = rt_stripe_rows(p.height, stripe_rows, rank, num_ranks, &rows))) return rc;
     p.local_rows = rows; p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
     return launch(p, false, (hipStream_t)stream, synchronize);
 }
 
-int rt_unstripe(const uint8_t* d_gathered, size_t local_pitch, int32_t max_local_rows, uint8_t* d_img, size_t pitch,
+int rt_render_stripes(RtScene* s, const RtCameraParams* cam, uint8_t* d_local, size_t local_pitch,
+                      int32_t stripe_rows, int32_t rank, int32_t num_ranks, void* stream, int synchronize)
+{
+    return rt_render_stripes_batch(s, cam, &d_local, local_pitch, 1, stripe_rows, rank, num_ranks, stream, synchronize);
+}
+
+int rt_unstripe(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, uint8_t* d_img, size_t pitch,
                 int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void* stream)
 {
     if (!d_gathered || !d_img || width <= 0 || height <= 0 || stripe_rows <= 0 || num_ranks <= 0 ||
         local_pitch < (size_t)width * 3 || pitch < (size_t)width * 3) return RT_E_INVALID;
     dim3 grid(4, (unsigned)height), block(256);
-    hipLaunchKernelGGL(unstripe_kernel, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, max_local_rows,
+    hipLaunchKernelGGL(unstripe_kernel, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride,
                        d_img, pitch, width * 3, height, stripe_rows, num_ranks);
     RT_HIP(hipGetLastError());
     return RT_OK;

@@ -32,6 +32,20 @@ def unstripe_host(gathered, height, stripe, world):
     return out
 
 
+# ---- buffer layout when F frames travel in one gather --------------------------------------------------
+# local buffer of a rank:   [F][max_rows][pitch]           (frame f starts f * max_rows rows in)
+# gathered buffer on dst:   [world][F][max_rows][pitch]    (rank r starts r * F * max_rows rows in)
+
+def batch_local_ptrs(local_base, F, max_rows, pitch):
+    """Device pointers of the F per-frame stripe buffers inside one rank's local buffer."""
+    return [local_base + f * max_rows * pitch for f in range(F)]
+
+
+def batch_unstripe_args(gathered_base, f, F, max_rows, pitch):
+    """(d_gathered, rank_stride) to pass to rt_unstripe for frame f of a gathered batch."""
+    return gathered_base + f * max_rows * pitch, F * max_rows * pitch
+
+
 def gather_stripes(local, gathered, rank, dst=0):
     """One frame's exchange step: every rank's padded local stripe buffer to rank `dst`.
     local: [max_rows, pitch] uint8 tensor; gathered: [world, max_rows, pitch] on dst, None elsewhere."""

@@ -124,6 +124,12 @@ int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack
  *      bytes, 3 bytes per pixel in uchar3 .x .y .z order (raycast.cu:292-294).  Asynchronous on
  *      `stream` unless synchronize != 0 (Camera.cu:38-39). ------------------------------------- */
 int rt_render(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch, void *stream, int synchronize);
+/* `count` (1..RT_MAX_BATCH) frames of the same size in ONE launch: cams[i] is rendered into d_imgs[i].  A frame
+ * stream rendered this way keeps the GPU full while the last long rays of one frame finish (the reference's own
+ * loop issues two renders before it synchronises, kernel.cu:277-279). */
+#define RT_MAX_BATCH 8
+int rt_render_batch(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_imgs, size_t pitch, int32_t count,
+                    void *stream, int synchronize);
 /* same frame plus the parity planes */
 int rt_render_debug(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch,
                     const RtDebugPlanes *planes, void *stream, int synchronize);
@@ -135,9 +141,11 @@ int rt_render_debug(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, s
 int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t *rows);
 int rt_render_stripes(RtScene *scene, const RtCameraParams *cam, uint8_t *d_local, size_t local_pitch,
                       int32_t stripe_rows, int32_t rank, int32_t num_ranks, void *stream, int synchronize);
-/* after a gather of every rank's local buffer (each padded to max_local_rows rows of local_pitch
- * bytes, rank-major) place the rows back into frame order */
-int rt_unstripe(const uint8_t *d_gathered, size_t local_pitch, int32_t max_local_rows,
+int rt_render_stripes_batch(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_locals, size_t local_pitch,
+                            int32_t count, int32_t stripe_rows, int32_t rank, int32_t num_ranks, void *stream, int synchronize);
+/* after a gather of every rank's local buffer (rank r's rows start at d_gathered + r * rank_stride bytes, rows
+ * local_pitch bytes apart) place the rows back into frame order */
+int rt_unstripe(const uint8_t *d_gathered, size_t local_pitch, size_t rank_stride,
                 uint8_t *d_img, size_t pitch, int32_t width, int32_t height,
                 int32_t stripe_rows, int32_t num_ranks, void *stream);
 

@@ -60,6 +60,12 @@ void rth_camera_set_stream(RthCamera *c, void *stream);
 int rth_camera_render_scene(RthCamera *c, RthScene *s, void *d_img, size_t pitch, int synchronize);
 int rth_camera_render_scene_stripes(RthCamera *c, RthScene *s, void *d_local, size_t local_pitch,
                                     int32_t stripe_rows, int32_t rank, int32_t num_ranks, int synchronize);
+/* Camera::render_scene_batch: `count` frames along a camera path (poses6 = count x lre) in one launch (rt_render_batch) */
+int rth_camera_render_scene_batch(RthCamera *c, RthScene *s, const float *poses6, void *const *d_imgs, size_t pitch,
+                                  int32_t count, int synchronize);
+int rth_camera_render_scene_stripes_batch(RthCamera *c, RthScene *s, const float *poses6, void *const *d_locals,
+                                          size_t local_pitch, int32_t count, int32_t stripe_rows, int32_t rank,
+                                          int32_t num_ranks, int synchronize);
 /* the RtCameraParams (rt_hip.h) the camera would launch with: 1 + 1 + 9 + 4 + 6 + 6 words */
 void rth_camera_params(const RthCamera *c, void *out_RtCameraParams);
 

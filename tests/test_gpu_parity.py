@@ -144,9 +144,69 @@ def test_stripes_equal_full_frame(rt, orc, scenes, blob5k):
         for r in range(nr):
             cam.render_scene_stripes(sp, gathered.ptr.value + r * maxr * pitch, pitch, stripe, r, nr, synchronize=True)
         out = rt.DeviceBuffer(width_bytes=W * 3, height=H)
-        rt.check(h.rt_unstripe(gathered.ptr, pitch, maxr, out.ptr, out.pitch, W, H, stripe, nr, None))
+        rt.check(h.rt_unstripe(gathered.ptr, pitch, maxr * pitch, out.ptr, out.pitch, W, H, stripe, nr, None))
         rt.check(h.rt_device_synchronize())
         got = out.to_host().reshape(H, W, 3)
         assert np.array_equal(got, full), "stripes nr=%d stripe=%d" % (nr, stripe)
         gathered.free()
         out.free()
+
+
+def test_batched_frames_equal_single_frames(rt, orc, scenes, blob5k):
+    """rt_render_batch: a camera path of 1..8 frames in one launch == the same frames rendered one by one
+    (and frame 0 == the oracle)."""
+    W, H = 200, 120
+    desc = sd.blob_scene(scenes, blob5k)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    K = scenes.scaled_K(W)
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    poses = [(0.05 * i, -1.5 - 0.15 * i, 0.2 + 0.02 * i, 0.02 * i, -0.01 * i, 0.0) for i in range(8)]
+    singles = []
+    for ps in poses:
+        cam.set_pose(ps)
+        singles.append(rt.render(sp, cam))
+    so = desc.build_oracle(orc)
+    assert np.array_equal(singles[0], so.render(W, H, K, scenes.D_REF, poses[0], planes=False)["img"])
+    for n in (1, 3, 8):
+        bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(n)]
+        cam.render_scene_batch(sp, poses[:n], [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)
+        for i, b in enumerate(bufs):
+            assert np.array_equal(b.to_host().reshape(H, W, 3), singles[i]), "batch %d frame %d" % (n, i)
+            b.free()
+    with pytest.raises(rt.RtError):
+        cam.render_scene_batch(sp, poses + poses[:1], [0] * 9, W * 3)
+
+
+def test_batched_stripes_layout(rt, scenes, blob5k):
+    """The buffer layout bench.py uses for N ranks x F frames per gather: every virtual rank renders its F stripe
+    buffers straight into its slice of the gathered buffer, then each frame is un-striped and compared."""
+    import importlib
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    W, H, F, stripe = 210, 133, 3, 16
+    sp = sd.blob_scene(scenes, blob5k).build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+    poses = [(0.03 * i, -1.6 - 0.2 * i, 0.2, 0.0, 0.01 * i, 0.0) for i in range(F)]
+    full = []
+    for ps in poses:
+        cam.set_pose(ps)
+        full.append(rt.render(sp, cam))
+    pitch = W * 3
+    for world in (2, 8):
+        max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+        gathered = rt.DeviceBuffer(nbytes=world * F * max_rows * pitch)
+        g0 = gathered.ptr.value
+        for r in range(world):
+            local_base = g0 + r * F * max_rows * pitch          # what the gather would place there
+            cam.render_scene_stripes_batch(sp, poses, tiling.batch_local_ptrs(local_base, F, max_rows, pitch), pitch, stripe, r, world,
+                                           synchronize=True)
+        for f in range(F):
+            out = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+            src, rank_stride = tiling.batch_unstripe_args(g0, f, F, max_rows, pitch)
+            rt.check(h.rt_unstripe(src, pitch, rank_stride, out.ptr, out.pitch, W, H, stripe, world, None))
+            rt.check(h.rt_device_synchronize())
+            assert np.array_equal(out.to_host().reshape(H, W, 3), full[f]), "world %d frame %d" % (world, f)
+            out.free()
+        gathered.free()

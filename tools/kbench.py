@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="blob70k", choices=["blob70k", "blob5k", "atrium"])
+    ap.add_argument("--batch", type=int, default=1, help="frames per launch (rt_render_batch)")
     ap.add_argument("--check", action="store_true", help="compare the frame hash with the debug kernel's")
     a = ap.parse_args()
     rt.build()
@@ -37,17 +38,24 @@ def main():
     W, H = a.width, a.height
     cams = {"atrium": {"inside": scenes.C4["cam_pose"]}}.get(a.scene, scenes.C2_CAMERAS)
     img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    extra = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(a.batch - 1)]
+    ptrs = [img.ptr] + [e.ptr for e in extra]
     t = rt.Timer()
     for name, pose in cams.items():
         cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
         cam.set_pose(pose)
+        def go():
+            if a.batch == 1:
+                cam.render_scene(scene, img.ptr, img.pitch)
+            else:
+                cam.render_scene_batch(scene, [pose] * a.batch, ptrs, img.pitch)
         for _ in range(5):
-            cam.render_scene(scene, img.ptr, img.pitch)
+            go()
         t.start()
         for _ in range(a.iters):
-            cam.render_scene(scene, img.ptr, img.pitch)
+            go()
         t.stop()
-        ms = t.elapsed_ms() / a.iters
+        ms = t.elapsed_ms() / a.iters / a.batch
         line = "%-6s %.4f ms  %.1f Mrays/s" % (name, ms, W * H / ms / 1e3)
         if a.check:
             import numpy as np
