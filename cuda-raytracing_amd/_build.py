@@ -41,7 +41,19 @@ def _host_deps():
 
 
 def build(force=False, verbose=False):
-    """Compile whatever is out of date.  Raises CalledProcessError on a compiler error."""
+    """Compile whatever is out of date.  Raises CalledProcessError on a compiler error.
+    Safe to call from several processes at once (one rank per GPU): an exclusive file lock serialises them
+    and every process after the first finds the libraries fresh."""
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     if force or _stale(HIP_SO, HIP_DEPS):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-o", HIP_SO] + HIP_SRCS

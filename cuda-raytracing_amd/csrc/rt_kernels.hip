@@ -82,6 +82,28 @@ struct Counters {
 template <>
 struct Counters<false> {};
 
+// Per-lane traversal stack (raycast.cu:54-61).  The first `lds_depth` entries live in LDS, one column per lane
+// ([entry][kBlock] ints: a wave's accesses are conflict-free); deeper entries -- rare: the tree may be 28+ levels
+// deep but rays seldom hold more than a dozen postponed nodes -- spill to a private (scratch) array.  Keeping the
+// LDS part at 16 entries lets 8 waves/SIMD stay resident (16 KB per 256-thread workgroup).
+constexpr int kLdsStack = 16;
+struct Stack {
+    int* lds;                   // this lane's LDS column
+    int* spill;                 // this lane's private overflow, kMaxStack - kLdsStack entries
+    int lds_depth;              // entries kept in LDS (<= kLdsStack)
+    int sp;
+    __device__ __forceinline__ void push(int32_t v)
+    {
+        if (sp < lds_depth) lds[sp * kBlock] = v; else spill[sp - lds_depth] = v;
+        sp++;
+    }
+    __device__ __forceinline__ int32_t pop()
+    {
+        --sp;
+        return sp < lds_depth ? lds[sp * kBlock] : spill[sp - lds_depth];
+    }
+};
+
 // Ray in mesh space (raycast.cu:33-51) plus what the leaf code needs of the instance.
 struct MeshRay {
     V3 ro, rd, dinv;
@@ -103,7 +125,7 @@ __device__ __forceinline__ MeshRay to_mesh_space(const DevInstance& in, V3 org, 
 // pushed last never goes through the stack).  Returns false when nothing was pushed.
 template <bool DEBUG>
 __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, float4 q3, const MeshRay& r, float hit_min,
-                                               int32_t& cur, int* stack, int& sp, Counters<DEBUG>& cnt)
+                                               int32_t& cur, Stack& stack, Counters<DEBUG>& cnt)
 {
     float da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.ro, r.dinv);
     float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ro, r.dinv);
@@ -114,7 +136,7 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     if (da < db) { first = rb; pf = pb; second = ra; ps = pa; }
     else         { first = ra; pf = pa; second = rb; ps = pb; }
     if (ps) {
-        if (pf) stack[(sp++) * kBlock] = first;
+        if (pf) stack.push(first);
         cur = second;
         return true;
     }
@@ -180,8 +202,7 @@ __device__ __forceinline__ void leaf_step(const RenderParams& p, const DevInstan
     }
 }
 
-// One instance of raycast.cu:26-139.  `stack` points at this lane's column of the LDS stack (entries kBlock
-// ints apart, so a wave's accesses are conflict-free).
+// One instance of raycast.cu:26-139.
 //
 // Interior nodes and triangles are both 64-B records, so every lane issues the same four 16-B loads from a
 // selected base ("unified fetch") and the wave waits for memory once per iteration, whatever mix of interior
@@ -189,18 +210,18 @@ __device__ __forceinline__ void leaf_step(const RenderParams& p, const DevInstan
 // PROF = diagnostic copy with s_memtime stamps per phase (RT_TRACE_FILE); its frames are never timed.
 template <bool DEBUG, bool PROF>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
-                                               V3 org, V3 dir, int* stack, Hit& hit, Counters<DEBUG>& cnt)
+                                               V3 org, V3 dir, Stack& stack, Hit& hit, Counters<DEBUG>& cnt)
 {
     const MeshRay r = to_mesh_space(in, org, dir);
-    int sp = 0;
+    stack.sp = 0;
     int32_t cur = in.root_ref;                                  // raycast.cu:58 (kept in a register)
     bool have = true;
     unsigned long long c_pop = 0, c_mem = 0, c_int = 0, c_leaf = 0, n_it = 0, n_int = 0, n_leaf = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     while (true) {
         if constexpr (PROF) t0 = __builtin_amdgcn_s_memtime();
         if (!have) {
-            if (sp == 0) break;
-            cur = stack[(--sp) * kBlock];                       // raycast.cu:61
+            if (stack.sp == 0) break;
+            cur = stack.pop();                                  // raycast.cu:61
         }
         if constexpr (DEBUG) cnt.pops++;
         const bool interior = cur >= 0;
@@ -212,7 +233,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             t2 = __builtin_amdgcn_s_memtime();
             n_it++; n_int += __ballot(interior) != 0; n_leaf += __ballot(!interior) != 0;
         }
-        if (interior) have = interior_apply<DEBUG>(r0, r1, r2, r3, r, hit.min, cur, stack, sp, cnt);
+        if (interior) have = interior_apply<DEBUG>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t3 = __builtin_amdgcn_s_memtime(); }
         if (!interior) {
             leaf_step<DEBUG>(p, in, inst_index, r, org, cur, hit, cnt, r0, r1, r2, r3);
@@ -277,7 +298,7 @@ __device__ __forceinline__ void shade(const RenderParams& p, const Hit& hit, uin
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
 // (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
 template <bool DEBUG, bool PROF>
-__device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x, int ly, int y, int* stack)
+__device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x, int ly, int y, int* lds_column)
 {
     const V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     const V3 dir = camera_direction(f, x, y);
@@ -285,6 +306,9 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
     Counters<DEBUG> cnt;
+    int spill[kMaxStack - kLdsStack];
+    Stack stack;
+    stack.lds = lds_column; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
     for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
         trace_instance<DEBUG, PROF>(p, p.instances[i], i, org, dir, stack, hit, cnt);
 
@@ -307,7 +331,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
 template <bool DEBUG, bool PROF>
 __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
 {
-    extern __shared__ int lds_stack[];                          // [stack_depth][kBlock]
+    extern __shared__ int lds_stack[];                          // [min(stack_depth, kLdsStack)][kBlock]
 
     // Workgroup b renders tile b (row-major) unless an explicit order is given.  Consecutive workgroups are
     // dealt round-robin to the 8 XCDs, so every XCD sees tiles from the whole frame: measured faster than giving
@@ -451,7 +475,7 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
     if (p.local_rows == 0) return RT_OK;
     p.tiles_x = (p.width + kTile - 1) / kTile;
     p.tiles_y = (p.local_rows + kTile - 1) / kTile;
-    const size_t lds = (size_t)p.stack_depth * kBlock * sizeof(int);
+    const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kBlock);
     const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
     const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;

@@ -60,3 +60,11 @@ def blob5k(scenes, cache_dir):
     if not os.path.exists(p):
         scenes.write_blob_obj(p, 50, 51)
     return p
+
+
+@pytest.fixture(scope="session")
+def atrium(scenes, cache_dir):
+    p = os.path.join(cache_dir, "atrium.obj")
+    if not os.path.exists(p):
+        scenes.write_atrium_obj(p)
+    return p

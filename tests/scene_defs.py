@@ -93,3 +93,26 @@ def multi_instance_scene(scenes, blob_path):
 
 
 MULTI_CAMERA = dict(width=320, height=200, pose=(0.1, -3.0, 0.4, 0.15, -0.05, 0.1))
+
+
+def atrium_scene(scenes, path):
+    """BASELINE.json configs[3] geometry ("Sponza-class", 260 352 triangles, camera inside) with a textured material so
+    that RGB varies across the frame."""
+    return SceneDesc([(scenes.C4["albedo"], checker_texture(128, 96, seed=21))], [("obj", path)], [(0, 0, (0,) * 6, (1, 1, 1))])
+
+
+def deep_stack_scene(n=28):
+    """Triangles at exponentially growing distance along the view axis (+y), each facing the camera and subtending the
+    same angle: the BVH degenerates into a chain (about n levels, capped at 32 by the builder) and central rays keep
+    one postponed far child per level on the traversal stack -- far more than the 16 entries the kernel keeps in LDS."""
+    import orc
+    o = orc.oracle()
+    tris = np.zeros((n, 18), np.float32)
+    for i in range(n):
+        y = 1e-4 * (6.1 ** i)                 # each triangle 6.1x farther: every candidate plane splits off only the last one
+                                              # (y^2 must stay finite in fp32, which caps the chain near 28 levels)
+        h = 0.6 * (y + 1.0)
+        # winding chosen so the normal points to -y (towards a camera at y = -1)
+        tris[i] = o.tri_from_vertices(np.array([-h, y, -h, h, y, -h, 0.0, y, h], np.float32))
+        tris[i, 12:18] = [0, 0, 0.5, 1, 1, 0]
+    return SceneDesc([((0.2, 0.9, 0.4), None)], [("tris", tris)], [(0, 0, (0,) * 6, (1, 1, 1))])

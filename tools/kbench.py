@@ -30,7 +30,7 @@ def main():
          "atrium": scenes.write_atrium_obj}[a.scene](obj)
     mesh = rt.Mesh.load_obj(obj)
     scene = rt.Scene()
-    scene.add_material(scenes.C2["albedo"])
+    scene.add_material(scenes.C4["albedo"] if a.scene == "atrium" else scenes.C2["albedo"])
     scene.add_mesh(mesh)
     scene.add_mesh_instance(0, 0)
     scene.upload_to_device()
