@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--height", type=int, default=scenes.C2["height"])
     ap.add_argument("--frames-per-launch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,15 +215,16 @@ def main():
                 render_local(0)
         timer.stop(stream)
         kernel_ms = timer.elapsed_ms() / n                      # one launch = F frames (this rank's stripes of them)
-        # latency of a single-frame launch, for reference
-        one = rt.DeviceBuffer(width_bytes=W * 3, height=H)
-        torch.cuda.synchronize()
-        timer.start(stream)
-        for _ in range(20):
-            cam.render_scene(scene, one.ptr, one.pitch)
-        timer.stop(stream)
-        single_ms = timer.elapsed_ms() / 20
-        one.free()
+        single_ms = None
+        if args.latency_probe:                                  # latency of a single-frame launch, for reference
+            one = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+            torch.cuda.synchronize()
+            timer.start(stream)
+            for _ in range(20):
+                cam.render_scene(scene, one.ptr, one.pitch)
+            timer.stop(stream)
+            single_ms = timer.elapsed_ms() / 20
+            one.free()
     if world > 1:
         dist.barrier()
 
@@ -253,7 +255,7 @@ def main():
                                    % (W, H, args.camera, str(tuple(pose[:3]))),
                        "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
                                       % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per %d frames" % F if world > 1 else ""),
-                       "frames_per_launch": F, "single_frame_launch_ms": round(single_ms, 4),
+                       "frames_per_launch": F, "single_frame_launch_ms": None if single_ms is None else round(single_ms, 4),
                        "coverage": round(st["hits"] / st["rays"], 4),
                        "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
                        "algorithmic_bytes_per_ray": round(alg_bytes / st["rays"], 1)},
