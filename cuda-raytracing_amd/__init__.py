@@ -42,16 +42,17 @@ RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
     "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
-    "rt_render_debug", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
+    "rt_render_debug", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
     "rth_obj_load", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
     "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
     "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
-    "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance",
+    "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance",
     "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
-    "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch",
+    "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
+    "rth_camera_render_scene_ex", "rth_xorwow",
     "rth_camera_params", "rth_q_rsqrt", "rth_atanf", "rth_normalize", "rth_invert_lre", "rth_apply_lre", "rth_euler2quat",
     "rth_apply_quat", "rth_invert_intrinsic", "rth_last_error"]
 
@@ -134,6 +135,11 @@ def _declare(h, s):
     s.rth_camera_render_scene_stripes_batch.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
                                                         C.c_int32, C.c_int]
     s.rth_camera_params.argtypes = [_vp, _vp]
+    s.rth_scene_set_material_params.argtypes = [_vp, C.c_int32, C.c_float, C.c_float, C.c_float]
+    s.rth_camera_set_options.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32]
+    s.rth_camera_render_scene_ex.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int]
+    s.rth_xorwow.restype = C.c_uint32
+    s.rth_xorwow.argtypes = [C.c_uint64, C.c_int32, _vp, _vp]
     s.rth_q_rsqrt.restype = C.c_float
     s.rth_q_rsqrt.argtypes = [C.c_float]
     s.rth_atanf.restype = C.c_float
@@ -232,8 +238,9 @@ class Scene:
         if not self.h:
             raise RtError("scene creation failed")
 
-    def add_material(self, albedo, texture_bgr=None, ppm=None):
+    def add_material(self, albedo, texture_bgr=None, ppm=None, roughness=0.0, metallic=0.0, illumination=0.0):
         s = libs()[1]
+        self._nmat = getattr(self, "_nmat", 0) + 1
         a = _fa(albedo)
         if ppm is not None:
             check(s.rth_scene_add_material_ppm(self.h, _fp(a), os.fsencode(ppm)), "add_material(ppm)")
@@ -242,6 +249,7 @@ class Scene:
             check(s.rth_scene_add_material(self.h, _fp(a), t.ctypes.data, t.shape[1], t.shape[0], t.strides[0]), "add_material")
         else:
             check(s.rth_scene_add_material(self.h, _fp(a), None, 0, 0, 0), "add_material")
+        check(s.rth_scene_set_material_params(self.h, self._nmat - 1, roughness, metallic, illumination), "set_material_params")
 
     def add_mesh(self, mesh):
         check(libs()[1].rth_scene_add_mesh(self.h, mesh.h), "add_mesh")
@@ -302,6 +310,13 @@ class Camera:
     def render_scene_stripes(self, scene, d_local, local_pitch, stripe_rows, rank, num_ranks, synchronize=False):
         check(libs()[1].rth_camera_render_scene_stripes(self.h, scene.h, d_local, local_pitch, stripe_rows, rank, num_ranks,
                                                         1 if synchronize else 0), "Camera::render_scene_stripes")
+
+    def set_options(self, spp=1, bounces=0, lighting=0):
+        libs()[1].rth_camera_set_options(self.h, spp, bounces, 1 if lighting else 0)
+
+    def render_scene_ex(self, scene, d_img, pitch, d_total_pops=None, synchronize=False):
+        check(libs()[1].rth_camera_render_scene_ex(self.h, scene.h, d_img, pitch, d_total_pops, 1 if synchronize else 0),
+              "Camera::render_scene_ex")
 
     def render_scene_batch(self, scene, poses, d_imgs, pitch, synchronize=False):
         """frames along a camera path in one launch: poses[i] -> d_imgs[i] (device pointers)"""
@@ -393,6 +408,18 @@ def render(scene, camera):
     camera.render_scene(scene, img.ptr, img.pitch, synchronize=True)
     out = img.to_host().reshape(H, W, 3)
     img.free()
+    return out
+
+
+def render_ex(scene, camera):
+    """One extension frame (camera.set_options) -> dict(img[h,w,3], total_pops[h,w])."""
+    W, H = camera.width, camera.height
+    img = DeviceBuffer(width_bytes=W * 3, height=H)
+    pops = DeviceBuffer(nbytes=W * H * 4)
+    camera.render_scene_ex(scene, img.ptr, img.pitch, pops.ptr, synchronize=True)
+    out = dict(img=img.to_host().reshape(H, W, 3), total_pops=pops.to_host(np.int32).reshape(H, W))
+    img.free()
+    pops.free()
     return out
 
 

@@ -18,10 +18,16 @@ public:
     float3x3 K_inv;
     float4 D;
     void* stream = nullptr;                        // hipStream_t; the reference always uses the default stream
+    // extension (rt_render_ex): with the defaults render_scene() is the reference's one-ray, illumination-1.0 frame
+    int spp = 1;                                   // samples per pixel (sample 0 = the reference ray)
+    int bounces = 0;                               // specular bounces (Material::metallic / roughness)
+    bool lighting = false;                         // sun + shadow pass of raycast.cu:249-287
     int last_error = 0;
 
     // asynchronous on `stream` unless synchronize (Camera.cu:38-39)
     void render_scene(Scene& scene, uchar3* img_ptr, size_t pitch, bool synchronize = false);
+    // extension frame with the optional per-pixel pops plane (device int32 [height][width]) for parity tests
+    void render_scene_ex(Scene& scene, uchar3* img_ptr, size_t pitch, int* d_total_pops, bool synchronize = false);
     // `count` frames (<= RT_MAX_BATCH) along a camera path in one launch: frame i uses poses[i] (K, D, size from
     // this camera) and goes to img_ptrs[i]; see rt_render_batch in rt_hip.h
     void render_scene_batch(Scene& scene, const lre* poses, int count, uchar3* const* img_ptrs, size_t pitch, bool synchronize = false);

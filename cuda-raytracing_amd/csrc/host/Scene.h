@@ -23,6 +23,8 @@ public:
     void add_material(Material material);
     void add_mesh(MeshPrimitive mesh);
     void add_mesh_instance(MeshInstance mesh_instance);
+    int num_materials() const { return (int)materials.size(); }
+    Material& material(int index) { return materials[index]; }      // edit before upload_to_device()
 
     RtScene* d_scene = nullptr;
     int num_mesh_instances = 0;

@@ -333,14 +333,30 @@ static RtCameraParams camera_params(const Camera& c, const lre& pose)
 
 void Camera::render_scene(Scene& scene, uchar3* img_ptr, size_t pitch, bool synchronize)
 {
+    if (spp != 1 || bounces != 0 || lighting) { render_scene_ex(scene, img_ptr, pitch, nullptr, synchronize); return; }
     RtCameraParams p = camera_params(*this, pose);
     last_error = rt_render(scene.d_scene, &p, (uint8_t*)img_ptr, pitch, stream, synchronize ? 1 : 0);
+}
+
+void Camera::render_scene_ex(Scene& scene, uchar3* img_ptr, size_t pitch, int* d_total_pops, bool synchronize)
+{
+    RtCameraParams p = camera_params(*this, pose);
+    RtRenderOptions o;
+    o.spp = spp; o.bounces = bounces; o.lighting = lighting ? 1 : 0;
+    last_error = rt_render_ex(scene.d_scene, &p, &o, (uint8_t*)img_ptr, pitch, d_total_pops, stream, synchronize ? 1 : 0);
 }
 
 void Camera::render_scene_stripes(Scene& scene, uchar3* local_ptr, size_t local_pitch, int stripe_rows, int rank, int num_ranks,
                                   bool synchronize)
 {
     RtCameraParams p = camera_params(*this, pose);
+    if (spp != 1 || bounces != 0 || lighting) {
+        RtRenderOptions o;
+        o.spp = spp; o.bounces = bounces; o.lighting = lighting ? 1 : 0;
+        last_error = rt_render_ex_stripes(scene.d_scene, &p, &o, (uint8_t*)local_ptr, local_pitch, stripe_rows, rank, num_ranks, stream,
+                                          synchronize ? 1 : 0);
+        return;
+    }
     last_error = rt_render_stripes(scene.d_scene, &p, (uint8_t*)local_ptr, local_pitch, stripe_rows, rank, num_ranks, stream,
                                    synchronize ? 1 : 0);
 }

@@ -95,6 +95,13 @@ int32_t rth_scene_add_material_ppm(RthScene* s, const float* albedo3, const char
     s->scene.add_material(std::move(m));
     return 0;
 }
+int rth_scene_set_material_params(RthScene* s, int32_t index, float roughness, float metallic, float illumination)
+{
+    if (index < 0 || index >= s->scene.num_materials()) return RT_E_INVALID;
+    Material& m = s->scene.material(index);
+    m.roughness = roughness; m.metallic = metallic; m.illumination = illumination;
+    return 0;
+}
 int32_t rth_scene_add_mesh(RthScene* s, const RthMesh* m) { try { s->scene.add_mesh(m->mesh); return 0; } catch (...) { return RT_E_NOMEM; } }
 int32_t rth_scene_add_mesh_instance(RthScene* s, int32_t mesh, int32_t material, const float* pose6, const float* scale3)
 { s->scene.add_mesh_instance(MeshInstance(mesh, material, LRE(pose6), F3(scale3))); return 0; }
@@ -118,6 +125,18 @@ RthCamera* rth_camera_create(int32_t width, int32_t height, const float* K9, con
 void rth_camera_free(RthCamera* c) { delete c; }
 void rth_camera_set_pose(RthCamera* c, const float* pose6) { c->cam.pose = LRE(pose6); }
 void rth_camera_set_stream(RthCamera* c, void* stream) { c->cam.stream = stream; }
+void rth_camera_set_options(RthCamera* c, int32_t spp, int32_t bounces, int32_t lighting)
+{ c->cam.spp = spp; c->cam.bounces = bounces; c->cam.lighting = lighting != 0; }
+int rth_camera_render_scene_ex(RthCamera* c, RthScene* s, void* d_img, size_t pitch, int32_t* d_total_pops, int synchronize)
+{ c->cam.render_scene_ex(s->scene, (uchar3*)d_img, pitch, d_total_pops, synchronize != 0); return c->cam.last_error; }
+uint32_t rth_xorwow(uint64_t seed, int32_t n, uint32_t* out_bits, float* out_uniform)
+{
+    rt::Xorwow a, b;
+    rt::xorwow_init(a, seed); b = a;
+    uint32_t last = 0;
+    for (int i = 0; i < n; i++) { last = rt::xorwow_next(a); if (out_bits) out_bits[i] = last; if (out_uniform) out_uniform[i] = rt::xorwow_uniform(b); }
+    return last;
+}
 int rth_camera_render_scene(RthCamera* c, RthScene* s, void* d_img, size_t pitch, int synchronize)
 { c->cam.render_scene(s->scene, (uchar3*)d_img, pitch, synchronize != 0); return c->cam.last_error; }
 int rth_camera_render_scene_stripes(RthCamera* c, RthScene* s, void* d_local, size_t local_pitch, int32_t stripe_rows, int32_t rank,

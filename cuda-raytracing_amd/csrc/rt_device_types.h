@@ -44,12 +44,13 @@ struct DevInstance {            // 128 B
     int32_t exact_uv;           // mesh has uv values that could make uv.x == FLT_MAX (raycast.cu:96)
 };
 
-struct DevMaterial {            // Material.hpp:6-16 (fields the path reads)
+struct DevMaterial {            // Material.hpp:6-16
     float albedo[3];
     int32_t texture_width;
     int32_t texture_height;
     uint32_t texture_pitch;
     const uint8_t* texture;
+    float roughness, metallic;  // read only by the extension kernel (dead in the reference)
 };
 
 constexpr int kMaxBatch = 8;    // frames per launch (rt_render_batch)
@@ -81,6 +82,9 @@ struct RenderParams {
     int32_t tiles_x, tiles_y;   // 16x16-pixel workgroup tiles over width x local_rows
     const int32_t* tile_list;   // optional explicit workgroup -> tile order
     unsigned long long* trace;  // diagnostics: per-wave {start, end, hw id, tile} stamps, or null
+    // extension kernel (rt_render_ex): samples per pixel, specular bounces, sun + shadow pass, optional pops plane
+    int32_t spp, bounces, lighting;
+    int32_t* total_pops;
     // parity planes (tight [height][width], frame coordinates), any may be null
     int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;
 };

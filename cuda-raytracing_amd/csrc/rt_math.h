@@ -107,6 +107,33 @@ RT_HD float atanf_fdlibm(float x)
     return hx < 0 ? -z : z;
 }
 
+// XORWOW generator seeded like cuRAND's curand_init(seed, 0, 0) (the reference initialises one per pixel,
+// raycast.cu:190-193, and never samples it; the extension modes do).  cuRAND is a third-party dependency that is
+// not part of the reference tree: restated from its published algorithm (Marsaglia xorwow + cuRAND's seed scramble).
+struct Xorwow { uint32_t v[5]; uint32_t d; };
+RT_HD void xorwow_init(Xorwow& st, unsigned long long seed)
+{
+    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    st.d = 6615241u + t1 + t0;
+    st.v[0] = 123456789u + t0;
+    st.v[1] = 362436069u ^ t0;
+    st.v[2] = 521288629u + t1;
+    st.v[3] = 88675123u ^ t1;
+    st.v[4] = 5783321u + t0;
+}
+RT_HD uint32_t xorwow_next(Xorwow& st)
+{
+    uint32_t t = st.v[0] ^ (st.v[0] >> 2);
+    st.v[0] = st.v[1]; st.v[1] = st.v[2]; st.v[2] = st.v[3]; st.v[3] = st.v[4];
+    st.v[4] = (st.v[4] ^ (st.v[4] << 4)) ^ (t ^ (t << 1));
+    st.d += 362437u;
+    return st.v[4] + st.d;
+}
+RT_HD float xorwow_uniform(Xorwow& st) { return (float)xorwow_next(st) * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }   // (0, 1]
+
 // ---- host-only pieces (libm sinf/cosf/atan2f/asinf: evaluated once per pose on the host,
 //      never per ray; the kernels receive the resulting quaternions) -----------------------
 inline Q4 euler2quat(V3 e)                                                          // transforms.hpp:148-163

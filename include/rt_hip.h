@@ -134,6 +134,22 @@ int rt_render_batch(RtScene *scene, const RtCameraParams *cams, uint8_t *const *
 int rt_render_debug(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch,
                     const RtDebugPlanes *planes, void *stream, int synchronize);
 
+/* ---- extension (no counterpart in the reference snapshot, whose shadow pass is commented out
+ *      at raycast.cu:262-287 and which has no spp / bounce loop).  Semantics: DESIGN.md "Extension".  With
+ *      spp = 1, bounces = 0, lighting = 0 the frame equals rt_render's bit for bit.  d_total_pops: optional tight
+ *      [height][width] int32 device plane receiving the node pops of all rays of each pixel. ------------------- */
+typedef struct RtRenderOptions {
+    int32_t spp;        /* >= 1; sample 0 is the reference's un-jittered ray, samples > 0 are jittered with XORWOW */
+    int32_t bounces;    /* specular bounces weighted by Material::metallic, perturbed by Material::roughness */
+    int32_t lighting;   /* 1 = sun + shadow ray of raycast.cu:249-287, 0 = illumination 1.0 (raycast.cu:282) */
+} RtRenderOptions;
+int rt_render_ex(RtScene *scene, const RtCameraParams *cam, const RtRenderOptions *opts, uint8_t *d_img, size_t pitch,
+                 int32_t *d_total_pops, void *stream, int synchronize);
+
+/* this rank's stripes of an extension frame (see rt_render_stripes below for the stripe layout) */
+int rt_render_ex_stripes(RtScene *scene, const RtCameraParams *cam, const RtRenderOptions *opts, uint8_t *d_local,
+                         size_t local_pitch, int32_t stripe_rows, int32_t rank, int32_t num_ranks, void *stream, int synchronize);
+
 /* ---- frame tiling across GPUs (no counterpart in the reference: it is single-GPU).  The frame
  *      is cut into stripes of `stripe_rows` rows; stripe s belongs to rank s % num_ranks.  A rank
  *      renders its stripes into a tight local buffer (rows packed in stripe order, pitch =

@@ -40,6 +40,8 @@ void rth_scene_free(RthScene *s);
 int32_t rth_scene_add_material(RthScene *s, const float *albedo3, const uint8_t *texture_bgr, int32_t w, int32_t h, size_t pitch);
 /* Material::upload_texture(path) (Material.hpp:29) then add_material; binary PPM only */
 int32_t rth_scene_add_material_ppm(RthScene *s, const float *albedo3, const char *ppm_path);
+/* Material::roughness / metallic / illumination of material `index` (set before upload_to_device) */
+int rth_scene_set_material_params(RthScene *s, int32_t index, float roughness, float metallic, float illumination);
 /* Scene::add_mesh (copies the mesh, as the by-value reference call does) */
 int32_t rth_scene_add_mesh(RthScene *s, const RthMesh *m);
 /* Scene::add_mesh_instance(MeshInstance(mesh, material, pose, scale)) */
@@ -56,6 +58,11 @@ RthCamera *rth_camera_create(int32_t width, int32_t height, const float *K9, con
 void rth_camera_free(RthCamera *c);
 void rth_camera_set_pose(RthCamera *c, const float *pose6);                        /* camera.pose = ... */
 void rth_camera_set_stream(RthCamera *c, void *stream);
+/* extension options (Camera::spp / bounces / lighting, see rt_render_ex); defaults 1, 0, 0 = the reference frame */
+void rth_camera_set_options(RthCamera *c, int32_t spp, int32_t bounces, int32_t lighting);
+int rth_camera_render_scene_ex(RthCamera *c, RthScene *s, void *d_img, size_t pitch, int32_t *d_total_pops, int synchronize);
+/* the XORWOW stream the extension kernel draws from (curand_init(seed,0,0) seeding), for known-answer tests */
+uint32_t rth_xorwow(uint64_t seed, int32_t n, uint32_t *out_bits, float *out_uniform);
 /* Camera::render_scene(scene, img_ptr, pitch, synchronize) (Camera.h:25) */
 int rth_camera_render_scene(RthCamera *c, RthScene *s, void *d_img, size_t pitch, int synchronize);
 int rth_camera_render_scene_stripes(RthCamera *c, RthScene *s, void *d_local, size_t local_pitch,

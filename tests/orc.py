@@ -130,6 +130,11 @@ class Oracle(_Lib):
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, _f, _f, _f, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_scene_set_material_params.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.orc_render_ex.restype = C.c_int
+        L.orc_render_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, _f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_xorwow.argtypes = [C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_camera_ray.argtypes = [C.c_int, C.c_int, _f, _f, _f, C.c_int, C.c_int, _f]
         L.orc_fnv1a64_image.restype = C.c_uint64
         L.orc_fnv1a64_image.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
@@ -157,13 +162,16 @@ class OracleScene:
         self.h = orc.lib.orc_scene_create()
         self._keep = []
 
-    def add_material(self, albedo, texture=None):
+    def add_material(self, albedo, texture=None, roughness=0.0, metallic=0.0, illumination=0.0):
         a = np.ascontiguousarray(albedo, np.float32)
         if texture is None:
-            return self.o.lib.orc_scene_add_material(self.h, _fp(a), None, 0, 0, 0)
-        t = np.ascontiguousarray(texture, np.uint8)
-        self._keep.append(t)
-        return self.o.lib.orc_scene_add_material(self.h, _fp(a), t.ctypes.data, t.shape[1], t.shape[0], t.strides[0])
+            idx = self.o.lib.orc_scene_add_material(self.h, _fp(a), None, 0, 0, 0)
+        else:
+            t = np.ascontiguousarray(texture, np.uint8)
+            self._keep.append(t)
+            idx = self.o.lib.orc_scene_add_material(self.h, _fp(a), t.ctypes.data, t.shape[1], t.shape[0], t.strides[0])
+        self.o.lib.orc_scene_set_material_params(self.h, idx, roughness, metallic, illumination)
+        return idx
 
     def add_mesh(self, mesh_handle):
         return self.o.lib.orc_scene_add_mesh(self.h, mesh_handle)
@@ -205,6 +213,27 @@ class OracleScene:
                                        inside=int(stats[4]), hits=int(stats[5]), max_stack=int(stats[6])))
         out.update(pl)
         return out
+
+    def render_ex(self, width, height, K, D, cam_pose, spp=1, bounces=0, lighting=0, threads=1):
+        """Extension semantics (oracle/rt_oracle.c orc_render_ex) -> dict(img, total_pops, stats)"""
+        img = np.zeros((height, width, 3), np.uint8)
+        pops = np.zeros((height, width), np.int32)
+        Kf, Df, Pf = (np.ascontiguousarray(v, np.float32) for v in (K, D, cam_pose))
+
+        def run(a, b):
+            st = np.zeros(4, np.int64)
+            rc = self.o.lib.orc_render_ex(self.h, width, height, _fp(Kf), _fp(Df), _fp(Pf), spp, bounces, lighting,
+                                          img.ctypes.data, width * 3, a, b, pops.ctypes.data, st.ctypes.data)
+            assert rc == 0
+            return st
+        if threads <= 1:
+            st = run(0, height)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            bands = [(a, min(a + 4, height)) for a in range(0, height, 4)]
+            with ThreadPoolExecutor(threads) as ex:
+                st = np.sum(list(ex.map(lambda ab: run(*ab), bands)), axis=0)
+        return dict(img=img, total_pops=pops, stats=dict(rays=int(st[0]), pops=int(st[1]), hits=int(st[2])))
 
     def close(self):
         if self.h:

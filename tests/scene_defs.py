@@ -26,7 +26,7 @@ def random_triangles(n, seed, spread=1.0, size=0.25, uv=True):
 
 
 class SceneDesc:
-    """materials: list of (albedo, texture or None); meshes: list of ('obj', path) | ('tris', array[n,18]) |
+    """materials: list of (albedo, texture or None[, dict(roughness=, metallic=, illumination=)]); meshes: list of ('obj', path) | ('tris', array[n,18]) |
     ('tri3', abc9); instances: list of (mesh, material, pose6, scale3)."""
 
     def __init__(self, materials, meshes, instances):
@@ -35,8 +35,10 @@ class SceneDesc:
     def build_oracle(self, orc):
         o = orc.oracle()
         s = orc.OracleScene(o)
-        for albedo, tex in self.materials:
-            s.add_material(albedo, tex)
+        for mat in self.materials:
+            albedo, tex = mat[0], mat[1]
+            extra = mat[2] if len(mat) > 2 else {}
+            s.add_material(albedo, tex, **extra)
         self.oracle_meshes = []
         for kind, arg in self.meshes:
             if kind == "obj":
@@ -54,8 +56,10 @@ class SceneDesc:
 
     def build_product(self, rt):
         s = rt.Scene()
-        for albedo, tex in self.materials:
-            s.add_material(albedo, texture_bgr=tex)
+        for mat in self.materials:
+            albedo, tex = mat[0], mat[1]
+            extra = mat[2] if len(mat) > 2 else {}
+            s.add_material(albedo, texture_bgr=tex, **extra)
         self.product_meshes = []
         for kind, arg in self.meshes:
             if kind == "obj":
@@ -116,3 +120,22 @@ def deep_stack_scene(n=28):
         tris[i] = o.tri_from_vertices(np.array([-h, y, -h, h, y, -h, 0.0, y, h], np.float32))
         tris[i, 12:18] = [0, 0, 0.5, 1, 1, 0]
     return SceneDesc([((0.2, 0.9, 0.4), None)], [("tris", tris)], [(0, 0, (0,) * 6, (1, 1, 1))])
+
+
+def shiny_scene(scenes, blob_path):
+    """Extension test scene: a half-mirror rough blob over a mirror-ish textured floor and a matte wall."""
+    import orc
+    o = orc.oracle()
+    floor = np.stack([o.tri_from_vertices(np.array(v, np.float32)) for v in
+                      ([-6, -6, -1.15, 6, -6, -1.15, 6, 8, -1.15], [-6, -6, -1.15, 6, 8, -1.15, -6, 8, -1.15])])
+    floor[:, 12:18] = [[0, 0, 1, 0, 1, 1], [0, 0, 1, 1, 0, 1]]
+    wall = np.stack([o.tri_from_vertices(np.array([-6, 3.5, -1.15, 6, 3.5, -1.15, 0, 3.5, 6], np.float32))])
+    return SceneDesc(
+        [((0.9, 0.5, 0.2), None, dict(roughness=0.08, metallic=0.5)),
+         ((1.0, 1.0, 1.0), checker_texture(32, 32, seed=3), dict(roughness=0.0, metallic=0.35)),
+         ((0.3, 0.8, 0.4), None, dict(roughness=0.4, metallic=0.0))],
+        [("obj", blob_path), ("tris", floor), ("tris", wall)],
+        [(0, 0, (0, 0, 0, 0.3, 0.0, 0.1), (0.9, 1.0, 1.1)), (1, 1, (0,) * 6, (1, 1, 1)), (2, 2, (0,) * 6, (1, 1, 1))])
+
+
+SHINY_CAMERA = dict(width=240, height=136, pose=(0.3, -3.2, 0.9, 0.05, -0.2, 0.0))

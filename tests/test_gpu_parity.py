@@ -256,3 +256,86 @@ def test_deep_traversal_stack_spills(rt, orc, scenes):
     img, ref = _compare(rt, orc, desc, W, H, scenes.scaled_K(W), scenes.D_REF, (0.0, -1.0, 0.0, 0, 0, 0))
     assert ref["stats"]["max_stack"] >= 24, ref["stats"]           # the scene really is deep (the reference stack holds 32)
     assert ref["stats"]["hits"] > 0
+
+
+# ---- extension: spp / bounces / sun+shadow; semantics defined by the oracle (parity unpinned) ------
+
+def _compare_ex(rt, orc, desc, W, H, K, pose, spp, bounces, lighting, threads=16):
+    so = desc.build_oracle(orc)
+    ref = so.render_ex(W, H, K, sd_D, pose, spp, bounces, lighting, threads=threads)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, sd_D)
+    cam.set_pose(pose)
+    cam.set_options(spp, bounces, lighting)
+    got = rt.render_ex(sp, cam)
+    nbad = int((got["img"] != ref["img"]).any(axis=2).sum())
+    assert nbad == 0, "%d pixels differ (spp %d bounces %d lighting %d)" % (nbad, spp, bounces, lighting)
+    assert np.array_equal(got["total_pops"], ref["total_pops"])
+    # Camera::render_scene with non-default options takes the same path
+    assert np.array_equal(rt.render(sp, cam), ref["img"])
+    so.close()
+    return got, ref
+
+
+sd_D = None
+
+
+@pytest.fixture(autouse=True)
+def _set_d(scenes):
+    global sd_D
+    sd_D = scenes.D_REF
+
+
+def test_ex_degenerates_to_reference_frame(rt, orc, scenes, blob5k):
+    """spp = 1, bounces = 0, lighting = 0 through rt_render_ex == rt_render == oracle reference frame."""
+    m = sd.SHINY_CAMERA
+    desc = sd.shiny_scene(scenes, blob5k)
+    K = scenes.scaled_K(m["width"])
+    got, _ = _compare_ex(rt, orc, desc, m["width"], m["height"], K, m["pose"], 1, 0, 0)
+    so = desc.build_oracle(orc)
+    ref = so.render(m["width"], m["height"], K, scenes.D_REF, m["pose"], threads=8)
+    assert np.array_equal(got["img"], ref["img"]) and np.array_equal(got["total_pops"], ref["pops"])
+
+
+@pytest.mark.parametrize("spp,bounces,lighting", [(1, 0, 1), (1, 3, 0), (4, 2, 1), (16, 8, 1)])
+def test_ex_modes_match_oracle(rt, orc, scenes, blob5k, spp, bounces, lighting):
+    m = sd.SHINY_CAMERA
+    _compare_ex(rt, orc, sd.shiny_scene(scenes, blob5k), m["width"], m["height"], scenes.scaled_K(m["width"]), m["pose"],
+                spp, bounces, lighting)
+
+
+def test_c3_bunny_64spp_8bounces(rt, orc, scenes, blob70k):
+    """BASELINE.json configs[2] shape: the 70k blob, 64 spp, 8 bounces, sun + shadow -- at 480x270 so that the oracle
+    finishes in seconds (the semantics are the extension's, parity unpinned)."""
+    W, H = 480, 270
+    desc = sd.SceneDesc([((0.9, 0.5, 0.2), None, dict(roughness=0.05, metallic=0.4))], [("obj", blob70k)], [(0, 0, (0,) * 6, (1, 1, 1))])
+    got, ref = _compare_ex(rt, orc, desc, W, H, scenes.scaled_K(W), scenes.C2_CAMERAS["mid"], 64, 8, 1, threads=32)
+    assert ref["stats"]["rays"] > 64 * W * H
+
+
+def test_c5_shape_tiled_64spp(rt, orc, scenes, blob5k):
+    """BASELINE.json configs[4] shape (64 spp, frame tiled over 8 ranks, gathered and un-striped) at 320x180: the
+    stitched extension frame equals the single-device extension frame and the oracle."""
+    import ctypes as C
+    import importlib
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    W, H, world, stripe = 320, 180, 8, 16
+    desc = sd.SceneDesc([((0.9, 0.5, 0.2), None, dict(roughness=0.1, metallic=0.5))], [("obj", blob5k)], [(0, 0, (0,) * 6, (1, 1, 1))])
+    K, pose = scenes.scaled_K(W), scenes.C2_CAMERAS["mid"]
+    got, ref = _compare_ex(rt, orc, desc, W, H, K, pose, 64, 2, 1)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose(pose)
+    cam.set_options(64, 2, 1)
+    pitch = W * 3
+    max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+    gathered = rt.DeviceBuffer(nbytes=world * max_rows * pitch)
+    for r in range(world):
+        cam.render_scene_stripes(sp, gathered.ptr.value + r * max_rows * pitch, pitch, stripe, r, world, synchronize=True)
+    out = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    rt.check(h.rt_unstripe(gathered.ptr, pitch, max_rows * pitch, out.ptr, out.pitch, W, H, stripe, world, None))
+    rt.check(h.rt_device_synchronize())
+    assert np.array_equal(out.to_host().reshape(H, W, 3), ref["img"])

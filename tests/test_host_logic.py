@@ -124,6 +124,29 @@ def test_plane_epsilon_float_threshold():
     assert "0x358637be" in src
 
 
+def test_xorwow_matches_oracle(rt, oracle):
+    """The extension's generator: product (rt_math.h) == oracle, and the seeding constants of curand_init(seed, 0, 0)."""
+    _, s = rt.libs()
+    for seed in (0, 1, 1000, 123456789, (1 << 63) + 12345, 0xFFFFFFFFFFFFF830):       # incl. a sign-extended negative seed
+        a_bits, a_u = np.zeros(64, np.uint32), np.zeros(64, np.float32)
+        b_bits, b_u = np.zeros(64, np.uint32), np.zeros(64, np.float32)
+        s.rth_xorwow(seed, 64, a_bits.ctypes.data, a_u.ctypes.data)
+        oracle.lib.orc_xorwow(seed, 64, b_bits.ctypes.data, b_u.ctypes.data)
+        assert np.array_equal(a_bits, b_bits) and same(a_u, b_u)
+        assert (a_u > 0).all() and (a_u <= 1).all()
+    # seed 0: state = the five Marsaglia constants mixed with t0 = 1099087573 * 0xaad26b49, t1 = 2591861531 * 0xf7dcefdd
+    t0 = (1099087573 * 0xaad26b49) & 0xFFFFFFFF
+    t1 = (2591861531 * 0xf7dcefdd) & 0xFFFFFFFF
+    v = [(123456789 + t0) & 0xFFFFFFFF, 362436069 ^ t0, (521288629 + t1) & 0xFFFFFFFF, 88675123 ^ t1, (5783321 + t0) & 0xFFFFFFFF]
+    d = (6615241 + t1 + t0) & 0xFFFFFFFF
+    t = v[0] ^ (v[0] >> 2)
+    v4 = ((v[4] ^ ((v[4] << 4) & 0xFFFFFFFF)) ^ (t ^ ((t << 1) & 0xFFFFFFFF))) & 0xFFFFFFFF
+    first = (v4 + d + 362437) & 0xFFFFFFFF
+    got = np.zeros(1, np.uint32)
+    s.rth_xorwow(0, 1, got.ctypes.data, None)
+    assert int(got[0]) == first
+
+
 def test_host_bvh_and_obj_vs_oracle(rt, oracle, blob5k):
     _mesh_equal(rt.Mesh.load_obj(blob5k).dump(), oracle.mesh_dump(oracle.obj_load(blob5k)))
     p = os.path.join(GOLDEN, "small_mixed.obj")

@@ -138,6 +138,26 @@ def test_c1_frame_pin(orc, scenes, pins):
     s.close()
 
 
+def test_extension_degenerates_to_pinned_frames(orc, scenes, blob5k, pins):
+    """orc_render_ex(spp=1, bounces=0, lighting=0) must be the reference frame: C1 by its SURVEY hash, a blob scene by
+    equality with orc_render (RGB and node pops).  This is the only pin the extension semantics have."""
+    import scene_defs as sd
+    c = scenes.C1
+    s = sd.c1_scene(scenes).build_oracle(orc)
+    ex = s.render_ex(c["width"], c["height"], c["K"], c["D"], c["cam_pose"], 1, 0, 0)
+    assert orc.fnv1a64(ex["img"]) == pins["frames"]["C1_256x256"]["fnv1a64"]
+    s.close()
+    m = sd.SHINY_CAMERA
+    s2 = sd.shiny_scene(scenes, blob5k).build_oracle(orc)
+    K = scenes.scaled_K(m["width"])
+    a = s2.render(m["width"], m["height"], K, scenes.D_REF, m["pose"], threads=4)
+    b = s2.render_ex(m["width"], m["height"], K, scenes.D_REF, m["pose"], 1, 0, 0, threads=4)
+    assert np.array_equal(a["img"], b["img"]) and np.array_equal(a["pops"], b["total_pops"])
+    lit = s2.render_ex(m["width"], m["height"], K, scenes.D_REF, m["pose"], 4, 2, 1, threads=4)
+    assert lit["stats"]["rays"] > 4 * m["width"] * m["height"] and not np.array_equal(lit["img"], a["img"])
+    s2.close()
+
+
 @pytest.mark.parametrize("cam", ["far", "mid", "near"])
 def test_c2_frame_pins(orc, scenes, blob70k, pins, cam):
     """BASELINE.json configs[1] at full size: oracle frame hash == the hash SURVEY.md 8(d) recorded
