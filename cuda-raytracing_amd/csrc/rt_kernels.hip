@@ -87,8 +87,9 @@ struct Counters<false> {};
 // deep but rays seldom hold more than a dozen postponed nodes -- spill to a private (scratch) array.  Keeping the
 // LDS part at 16 entries lets 8 waves/SIMD stay resident (16 KB per 256-thread workgroup).
 constexpr int kLdsStack = 16;
+typedef __attribute__((address_space(3))) int lds_int;      // typed LDS pointer: keeps stack traffic on ds_read/ds_write
 struct Stack {
-    int* lds;                   // this lane's LDS column
+    lds_int* lds;               // this lane's LDS column
     int* spill;                 // this lane's private overflow, kMaxStack - kLdsStack entries
     int lds_depth;              // entries kept in LDS (<= kLdsStack)
     int sp;
@@ -100,7 +101,11 @@ struct Stack {
     __device__ __forceinline__ int32_t pop()
     {
         --sp;
-        return sp < lds_depth ? lds[sp * kBlock] : spill[sp - lds_depth];
+        // always an LDS read (index clamped) and, rarely, a private read on top: a select between the two
+        // address spaces would turn into one slow flat_load
+        int32_t v = lds[(sp < lds_depth ? sp : lds_depth - 1) * kBlock];
+        if (sp >= lds_depth) v = spill[sp - lds_depth];
+        return v;
     }
 };
 
@@ -131,10 +136,11 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ro, r.dinv);
     int32_t ra = __float_as_int(q3.x), rb = __float_as_int(q3.y);
     if constexpr (DEBUG) cnt.aabb += 2;
-    bool pa = da < hit_min, pb = db < hit_min;
-    int32_t first, second; bool pf, ps;                         // push order of raycast.cu:72-79
-    if (da < db) { first = rb; pf = pb; second = ra; ps = pa; }
-    else         { first = ra; pf = pa; second = rb; ps = pb; }
+    // push order of raycast.cu:72-79: `first` is pushed first, `second` last (= popped next)
+    const bool a_near = da < db;
+    const int32_t first = a_near ? rb : ra, second = a_near ? ra : rb;
+    const float d_first = a_near ? db : da, d_second = a_near ? da : db;
+    const bool pf = d_first < hit_min, ps = d_second < hit_min;
     if (ps) {
         if (pf) stack.push(first);
         cur = second;
@@ -161,44 +167,53 @@ __device__ __forceinline__ void leaf_step(const RenderParams& p, const DevInstan
         if (i > 0) { t0 = t[0]; t1 = t[1]; t2 = t[2]; t3 = t[3]; }
         if constexpr (DEBUG) cnt.tris++;
         V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
+        // The reference's chain of early returns (TrianglePrimitive.hpp:66,72, raycast.cu:91,96) is evaluated as
+        // one predicate over straight-line code: a wave almost always has some lane that passes each test, so
+        // branching per test only adds exec-mask bookkeeping.  Lanes whose predicate is already false compute
+        // on garbage that is never used.
         // TrianglePrimitive::ray_intersect, TrianglePrimitive.hpp:62-79
         float denom = dot(r.rd, nrm);
         // `abs(denom) < 1e-6` compares in double; 0x358637be is the smallest float whose double value is >= 1e-6,
         // so this float compare selects exactly the same floats (tests/test_host_logic.py checks the boundary).
-        if (fabsf(denom) < __int_as_float(0x358637be)) continue;
+        bool ok = !(fabsf(denom) < __int_as_float(0x358637be));
         // A candidate is only ever accepted when same_dir = denom < 0 (raycast.cu:107-109); for denom >= 0 (or NaN)
-        // the rest of the test has no observable effect, so the production kernel stops here.  The debug kernel
+        // the rest of the test has no observable effect, so the production kernel drops it here.  The debug kernel
         // goes on because the inside-hit count of raycast.cu:96 is one of the parity planes.
-        if (!DEBUG && !(denom < 0.0f)) continue;
+        if constexpr (!DEBUG) ok = ok && (denom < 0.0f);
         float tt = dot(v0 - r.ro, nrm) / denom;
-        if (tt < 0.0f) continue;
+        ok = ok && !(tt < 0.0f);
         V3 pt = r.ro + tt * r.rd;
-        if (pt.x == FLT_MAX) continue;                          // raycast.cu:91
+        ok = ok && !(pt.x == FLT_MAX);                          // raycast.cu:91
         // TrianglePrimitive::point_inside, TrianglePrimitive.hpp:151-185
         V3 e0 = v3(t1.z, t1.w, t2.x), e1 = v3(t2.y, t2.z, t2.w);
         V3 e2 = pt - v0;
         float dot02 = dot(e0, e2), dot12 = dot(e1, e2);
         float u = (t3.z * dot02 - t3.y * dot12) * t3.w;
         float v = (t3.x * dot12 - t3.y * dot02) * t3.w;
-        if (!((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f))) continue;
+        ok = ok && (u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f);
         float2 uv = make_float2(0.0f, 0.0f);
-        if (exact_uv) {                                         // raycast.cu:96 can only fail for absurd uv data
+        if (exact_uv && ok) {                                   // raycast.cu:96 can only fail for absurd uv data
             const float* q = p.tri_uv + (size_t)slot * 6;
             float w = 1.0f - u - v;
             uv.x = (w * q[0] + v * q[2]) + u * q[4];
             uv.y = (w * q[1] + v * q[3]) + u * q[5];
-            if (!(uv.x != FLT_MAX)) continue;
+            ok = uv.x != FLT_MAX;
         }
-        if constexpr (DEBUG) cnt.inside++;
-        // raycast.cu:98-104
-        V3 loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
-        loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
-        float distance = magnitude(loc - org);
-        // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
-        if (denom < 0 && (hit.min == FLT_MAX || distance < hit.min)) {
-            hit.min = distance;
-            hit.slot = slot; hit.instance = inst_index; hit.u = u; hit.v = v; hit.uv = uv;
-            if constexpr (EX) hit.loc = loc;
+        if (ok) {
+            if constexpr (DEBUG) cnt.inside++;
+            // raycast.cu:98-104
+            V3 loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
+            loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
+            float distance = magnitude(loc - org);
+            // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
+            const bool accept = denom < 0 && (hit.min == FLT_MAX || distance < hit.min);
+            hit.min = accept ? distance : hit.min;
+            hit.slot = accept ? slot : hit.slot;
+            hit.instance = accept ? inst_index : hit.instance;
+            hit.u = accept ? u : hit.u;
+            hit.v = accept ? v : hit.v;
+            if (exact_uv) { hit.uv.x = accept ? uv.x : hit.uv.x; hit.uv.y = accept ? uv.y : hit.uv.y; }
+            if constexpr (EX) { hit.loc.x = accept ? loc.x : hit.loc.x; hit.loc.y = accept ? loc.y : hit.loc.y; hit.loc.z = accept ? loc.z : hit.loc.z; }
         }
     }
 }
@@ -226,9 +241,25 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         }
         if constexpr (DEBUG) cnt.pops++;
         const bool interior = cur >= 0;
-        const float4* rec = interior ? p.inodes + (size_t)cur * 4 : p.tris + (size_t)(cur & kSlotMask) * 4;
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t1 = __builtin_amdgcn_s_memtime(); }
-        float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        // About half of all wave iterations (three quarters for close-up views) find every active lane holding
+        // the SAME entry -- coherent rays walk the top of the tree in lockstep.  Those iterations fetch the record
+        // once per wave through the scalar cache (s_load_dwordx16) instead of 64 x 64 B through the vector memory
+        // path, which is otherwise the busiest unit of the kernel (-9..-13 % frame time).
+        float4 r0, r1, r2, r3;
+        const int32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
+        if (!PROF && __ballot(cur != cur0) == 0ull) {
+            const float4* g = cur0 >= 0 ? p.inodes + (size_t)cur0 * 4 : p.tris + (size_t)(cur0 & kSlotMask) * 4;
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            f16v w;
+            // inline asm: hipcc would otherwise merge this load with the per-lane one below into a single vector load
+            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(g) : "memory");
+            r0 = make_float4(w[0], w[1], w[2], w[3]);   r1 = make_float4(w[4], w[5], w[6], w[7]);
+            r2 = make_float4(w[8], w[9], w[10], w[11]); r3 = make_float4(w[12], w[13], w[14], w[15]);
+        } else {
+            const float4* rec = interior ? p.inodes + (size_t)cur * 4 : p.tris + (size_t)(cur & kSlotMask) * 4;
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+        }
         if constexpr (PROF) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             t2 = __builtin_amdgcn_s_memtime();
@@ -284,24 +315,21 @@ __device__ __forceinline__ V3 base_colour(const RenderParams& p, const Hit& hit)
     return v3(1.0f * m.albedo[0], 1.0f * m.albedo[1], 1.0f * m.albedo[2]);     // raycast.cu:241-245
 }
 
-// raycast.cu:207-294
-__device__ __forceinline__ void shade(const RenderParams& p, const Hit& hit, uint8_t* px)
+// raycast.cu:207-294 -> the pixel's three bytes packed as x | y << 8 | z << 16
+__device__ __forceinline__ uint32_t shade(const RenderParams& p, const Hit& hit)
 {
-    if (hit.min == FLT_MAX) {                                   // sky, raycast.cu:208-216
-        px[0] = 255; px[1] = 204; px[2] = 153;
-        return;
-    }
+    if (hit.min == FLT_MAX) return 255u | (204u << 8) | (153u << 16);      // sky, raycast.cu:208-216
     const V3 c = base_colour(p, hit);
     const float illumination = 1.0f;                            // raycast.cu:282-290
-    px[0] = to_u8(illumination * c.x * 255.0f);                 // raycast.cu:292-294
-    px[1] = to_u8(illumination * c.y * 255.0f);
-    px[2] = to_u8(illumination * c.z * 255.0f);
+    return (uint32_t)to_u8(illumination * c.x * 255.0f) |       // raycast.cu:292-294
+           ((uint32_t)to_u8(illumination * c.y * 255.0f) << 8) |
+           ((uint32_t)to_u8(illumination * c.z * 255.0f) << 16);
 }
 
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
 // (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
 template <bool DEBUG, bool PROF>
-__device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x, int ly, int y, int* lds_column)
+__device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x, int ly, int y, lds_int* lds_column)
 {
     const V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     const V3 dir = camera_direction(f, (float)x, (float)y);
@@ -315,10 +343,9 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
         trace_instance<DEBUG, PROF>(p, p.instances[i], i, org, dir, stack, hit, cnt);
 
-    uint8_t px[3];
-    shade(p, hit, px);
+    const uint32_t px = shade(p, hit);
     uint8_t* out = f.img + (size_t)ly * p.pitch + 3 * (size_t)x;
-    out[0] = px[0]; out[1] = px[1]; out[2] = px[2];
+    out[0] = (uint8_t)px; out[1] = (uint8_t)(px >> 8); out[2] = (uint8_t)(px >> 16);
 
     if constexpr (DEBUG) {
         size_t o = (size_t)y * p.width + x;
@@ -332,7 +359,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
 }
 
 template <bool DEBUG, bool PROF>
-__global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
+__global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];                          // [min(stack_depth, kLdsStack)][kBlock]
 
@@ -351,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams p)
     if (x < p.width && ly < p.local_rows) {
         // stripes: local row -> frame row (identity when num_ranks == 1)
         const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
-        render_pixel<DEBUG, PROF>(p, p.frames[blockIdx.y], x, ly, y, lds_stack + tid);   // blockIdx.y = frame of the batch
+        render_pixel<DEBUG, PROF>(p, p.frames[blockIdx.y], x, ly, y, (lds_int*)lds_stack + tid);   // blockIdx.y = frame of the batch
     }
     if (p.trace && lane == 0) {                                 // diagnostic: per-wave lifetime (RT_TRACE_FILE)
         unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave) * 16;
@@ -403,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void render_ex_kernel(const RenderParams p)
 
     int spill[kMaxStack - kLdsStack];
     Stack stack;
-    stack.lds = lds_stack + tid; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
+    stack.lds = (lds_int*)lds_stack + tid; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
     Counters<true> cnt;
 
     Xorwow rng;

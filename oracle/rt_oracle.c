@@ -642,7 +642,9 @@ typedef struct {                                    /* raycast.cu:10-18 + bookke
  * k >= 1 = leaf with k-1 triangle tests (capped at 254) */
 static __thread uint8_t *g_rec = NULL;
 static __thread int g_rec_n = 0, g_rec_cap = 0;
+static __thread int32_t *g_rec_nodes = NULL;
 static void rec_step(int v) { if (g_rec && g_rec_n < g_rec_cap) g_rec[g_rec_n] = (uint8_t)(v > 255 ? 255 : v); if (g_rec) g_rec_n++; }
+static void rec_node(int node) { if (g_rec_nodes && g_rec_n < g_rec_cap) g_rec_nodes[g_rec_n] = node; }
 
 /* raycast.cu:21-142 */
 static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
@@ -670,6 +672,7 @@ static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
             const node_t *cur;
             if (stack_index > hit.max_stack) hit.max_stack = stack_index;
             node_index = stack[--stack_index];                           /* :61 */
+            rec_node(node_index);
             cur = &mesh->nodes[node_index];
             hit.pops++;
             if (cur->child_a > 0) {                                      /* :66 */
@@ -833,6 +836,7 @@ int orc_render(const OrcScene *sc, int width, int height, const float *K9, const
 }
 
 /* step sequence of the ray of pixel (x, y): returns the number of node pops, writes min(n, cap) bytes */
+void orc_trace_set_node_buffer(int32_t *nodes) { g_rec_nodes = nodes; }
 int orc_trace_steps(const OrcScene *sc, int width, int height, const float *K9, const float *D4, const float *cam_pose6,
                     int x, int y, uint8_t *out, int cap)
 {
