@@ -37,6 +37,27 @@ class RtDebugPlanes(C.Structure):
     _fields_ = [(n, _vp) for n in ("hit_instance", "hit_triangle", "node_pops", "aabb_tests", "tri_tests", "inside_hits")]
 
 
+class RtMeshDesc(C.Structure):              # include/rt_hip.h
+    _fields_ = [("num_triangles", C.c_int32), ("vertices", _f), ("normals", _f), ("uvs", _f), ("num_nodes", C.c_int32),
+                ("node_bounds", _f), ("node_children", _i), ("node_leaf_first", _i), ("node_leaf_count", _i),
+                ("num_leaf_indices", C.c_int32), ("leaf_indices", _i)]
+
+
+class RtMaterialDesc(C.Structure):
+    _fields_ = [("roughness", C.c_float), ("albedo", C.c_float * 3), ("metallic", C.c_float), ("illumination", C.c_float),
+                ("texture", _vp), ("texture_width", C.c_int32), ("texture_height", C.c_int32), ("texture_pitch", C.c_size_t)]
+
+
+class RtInstanceDesc(C.Structure):
+    _fields_ = [("mesh_index", C.c_int32), ("material_index", C.c_int32), ("pose", C.c_float * 6), ("inv_pose", C.c_float * 6),
+                ("rotation", C.c_float * 3), ("inv_rotation", C.c_float * 3), ("scale", C.c_float * 3), ("inv_scale", C.c_float * 3)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [("num_meshes", C.c_int32), ("meshes", C.POINTER(RtMeshDesc)), ("num_materials", C.c_int32),
+                ("materials", C.POINTER(RtMaterialDesc)), ("num_instances", C.c_int32), ("instances", C.POINTER(RtInstanceDesc))]
+
+
 # every exported symbol of include/rt_hip.h and include/rt_host.h (tests check the libraries export them all)
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
@@ -45,14 +66,14 @@ RT_HIP_SYMBOLS = [
     "rt_render_debug", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
-    "rth_obj_load", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
+    "rth_obj_load", "rth_obj_load_lenient", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
     "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
     "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
     "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance",
     "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
     "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
-    "rth_camera_render_scene_ex", "rth_xorwow",
+    "rth_camera_render_scene_ex", "rth_xorwow", "rth_save_png", "rth_write_png_bgr",
     "rth_camera_params", "rth_q_rsqrt", "rth_atanf", "rth_normalize", "rth_invert_lre", "rth_apply_lre", "rth_euler2quat",
     "rth_apply_quat", "rth_invert_intrinsic", "rth_last_error"]
 
@@ -89,6 +110,7 @@ def _declare(h, s):
     h.rt_memcpy_h2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
     h.rt_memcpy2d_d2h.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]
     h.rt_stream_synchronize.argtypes = [_vp]
+    h.rt_scene_upload.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(_vp)]
     h.rt_scene_info.argtypes = [_vp, C.POINTER(C.c_size_t), _i]
     h.rt_scene_update_instance.argtypes = [_vp, C.c_int32, _vp]
     h.rt_scene_destroy.argtypes = [_vp]
@@ -104,10 +126,11 @@ def _declare(h, s):
     h.rt_timer_destroy.argtypes = [_vp]
 
     s.rth_last_error.restype = C.c_char_p
-    for n in ("rth_obj_load", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
+    for n in ("rth_obj_load", "rth_obj_load_lenient", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
               "rth_scene_device_handle"):
         getattr(s, n).restype = _vp
     s.rth_obj_load.argtypes = [C.c_char_p]
+    s.rth_obj_load_lenient.argtypes = [C.c_char_p]
     s.rth_mesh_from_triangles.argtypes = [_f, C.c_int32]
     s.rth_mesh_single_triangle.argtypes = [_f]
     for n in ("rth_mesh_free", "rth_mesh_num_triangles", "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_print_stats",
@@ -138,6 +161,8 @@ def _declare(h, s):
     s.rth_scene_set_material_params.argtypes = [_vp, C.c_int32, C.c_float, C.c_float, C.c_float]
     s.rth_camera_set_options.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32]
     s.rth_camera_render_scene_ex.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int]
+    s.rth_save_png.argtypes = [C.c_char_p, _vp, C.c_int32, C.c_int32, C.c_size_t]
+    s.rth_write_png_bgr.argtypes = [C.c_char_p, _vp, C.c_int32, C.c_int32, C.c_size_t]
     s.rth_xorwow.restype = C.c_uint32
     s.rth_xorwow.argtypes = [C.c_uint64, C.c_int32, _vp, _vp]
     s.rth_q_rsqrt.restype = C.c_float
@@ -183,8 +208,9 @@ class Mesh:
         self.h = handle
 
     @classmethod
-    def load_obj(cls, path):                          # OBJLoader::load
-        return cls(libs()[1].rth_obj_load(os.fsencode(path)))
+    def load_obj(cls, path, lenient=False):           # OBJLoader::load / load_lenient
+        fn = libs()[1].rth_obj_load_lenient if lenient else libs()[1].rth_obj_load
+        return cls(fn(os.fsencode(path)))
 
     @classmethod
     def from_triangles(cls, tris18):                  # MeshPrimitive(std::vector<TrianglePrimitive>)
@@ -421,6 +447,12 @@ def render_ex(scene, camera):
     img.free()
     pops.free()
     return out
+
+
+def write_png(path, img_bgr):
+    """[h, w, 3] uint8 B,G,R image -> RGB PNG (host side of display_image's out.png)."""
+    a = np.ascontiguousarray(img_bgr, np.uint8)
+    check(libs()[1].rth_write_png_bgr(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], a.strides[0]), "write_png")
 
 
 class Timer:

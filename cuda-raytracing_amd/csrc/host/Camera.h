@@ -7,6 +7,13 @@
 
 using namespace transforms;
 
+// Replacement for display_image()'s `cv::imwrite("out.png", ...)` (kernel.cu:30-43) without OpenCV: copies a pitched BGR
+// device image to the host and writes it as an 8-bit RGB PNG (stored, i.e. uncompressed, deflate blocks).
+// Returns 0 or an rt_hip.h error code (RT_E_INVALID if the file cannot be written).
+int save_png(const char* path, const uchar3* d_img, int width, int height, size_t pitch, void* stream = nullptr);
+// same from host memory
+int write_png_bgr(const char* path, const unsigned char* bgr, int width, int height, size_t pitch);
+
 class Camera {
 public:
     Camera(int width, int height, float3x3 K, float4 D);

@@ -10,7 +10,12 @@
 namespace OBJLoader {
 // Triangles of the file; returns false (and fills *error) when the file cannot be opened or a
 // face is malformed / out of range.
-bool parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error);
+// lenient = false reproduces the reference (a `v//vn` token or a negative index is an error, H11);
+// lenient = true additionally accepts `v//vn` (no texture index) and negative (relative) indices as the OBJ
+// format defines them: -1 is the most recent `v` / `vt` record before the face line.
+bool parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error, bool lenient = false);
+// parse(lenient = true) + MeshPrimitive; throws std::runtime_error on failure
+MeshPrimitive load_lenient(std::string fp);
 // Reference behaviour: prints the progress lines, and on an unreadable file prints
 // "Could not open file" and exit(1)s (OBJLoader.hpp:23-27); malformed faces throw std::runtime_error
 // (the reference throws std::invalid_argument from stoi).

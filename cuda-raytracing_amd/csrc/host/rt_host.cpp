@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -379,6 +380,78 @@ void Camera::render_scene_stripes_batch(Scene& scene, const lre* poses, int coun
                                          num_ranks, stream, synchronize ? 1 : 0);
 }
 
+// ------------------------------------------------------------------------------- PNG out
+
+namespace {
+uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n)
+{
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<unsigned char>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+void png_chunk(std::vector<unsigned char>& out, const char* type, const std::vector<unsigned char>& data)
+{
+    put_be32(out, (uint32_t)data.size());
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put_be32(out, crc32_update(0xFFFFFFFFu, &out[start], out.size() - start) ^ 0xFFFFFFFFu);
+}
+}  // namespace
+
+int write_png_bgr(const char* path, const unsigned char* bgr, int width, int height, size_t pitch)
+{
+    if (!path || !bgr || width <= 0 || height <= 0 || pitch < (size_t)width * 3) return RT_E_INVALID;
+    // raw scanlines: filter byte 0 + RGB
+    std::vector<unsigned char> raw((size_t)height * (1 + (size_t)width * 3));
+    for (int y = 0; y < height; y++) {
+        unsigned char* d = &raw[(size_t)y * (1 + (size_t)width * 3)];
+        const unsigned char* s = bgr + (size_t)y * pitch;
+        *d++ = 0;
+        for (int x = 0; x < width; x++) { d[3 * x] = s[3 * x + 2]; d[3 * x + 1] = s[3 * x + 1]; d[3 * x + 2] = s[3 * x]; }   // B,G,R -> R,G,B (H12)
+    }
+    // zlib stream of stored blocks
+    std::vector<unsigned char> z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size();) {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = 0; i < n; i++) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+        pos += n;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, (uint32_t)width); put_be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    png_chunk(out, "IHDR", ihdr);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", std::vector<unsigned char>());
+    FILE* f = fopen(path, "wb");
+    if (!f) return RT_E_INVALID;
+    size_t w = fwrite(out.data(), 1, out.size(), f);
+    fclose(f);
+    return w == out.size() ? RT_OK : RT_E_INVALID;
+}
+
+int save_png(const char* path, const uchar3* d_img, int width, int height, size_t pitch, void* stream)
+{
+    if (!d_img || width <= 0 || height <= 0) return RT_E_INVALID;
+    std::vector<unsigned char> host((size_t)width * 3 * (size_t)height);
+    int rc = rt_memcpy2d_d2h(host.data(), (size_t)width * 3, d_img, pitch, (size_t)width * 3, (size_t)height, stream);
+    if (rc) return rc;
+    return write_png_bgr(path, host.data(), width, height, (size_t)width * 3);
+}
+
 // ----------------------------------------------------------------------------- OBJLoader
 
 namespace {
@@ -393,7 +466,7 @@ bool lead_int(const char* s, int& out)
 }
 }  // namespace
 
-bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error)
+bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error, bool lenient)
 {
     auto fail = [&](const std::string& msg) { if (error) *error = msg; return false; };
     FILE* f = fopen(fp.c_str(), "rb");
@@ -413,6 +486,7 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
     size_t pos = 0;
     const size_t N = data.size();
     std::vector<std::pair<size_t, size_t>> faces;      // [begin, end) of each "f" line
+    std::vector<std::pair<int, int>> counts_at_face;   // #v, #vt records seen before that line (relative indices)
     while (pos < N) {
         size_t eol = data.find('\n', pos);
         if (eol == std::string::npos) eol = N;
@@ -434,12 +508,15 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
             tex_coords.push_back(make_float2(x, y));
         } else if (len == 1 && data[a] == 'f') {
             faces.push_back(std::make_pair(b, eol));
+            counts_at_face.push_back(std::make_pair((int)vertices.size(), (int)tex_coords.size()));
         }
         pos = eol + 1;
     }
     // pass 2: faces -> fan triangles (OBJLoader.hpp:90-171)
     std::vector<int> vi, ti;
-    for (const auto& fl : faces) {
+    for (size_t fi = 0; fi < faces.size(); fi++) {
+        const auto& fl = faces[fi];
+        const int nv_here = counts_at_face[fi].first, nt_here = counts_at_face[fi].second;
         vi.clear(); ti.clear();
         size_t p = fl.first;
         while (p < fl.second) {
@@ -454,12 +531,15 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
             {
                 std::string head(&data[p], s1 - p);
                 if (!lead_int(head.c_str(), v)) return fail("malformed face token");
-                vi.push_back(v - 1);
+                vi.push_back(lenient && v < 0 ? nv_here + v : v - 1);
             }
             if (s1 < q) {
                 std::string rest(&data[s1 + 1], q - s1 - 1);
-                if (!lead_int(rest.c_str(), v)) return fail("malformed face token (v//vn is not supported)");
-                ti.push_back(v - 1);
+                const bool no_tex = lenient && !rest.empty() && rest[0] == '/';         // v//vn
+                if (!no_tex) {
+                    if (!lead_int(rest.c_str(), v)) return fail("malformed face token (v//vn is not supported)");
+                    ti.push_back(lenient && v < 0 ? nt_here + v : v - 1);
+                }
                 size_t s2 = rest.find('/');
                 if (s2 != std::string::npos && !lead_int(rest.c_str() + s2 + 1, v)) return fail("malformed face token");
             }
@@ -483,6 +563,14 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
         }
     }
     return true;
+}
+
+MeshPrimitive OBJLoader::load_lenient(std::string fp)
+{
+    std::vector<TrianglePrimitive> triangles;
+    std::string err;
+    if (!parse(fp, triangles, &err, true)) throw std::runtime_error("OBJLoader: " + err);
+    return MeshPrimitive(std::move(triangles));
 }
 
 MeshPrimitive OBJLoader::load(std::string fp)

@@ -30,6 +30,15 @@ RthMesh* rth_obj_load(const char* path)
         return new RthMesh(MeshPrimitive(std::move(tris)));
     } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
+RthMesh* rth_obj_load_lenient(const char* path)
+{
+    try {
+        std::vector<TrianglePrimitive> tris;
+        std::string err;
+        if (!path || !OBJLoader::parse(path, tris, &err, true)) { g_err = path ? err : "null path"; return nullptr; }
+        return new RthMesh(MeshPrimitive(std::move(tris)));
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
 RthMesh* rth_mesh_from_triangles(const float* tris18, int32_t n)
 {
     try {
@@ -173,6 +182,10 @@ void rth_camera_params(const RthCamera* c, void* out)
     memcpy(out, &p, sizeof p);
 }
 
+int rth_save_png(const char* path, const void* d_img, int32_t width, int32_t height, size_t pitch)
+{ return save_png(path, (const uchar3*)d_img, width, height, pitch, nullptr); }
+int rth_write_png_bgr(const char* path, const uint8_t* bgr, int32_t width, int32_t height, size_t pitch)
+{ return write_png_bgr(path, bgr, width, height, pitch); }
 float rth_q_rsqrt(float x) { return Q_rsqrt(x); }
 float rth_atanf(float x) { return rt::atanf_fdlibm(x); }
 void rth_normalize(const float* v, float* o) { float3 r = normalize(F3(v)); o[0] = r.x; o[1] = r.y; o[2] = r.z; }

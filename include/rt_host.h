@@ -19,6 +19,8 @@ typedef struct RthCamera RthCamera;   /* Camera */
 
 /* OBJLoader::load(fp) (OBJLoader.hpp:15); NULL on failure, message via rth_last_error() */
 RthMesh *rth_obj_load(const char *path);
+/* OBJLoader::load_lenient: additionally accepts `v//vn` tokens and negative (relative) indices */
+RthMesh *rth_obj_load_lenient(const char *path);
 /* MeshPrimitive(std::vector<TrianglePrimitive>) (MeshPrimitive.h:31); tris18 = n x {v0 v1 v2 normal uv0 uv1 uv2} */
 RthMesh *rth_mesh_from_triangles(const float *tris18, int32_t n);
 /* TrianglePrimitive(a, b, c) (TrianglePrimitive.hpp:15): one triangle, normal from the winding */
@@ -75,6 +77,10 @@ int rth_camera_render_scene_stripes_batch(RthCamera *c, RthScene *s, const float
                                           int32_t num_ranks, int synchronize);
 /* the RtCameraParams (rt_hip.h) the camera would launch with: 1 + 1 + 9 + 4 + 6 + 6 words */
 void rth_camera_params(const RthCamera *c, void *out_RtCameraParams);
+
+/* display_image()'s `cv::imwrite("out.png", ...)` (kernel.cu:30-43): device BGR image -> RGB PNG file; and from host bytes */
+int rth_save_png(const char *path, const void *d_img, int32_t width, int32_t height, size_t pitch);
+int rth_write_png_bgr(const char *path, const uint8_t *bgr, int32_t width, int32_t height, size_t pitch);
 
 /* host math with the reference's names, for parity tests (utils.hpp / transforms.hpp) */
 float rth_q_rsqrt(float x);

@@ -220,3 +220,93 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
                 text = open(os.path.join(dp, f), errors="ignore").read()
                 assert "rt_oracle" not in text and "librt_oracle" not in text and "import orc" not in text, f
+
+
+def test_png_writer_roundtrip(rt, tmp_path):
+    """write_png_bgr (display_image's out.png without OpenCV): decodes with PIL to the same pixels, B,G,R -> R,G,B."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for w, h in [(1, 1), (7, 5), (301, 223)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / ("t_%d_%d.png" % (w, h)))
+        rt.write_png(p, img)
+        back = np.asarray(Image.open(p).convert("RGB"))
+        assert back.shape == (h, w, 3) and np.array_equal(back, img[:, :, ::-1])
+    _, s = rt.libs()
+    assert s.rth_write_png_bgr(b"/nonexistent_dir/x.png", img.ctypes.data, w, h, w * 3) == -1
+
+
+def test_obj_lenient_mode(rt, tmp_path):
+    """OBJLoader::load_lenient: `v//vn` tokens and negative (relative) indices give the same mesh as the equivalent
+    strict file; strict mode still rejects them like the reference (H11)."""
+    strict = tmp_path / "strict.obj"
+    strict.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nf 1/1 2/2 3/3\nv 0 1 0.5\nvt 0 1\nf 1/1 3/3 4/4\nf 1 2 4\n")
+    loose = tmp_path / "loose.obj"
+    loose.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nf -3/-3 -2/-2 -1/-1\nv 0 1 0.5\nvt 0 1\n"
+                     "f 1/1/1 3/3/1 -1/-1/1\nf 1//1 2//1 4//1\n")
+    a = rt.Mesh.load_obj(str(strict)).dump()
+    b = rt.Mesh.load_obj(str(loose), lenient=True).dump()
+    assert a["tris"].shape == (3, 18)
+    _mesh_equal(a, b)
+    with pytest.raises(rt.RtError):
+        rt.Mesh.load_obj(str(loose))
+
+
+def _desc_from_mesh(rt, dump):
+    """RtMeshDesc (plus the arrays that back it) from a Mesh.dump()."""
+    t = dump["tris"]
+    keep = dict(v=np.ascontiguousarray(t[:, 0:9]), n=np.ascontiguousarray(t[:, 9:12]), uv=np.ascontiguousarray(t[:, 12:18]),
+                b=np.ascontiguousarray(dump["boxes"]), c=np.ascontiguousarray(dump["child"]),
+                lc=np.ascontiguousarray(dump["leaf_count"]), li=np.ascontiguousarray(dump["leaf_idx"]))
+    first = np.zeros(len(keep["lc"]), np.int32)
+    first[1:] = np.cumsum(keep["lc"])[:-1]
+    keep["lf"] = first
+    f, i = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    d = rt.RtMeshDesc(t.shape[0], keep["v"].ctypes.data_as(f), keep["n"].ctypes.data_as(f), keep["uv"].ctypes.data_as(f),
+                      len(keep["lc"]), keep["b"].ctypes.data_as(f), keep["c"].ctypes.data_as(i), keep["lf"].ctypes.data_as(i),
+                      keep["lc"].ctypes.data_as(i), len(keep["li"]), keep["li"].ctypes.data_as(i))
+    return d, keep
+
+
+def test_scene_upload_validates_its_input(rt, blob5k):
+    """rt_scene_upload rejects malformed trees / indices with RT_E_INVALID before it touches the device (the traversal
+    kernel trusts the uploaded layout, so a bad tree must never reach it)."""
+    import scene_defs as sd
+    h, _ = rt.libs()
+    dump = rt.Mesh.from_triangles(sd.random_triangles(40, seed=9)).dump()
+    mat = rt.RtMaterialDesc(0.0, (C.c_float * 3)(1, 1, 1), 0.0, 0.0, None, 0, 0, 0)
+    inst = rt.RtInstanceDesc(0, 0, (C.c_float * 6)(), (C.c_float * 6)(), (C.c_float * 3)(), (C.c_float * 3)(),
+                             (C.c_float * 3)(1, 1, 1), (C.c_float * 3)(1, 1, 1))
+
+    def upload(mesh_desc, instance=inst, material=mat):
+        sd_ = rt.RtSceneDesc(1, C.pointer(mesh_desc), 1, C.pointer(material), 1, C.pointer(instance))
+        out = C.c_void_p()
+        rc = h.rt_scene_upload(C.byref(sd_), C.byref(out))
+        if rc == 0:
+            h.rt_scene_destroy(out)
+        return rc
+
+    d, keep = _desc_from_mesh(rt, dump)
+    ok = upload(d)
+    assert ok != -1                                        # valid: succeeds on a GPU box, "no device"-type error here
+    if rt.device_count() == 0:
+        assert ok != 0
+
+    def broken(mutate):
+        d2, k2 = _desc_from_mesh(rt, dump)
+        mutate(d2, k2)
+        return upload(d2)
+    interior = int(np.nonzero(keep["c"][:, 0] > 0)[0][0])
+    leaf = int(np.nonzero(keep["c"][:, 0] < 0)[0][0])
+    assert broken(lambda d2, k: k["c"].__setitem__((interior, 0), len(k["lc"]) + 5)) == -1      # child out of range
+    assert broken(lambda d2, k: k["c"].__setitem__((interior, 1), interior)) == -1              # child not after parent (cycle)
+    assert broken(lambda d2, k: k["c"].__setitem__((interior, 1), k["c"][interior, 0])) == -1   # both children the same node
+    assert broken(lambda d2, k: k["lc"].__setitem__(leaf, 10 ** 6)) == -1                       # leaf range past the list
+    assert broken(lambda d2, k: k["li"].__setitem__(0, 10 ** 6)) == -1                          # triangle index out of range
+    assert broken(lambda d2, k: setattr(d2, "num_nodes", 0)) == -1
+    bad_inst = rt.RtInstanceDesc(3, 0, (C.c_float * 6)(), (C.c_float * 6)(), (C.c_float * 3)(), (C.c_float * 3)(),
+                                 (C.c_float * 3)(1, 1, 1), (C.c_float * 3)(1, 1, 1))
+    assert upload(d, instance=bad_inst) == -1                                                   # mesh_index out of range
+    tex = np.zeros((4, 4, 3), np.uint8)
+    bad_mat = rt.RtMaterialDesc(0.0, (C.c_float * 3)(1, 1, 1), 0.0, 0.0, tex.ctypes.data, 4, 4, 5)   # pitch < width * 3
+    assert upload(d, material=bad_mat) == -1
