@@ -7,7 +7,7 @@ casts exactly one ray per pixel: raycast.cu:204), scene resident in HBM before t
 
   python bench.py [--gpus N --steps K --warmup W] [--camera far|mid|near] [--no-cpu-baseline]
 
-Frames are issued in groups of --frames-per-launch F (default 4) through Camera::render_scene_batch /
+Frames are issued in groups of --frames-per-launch F (default 8, the maximum) through Camera::render_scene_batch /
 rt_render_batch: one launch renders F complete frames into F buffers, so the last long rays of one frame
 overlap the bulk of the next (the reference's own loop issues two renders per synchronise,
 kernel.cu:277-279).  K steps = K frames = K/F launches; F = 1 gives one launch per frame.
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
     ap.add_argument("--width", type=int, default=scenes.C2["width"])
     ap.add_argument("--height", type=int, default=scenes.C2["height"])
-    ap.add_argument("--frames-per-launch", type=int, default=4)
+    ap.add_argument("--frames-per-launch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
     args = ap.parse_args()
@@ -143,8 +143,9 @@ def main():
     import math
     F = max(1, min(args.frames_per_launch, 8))
     F = math.gcd(F, args.steps) if args.steps > 0 else F        # K frames in exactly K / F launches
+    warmup_req = args.warmup
     if args.warmup % F:
-        args.warmup += F - args.warmup % F
+        args.warmup += F - args.warmup % F                       # whole groups: at least the requested warm-up
     pitch = W * 3
     frames = torch.empty((F, H, pitch), dtype=torch.uint8, device=dev)      # rank 0: the finished frames of one group
     hlib = rt.libs()[0]
@@ -170,10 +171,9 @@ def main():
                                        STRIPE_ROWS, rank, world)
 
     def unstripe(b):
-        st = torch.cuda.current_stream().cuda_stream
-        for f in range(F):
-            src, rank_stride = tiling.batch_unstripe_args(gathered[b].data_ptr(), f, F, max_rows, pitch)
-            rt.check(hlib.rt_unstripe(src, pitch, rank_stride, frames[f].data_ptr(), pitch, W, H, STRIPE_ROWS, world, st))
+        src, rank_stride = tiling.batch_unstripe_args(gathered[b].data_ptr(), 0, F, max_rows, pitch)
+        rt.check(hlib.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch, F,
+                                        W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 
     pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe) if world > 1 else None
 
@@ -248,7 +248,7 @@ def main():
         out = {
             "metric": "Mrays/sec + ms/frame, 70k-tri OBJ at 1920x1080 1spp; 1/2/4/8 MI355X",
             "value": round(W * H * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": warmup_req, "warmup_frames_done": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"

@@ -63,7 +63,7 @@ RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
     "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
-    "rt_render_debug", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
+    "rt_render_debug", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
     "rth_obj_load", "rth_obj_load_lenient", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
@@ -119,6 +119,8 @@ def _declare(h, s):
     h.rt_stripe_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i]
     h.rt_render_stripes.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int]
     h.rt_unstripe.argtypes = [_vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
+    h.rt_unstripe_batch.argtypes = [_vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, _vp]
     h.rt_timer_create.argtypes = [C.POINTER(_vp)]
     h.rt_timer_start.argtypes = [_vp, _vp]
     h.rt_timer_stop.argtypes = [_vp, _vp]

@@ -486,12 +486,14 @@ __global__ __launch_bounds__(kBlock) void render_ex_kernel(const RenderParams p)
 }
 
 // rows of a rank-major gathered buffer back into frame order (rt_unstripe)
-__global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pitch, size_t rank_stride,
-                                uint8_t* __restrict__ dst, size_t pitch, int row_bytes, int height,
+__global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
+                                uint8_t* __restrict__ dst, size_t pitch, size_t dst_frame_stride, int row_bytes, int height,
                                 int stripe_rows, int num_ranks)
 {
     const int y = blockIdx.y;
     if (y >= height) return;
+    src += (size_t)blockIdx.z * src_frame_stride;               // blockIdx.z = frame of the batch
+    dst += (size_t)blockIdx.z * dst_frame_stride;
     const int stripe = y / stripe_rows, rank = stripe % num_ranks;
     const int ly = (stripe / num_ranks) * stripe_rows + y % stripe_rows;
     const uint8_t* s = src + (size_t)rank * rank_stride + (size_t)ly * local_pitch;
@@ -929,16 +931,23 @@ int rt_render_stripes(RtScene* s, const RtCameraParams* cam, uint8_t* d_local, s
     return rt_render_stripes_batch(s, cam, &d_local, local_pitch, 1, stripe_rows, rank, num_ranks, stream, synchronize);
 }
 
+int rt_unstripe_batch(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
+                      uint8_t* d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
+                      int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void* stream)
+{
+    if (!d_gathered || !d_imgs || count < 1 || width <= 0 || height <= 0 || stripe_rows <= 0 || num_ranks <= 0 ||
+        local_pitch < (size_t)width * 3 || pitch < (size_t)width * 3) return RT_E_INVALID;
+    dim3 grid(4, (unsigned)height, (unsigned)count), block(256);
+    hipLaunchKernelGGL(unstripe_kernel, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride, src_frame_stride,
+                       d_imgs, pitch, dst_frame_stride, width * 3, height, stripe_rows, num_ranks);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
 int rt_unstripe(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, uint8_t* d_img, size_t pitch,
                 int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void* stream)
 {
-    if (!d_gathered || !d_img || width <= 0 || height <= 0 || stripe_rows <= 0 || num_ranks <= 0 ||
-        local_pitch < (size_t)width * 3 || pitch < (size_t)width * 3) return RT_E_INVALID;
-    dim3 grid(4, (unsigned)height), block(256);
-    hipLaunchKernelGGL(unstripe_kernel, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride,
-                       d_img, pitch, width * 3, height, stripe_rows, num_ranks);
-    RT_HIP(hipGetLastError());
-    return RT_OK;
+    return rt_unstripe_batch(d_gathered, local_pitch, rank_stride, 0, d_img, pitch, 0, 1, width, height, stripe_rows, num_ranks, stream);
 }
 
 int rt_timer_create(RtTimer** t)

@@ -165,6 +165,12 @@ int rt_unstripe(const uint8_t *d_gathered, size_t local_pitch, size_t rank_strid
                 uint8_t *d_img, size_t pitch, int32_t width, int32_t height,
                 int32_t stripe_rows, int32_t num_ranks, void *stream);
 
+/* the same for `count` frames at once: frame f reads from d_gathered + f * src_frame_stride and writes to
+ * d_imgs + f * dst_frame_stride (the layout of a gathered rt_render_stripes_batch group) */
+int rt_unstripe_batch(const uint8_t *d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
+                      uint8_t *d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
+                      int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void *stream);
+
 /* ---- timing on the stream the kernels run on (hipEvent) ---------------------------------- */
 typedef struct RtTimer RtTimer;
 int rt_timer_create(RtTimer **t);

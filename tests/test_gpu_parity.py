@@ -209,6 +209,15 @@ def test_batched_stripes_layout(rt, scenes, blob5k):
             rt.check(h.rt_device_synchronize())
             assert np.array_equal(out.to_host().reshape(H, W, 3), full[f]), "world %d frame %d" % (world, f)
             out.free()
+        # all F frames in one rt_unstripe_batch call, as bench.py does
+        outs = rt.DeviceBuffer(nbytes=F * H * pitch)
+        src, rank_stride = tiling.batch_unstripe_args(g0, 0, F, max_rows, pitch)
+        rt.check(h.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, outs.ptr, pitch, H * pitch, F, W, H, stripe, world, None))
+        rt.check(h.rt_device_synchronize())
+        got = outs.to_host().reshape(F, H, W, 3)
+        for f in range(F):
+            assert np.array_equal(got[f], full[f]), "batched unstripe world %d frame %d" % (world, f)
+        outs.free()
         gathered.free()
 
 
