@@ -150,21 +150,14 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     return false;
 }
 
-// One leaf (raycast.cu:83-137): contiguous triangle slots.  The caller already fetched the whole 64-B record
-// of the first slot into t0..t3 (the scene keeps one padding record after the last slot so that fetch is
-// always in bounds, even for an empty leaf).
+// One triangle of a leaf (one iteration of raycast.cu:85-136) from its already fetched 64-B record t0..t3.
 template <bool DEBUG, bool EX>
-__device__ __forceinline__ void leaf_step(const RenderParams& p, const DevInstance& in, int inst_index, const MeshRay& r,
-                                          V3 org, int32_t cur, Hit& hit, Counters<DEBUG>& cnt,
-                                          float4 t0, float4 t1, float4 t2, float4 t3)
+__device__ __forceinline__ void triangle_step(const RenderParams& p, const DevInstance& in, int inst_index, const MeshRay& r,
+                                              V3 org, int slot, Hit& hit, Counters<DEBUG>& cnt,
+                                              float4 t0, float4 t1, float4 t2, float4 t3)
 {
     const bool exact_uv = in.exact_uv != 0;
-    int slot = cur & kSlotMask;
-    int count = (cur >> kSlotBits) & 31;
-    if (count == 31) count = p.leaf_count[slot];
-    for (int i = 0; i < count; i++, slot++) {
-        const float4* t = p.tris + (size_t)slot * 4;
-        if (i > 0) { t0 = t[0]; t1 = t[1]; t2 = t[2]; t3 = t[3]; }
+    {
         if constexpr (DEBUG) cnt.tris++;
         V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
         // The reference's chain of early returns (TrianglePrimitive.hpp:66,72, raycast.cu:91,96) is evaluated as
@@ -232,15 +225,19 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
     stack.sp = 0;
     int32_t cur = in.root_ref;                                  // raycast.cu:58 (kept in a register)
     bool have = true;
+    int rem = -1;                                               // triangles left in the leaf being walked, -1 = not in a leaf
     unsigned long long c_pop = 0, c_mem = 0, c_int = 0, c_leaf = 0, n_it = 0, n_int = 0, n_leaf = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    // One iteration = one interior node or ONE triangle of a leaf (a leaf with k triangles takes k iterations and
+    // keeps `cur` pointing at its next slot), so the loop has no inner loop and every record -- node or triangle,
+    // first or later -- comes through the same fetch below.
     while (true) {
         if constexpr (PROF) t0 = __builtin_amdgcn_s_memtime();
         if (!have) {
             if (stack.sp == 0) break;
             cur = stack.pop();                                  // raycast.cu:61
         }
-        if constexpr (DEBUG) cnt.pops++;
         const bool interior = cur >= 0;
+        if constexpr (DEBUG) cnt.pops += (interior || rem < 0) ? 1 : 0;
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t1 = __builtin_amdgcn_s_memtime(); }
         // About half of all wave iterations (three quarters for close-up views) find every active lane holding
         // the SAME entry -- coherent rays walk the top of the tree in lockstep.  Those iterations fetch the record
@@ -267,9 +264,17 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         }
         if (interior) have = interior_apply<DEBUG>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t3 = __builtin_amdgcn_s_memtime(); }
-        if (!interior) {
-            leaf_step<DEBUG, EX>(p, in, inst_index, r, org, cur, hit, cnt, r0, r1, r2, r3);
-            have = false;
+        if (!interior) {                                        // leaf: contiguous triangle slots, raycast.cu:83-137
+            const int slot = cur & kSlotMask;
+            if (rem < 0) {                                      // first visit: decode the triangle count
+                rem = (cur >> kSlotBits) & 31;
+                if (rem == 31) rem = p.leaf_count[slot];
+            }
+            if (rem > 0) triangle_step<DEBUG, EX>(p, in, inst_index, r, org, slot, hit, cnt, r0, r1, r2, r3);
+            rem--;
+            have = rem > 0;
+            cur = have ? cur + 1 : cur;                         // next slot of the same leaf (the slot field never overflows)
+            rem = have ? rem : -1;
         }
         if constexpr (PROF) {
             __builtin_amdgcn_s_waitcnt(0);
