@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for b in 1 8; do python tools/kbench.py --iters 50 --batch $b --check 2>&1 | grep -v "^Loading\|^OBJ\|^Loaded\|^scene"; done
-python tools/kbench.py --scene atrium --width 3840 --height 2160 --iters 20 --batch 4 --check 2>&1 | grep -v "^Loading\|^OBJ\|^Loaded\|^scene"
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python tools/kbench.py --iters 5 --ex 1,0,1 2>&1 | grep -v "^Loading\|^OBJ\|^Loaded\|^scene"
+python tools/kbench.py --iters 3 --ex 64,8,1 2>&1 | grep -v "^Loading\|^OBJ\|^Loaded\|^scene"
+python tools/kbench.py --iters 3 --ex 16,0,0 --scene atrium --width 3840 --height 2160 2>&1 | grep -v "^Loading\|^OBJ\|^Loaded\|^scene"
+rm -rf gpurun_out/prof_v5; bash tools/profile_bench.sh gpurun_out/prof_v5 | tail -2
+python bench.py --latency-probe 2>&1 | tail -1 > gpurun_out/bench_r01_final.json; cut -c1-300 gpurun_out/bench_r01_final.json

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="blob70k", choices=["blob70k", "blob5k", "atrium"])
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (rt_render_batch)")
+    ap.add_argument("--ex", default=None, help="spp,bounces,lighting: time the extension kernel (rt_render_ex) instead")
     ap.add_argument("--check", action="store_true", help="compare the frame hash with the debug kernel's")
     a = ap.parse_args()
     rt.build()
@@ -30,7 +31,8 @@ def main():
          "atrium": scenes.write_atrium_obj}[a.scene](obj)
     mesh = rt.Mesh.load_obj(obj)
     scene = rt.Scene()
-    scene.add_material(scenes.C4["albedo"] if a.scene == "atrium" else scenes.C2["albedo"])
+    scene.add_material(scenes.C4["albedo"] if a.scene == "atrium" else scenes.C2["albedo"], roughness=0.05 if a.ex else 0.0,
+                       metallic=0.4 if a.ex else 0.0)
     scene.add_mesh(mesh)
     scene.add_mesh_instance(0, 0)
     scene.upload_to_device()
@@ -44,8 +46,12 @@ def main():
     for name, pose in cams.items():
         cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
         cam.set_pose(pose)
+        if a.ex:
+            spp, bounces, lighting = (int(v) for v in a.ex.split(","))
+            cam.set_options(spp, bounces, lighting)
+
         def go():
-            if a.batch == 1:
+            if a.ex or a.batch == 1:
                 cam.render_scene(scene, img.ptr, img.pitch)
             else:
                 cam.render_scene_batch(scene, [pose] * a.batch, ptrs, img.pitch)
