@@ -166,11 +166,12 @@ def main():
     frame_ptrs = [frames[f].data_ptr() for f in range(F)]
     local_ptrs = [tiling.batch_local_ptrs(local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if world > 1 else None
 
-    def render_group_single():
-        cam.render_scene_batch(scene, poses, frame_ptrs, pitch)
+    render_group_single = cam.prepared_batch(scene, poses, frame_ptrs, pitch)
+    render_local_calls = [cam.prepared_batch(scene, poses, local_ptrs[b], pitch, stripes=(STRIPE_ROWS, rank, world))
+                          for b in range(2)] if world > 1 else None
 
     def render_local(b):
-        cam.render_scene_stripes_batch(scene, poses, local_ptrs[b], pitch, STRIPE_ROWS, rank, world)
+        render_local_calls[b]()
 
     def unstripe(b):
         src, rank_stride = tiling.batch_unstripe_args(gathered[b].data_ptr(), 0, F, max_rows, pitch)

@@ -354,6 +354,32 @@ class Camera:
         check(libs()[1].rth_camera_render_scene_batch(self.h, scene.h, _fp(P), ptrs, pitch, n, 1 if synchronize else 0),
               "Camera::render_scene_batch")
 
+    def prepared_batch(self, scene, poses, d_ptrs, pitch, stripes=None):
+        """A zero-argument callable that issues one batched launch with pre-built ctypes arguments (the per-call Python
+        overhead matters when a rank's share of a frame takes tens of microseconds).  stripes = (stripe_rows, rank,
+        num_ranks) renders this rank's stripes, None renders whole frames."""
+        n = len(poses)
+        P = _fa(np.asarray(poses, np.float32).reshape(n, 6))
+        ptrs = (_vp * n)(*[int(x) if not isinstance(x, _vp) else x.value for x in d_ptrs])
+        host, cam_h, scene_h, Pp = libs()[1], self.h, scene.h, _fp(P)
+        if stripes is None:
+            fn = host.rth_camera_render_scene_batch
+
+            def call():
+                rc = fn(cam_h, scene_h, Pp, ptrs, pitch, n, 0)
+                if rc:
+                    check(rc, "Camera::render_scene_batch")
+        else:
+            fn = host.rth_camera_render_scene_stripes_batch
+            sr, rk, nr = stripes
+
+            def call():
+                rc = fn(cam_h, scene_h, Pp, ptrs, pitch, n, sr, rk, nr, 0)
+                if rc:
+                    check(rc, "Camera::render_scene_stripes_batch")
+        call._keep = (P, ptrs)
+        return call
+
     def render_scene_stripes_batch(self, scene, poses, d_locals, local_pitch, stripe_rows, rank, num_ranks, synchronize=False):
         n = len(poses)
         P = _fa(np.asarray(poses, np.float32).reshape(n, 6))

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "cpp_demo" 2>&1 | tail -15
+python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-330
+python bench.py --no-cpu-baseline --camera far 2>&1 | tail -1 | cut -c1-330
