@@ -62,11 +62,11 @@ class RtSceneDesc(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
+    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
     "rt_render_debug", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
-    "rth_obj_load", "rth_obj_load_lenient", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
+    "rth_obj_load", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
     "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
     "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
     "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance",
@@ -128,11 +128,13 @@ def _declare(h, s):
     h.rt_timer_destroy.argtypes = [_vp]
 
     s.rth_last_error.restype = C.c_char_p
-    for n in ("rth_obj_load", "rth_obj_load_lenient", "rth_mesh_from_triangles", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
+    for n in ("rth_obj_load", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
               "rth_scene_device_handle"):
         getattr(s, n).restype = _vp
     s.rth_obj_load.argtypes = [C.c_char_p]
     s.rth_obj_load_lenient.argtypes = [C.c_char_p]
+    s.rth_obj_load_gpu.argtypes = [C.c_char_p]
+    s.rth_mesh_from_triangles_gpu.argtypes = [_f, C.c_int32]
     s.rth_mesh_from_triangles.argtypes = [_f, C.c_int32]
     s.rth_mesh_single_triangle.argtypes = [_f]
     for n in ("rth_mesh_free", "rth_mesh_num_triangles", "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_print_stats",
@@ -210,14 +212,15 @@ class Mesh:
         self.h = handle
 
     @classmethod
-    def load_obj(cls, path, lenient=False):           # OBJLoader::load / load_lenient
-        fn = libs()[1].rth_obj_load_lenient if lenient else libs()[1].rth_obj_load
+    def load_obj(cls, path, lenient=False, gpu_build=False):    # OBJLoader::load / load_lenient; BVH on host or GPU
+        fn = libs()[1].rth_obj_load_gpu if gpu_build else (libs()[1].rth_obj_load_lenient if lenient else libs()[1].rth_obj_load)
         return cls(fn(os.fsencode(path)))
 
     @classmethod
-    def from_triangles(cls, tris18):                  # MeshPrimitive(std::vector<TrianglePrimitive>)
+    def from_triangles(cls, tris18, gpu_build=False):  # MeshPrimitive(std::vector<TrianglePrimitive>[, build_on_device])
         t = _fa(tris18).reshape(-1, 18)
-        return cls(libs()[1].rth_mesh_from_triangles(_fp(t), t.shape[0]))
+        fn = libs()[1].rth_mesh_from_triangles_gpu if gpu_build else libs()[1].rth_mesh_from_triangles
+        return cls(fn(_fp(t), t.shape[0]))
 
     @classmethod
     def single_triangle(cls, abc9):                   # TrianglePrimitive(a, b, c)

@@ -19,7 +19,7 @@ HOST_SO = os.path.join(HERE, "librt_host.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-HIP_SRCS = [os.path.join(CSRC, "rt_kernels.hip")]
+HIP_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_bvh_build.hip")]
 HIP_DEPS = HIP_SRCS + [os.path.join(CSRC, n) for n in ("rt_math.h", "rt_device_types.h")] + \
     [os.path.join(ROOT, "include", "rt_hip.h")]
 HOST_SRCS = [os.path.join(CSRC, "host", n) for n in ("rt_host.cpp", "rt_host_capi.cpp")]

@@ -23,6 +23,8 @@ public:
 
     BVHTree() {}
     void build(const TrianglePrimitive* triangles, int num_triangles, int max_depth = 32);   // fill(1, 32)
+    // the same tree built on the GPU (rt_bvh_build); returns an rt_hip.h status, the tree is unchanged on failure
+    int build_on_device(const TrianglePrimitive* triangles, int num_triangles, int max_depth = 32);
     int max_level() const { return levels_; }
     void print_stats() const;                      // same report as BVHTree.hpp:117-172
 

@@ -8,6 +8,9 @@
 class MeshPrimitive {
 public:
     explicit MeshPrimitive(std::vector<TrianglePrimitive> triangles);
+    // build_on_device = true builds the BVH with rt_bvh_build (GPU) instead of the host builder; same tree.
+    // Throws std::runtime_error if the device build fails.
+    MeshPrimitive(std::vector<TrianglePrimitive> triangles, bool build_on_device);
     int num_triangles;
     BVHTree bvh_top;
     const std::vector<TrianglePrimitive>& triangle_array() const { return triangles; }

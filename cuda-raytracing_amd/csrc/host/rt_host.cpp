@@ -143,6 +143,38 @@ void BVHTree::fill(int self, int depth, int max_depth)
     fill(b, depth + 1, max_depth);
 }
 
+int BVHTree::build_on_device(const TrianglePrimitive* triangles, int n, int max_depth)
+{
+    std::vector<float> v((size_t)n * 9);
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            v[9 * (size_t)i + 3 * k] = triangles[i].vertices[k].x;
+            v[9 * (size_t)i + 3 * k + 1] = triangles[i].vertices[k].y;
+            v[9 * (size_t)i + 3 * k + 2] = triangles[i].vertices[k].z;
+        }
+    const size_t cap = n > 0 ? 2 * (size_t)n : 1;
+    std::vector<float> bounds(cap * 6);
+    std::vector<int32_t> children(cap * 2), lfirst(cap), lcount(cap), leaf((size_t)(n > 0 ? n : 1));
+    int32_t num = 0, levels = 1;
+    int rc = rt_bvh_build(v.data(), n, max_depth, bounds.data(), children.data(), lfirst.data(), lcount.data(), leaf.data(), &num, &levels);
+    if (rc) return rc;
+    nodes.assign((size_t)num, BVHNode());
+    for (int k = 0; k < num; k++) {
+        BVHNode& nd = nodes[k];
+        nd.min = make_float3(bounds[6 * k], bounds[6 * k + 1], bounds[6 * k + 2]);
+        nd.max = make_float3(bounds[6 * k + 3], bounds[6 * k + 4], bounds[6 * k + 5]);
+        nd.child_index_a = children[2 * k]; nd.child_index_b = children[2 * k + 1];
+        nd.first = lfirst[k];
+    }
+    // BVHNode::count is the node's own triangle count for interior nodes too: recover it bottom-up (children follow parents)
+    for (int k = num - 1; k >= 0; k--)
+        nodes[k].count = nodes[k].child_index_a < 0 ? lcount[k] : nodes[nodes[k].child_index_a].count + nodes[nodes[k].child_index_b].count;
+    order.assign(leaf.begin(), leaf.begin() + n);
+    levels_ = levels;
+    tris_ = triangles;
+    return RT_OK;
+}
+
 void BVHTree::print_stats() const
 {
     int count_nodes = 0, max_t = 0, min_t = 1000000, max_depth = 0, count_leaves = 0;
@@ -178,6 +210,14 @@ MeshPrimitive::MeshPrimitive(std::vector<TrianglePrimitive> tris) : triangles(st
 {
     num_triangles = (int)triangles.size();
     bvh_top.build(triangles.data(), num_triangles, 32);
+}
+
+MeshPrimitive::MeshPrimitive(std::vector<TrianglePrimitive> tris, bool build_on_device) : triangles(std::move(tris))
+{
+    num_triangles = (int)triangles.size();
+    if (!build_on_device) { bvh_top.build(triangles.data(), num_triangles, 32); return; }
+    int rc = bvh_top.build_on_device(triangles.data(), num_triangles, 32);
+    if (rc) throw std::runtime_error(std::string("MeshPrimitive: GPU BVH build failed: ") + rt_error_string(rc));
 }
 
 // ------------------------------------------------------------------------------ Material

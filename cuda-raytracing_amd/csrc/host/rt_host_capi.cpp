@@ -48,6 +48,23 @@ RthMesh* rth_mesh_from_triangles(const float* tris18, int32_t n)
         return new RthMesh(MeshPrimitive(std::move(tris)));
     } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
+RthMesh* rth_mesh_from_triangles_gpu(const float* tris18, int32_t n)
+{
+    try {
+        std::vector<TrianglePrimitive> tris((size_t)(n > 0 ? n : 0));
+        if (n > 0) memcpy((void*)tris.data(), tris18, (size_t)n * 72);
+        return new RthMesh(MeshPrimitive(std::move(tris), true));
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+RthMesh* rth_obj_load_gpu(const char* path)
+{
+    try {
+        std::vector<TrianglePrimitive> tris;
+        std::string err;
+        if (!path || !OBJLoader::parse(path, tris, &err)) { g_err = path ? err : "null path"; return nullptr; }
+        return new RthMesh(MeshPrimitive(std::move(tris), true));
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
 RthMesh* rth_mesh_single_triangle(const float* abc9)
 {
     try {

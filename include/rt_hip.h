@@ -119,6 +119,14 @@ int rt_scene_destroy(RtScene *scene);
 /* bytes of device memory the scene holds, and the traversal-stack depth it needs */
 int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);
 
+/* ---- GPU build of the reference's BVH (replaces MeshPrimitive::build_bvh -> BVHTree::fill(1, 32), MeshPrimitive.cpp:38-56,
+ *      BVHTree.hpp:203-292): identical topology, bounds and pre-order node numbering, built level by level on the device.
+ *      vertices: HOST [n][3][3].  Outputs are HOST arrays sized for 2n nodes (n leaf indices) in the RtMeshDesc layout;
+ *      *num_nodes receives the node count, *num_levels (optional) the tree depth in levels. ------------------------------ */
+int rt_bvh_build(const float *vertices, int32_t n, int32_t max_depth, float *node_bounds, int32_t *node_children,
+                 int32_t *node_leaf_first, int32_t *node_leaf_count, int32_t *leaf_indices, int32_t *num_nodes,
+                 int32_t *num_levels);
+
 /* ---- render (replaces Camera::render_scene -> render<<<grid, block>>>, Camera.cu:18-41,
  *      raycast.cu:146-297).  d_img is a caller-owned DEVICE buffer of `height` rows of `pitch`
  *      bytes, 3 bytes per pixel in uchar3 .x .y .z order (raycast.cu:292-294).  Asynchronous on

@@ -23,6 +23,9 @@ RthMesh *rth_obj_load(const char *path);
 RthMesh *rth_obj_load_lenient(const char *path);
 /* MeshPrimitive(std::vector<TrianglePrimitive>) (MeshPrimitive.h:31); tris18 = n x {v0 v1 v2 normal uv0 uv1 uv2} */
 RthMesh *rth_mesh_from_triangles(const float *tris18, int32_t n);
+/* the same meshes with the BVH built on the GPU (rt_bvh_build): identical tree, NULL if no device */
+RthMesh *rth_mesh_from_triangles_gpu(const float *tris18, int32_t n);
+RthMesh *rth_obj_load_gpu(const char *path);
 /* TrianglePrimitive(a, b, c) (TrianglePrimitive.hpp:15): one triangle, normal from the winding */
 RthMesh *rth_mesh_single_triangle(const float *abc9);
 void rth_mesh_free(RthMesh *m);

@@ -377,3 +377,48 @@ def test_cpp_demo_application(rt, orc, scenes, blob5k, tmp_path):
     ref = so.render(1920, 1080, scenes.K_1080, scenes.D_REF, (0.0, -1.6, 0.2, 0, 0, 0), planes=False, threads=16)
     assert np.array_equal(got, ref["img"])
     so.close()
+
+
+def _same_tree(a, b):
+    assert np.array_equal(a["child"], b["child"]) and np.array_equal(a["leaf_count"], b["leaf_count"])
+    assert np.array_equal(a["leaf_idx"], b["leaf_idx"])
+    assert np.array_equal(a["boxes"], b["boxes"])          # by value: atomics may pick -0.0 where the host fold picks +0.0
+    assert np.array_equal(a["tris"].view(np.uint32), b["tris"].view(np.uint32))
+
+
+def test_gpu_bvh_build_matches_host_builder(rt, scenes, blob5k, blob70k, atrium):
+    """rt_bvh_build: the level-parallel GPU build gives the host builder's (= the reference's) tree node
+    for node -- children, leaf lists, bounds, pre-order numbering -- on OBJ meshes, soups, degenerate and deep inputs."""
+    for path in (blob5k, blob70k, atrium):
+        host = rt.Mesh.load_obj(path)
+        dev = rt.Mesh.load_obj(path, gpu_build=True)
+        assert dev.num_nodes == host.num_nodes and dev.max_level == host.max_level
+        _same_tree(dev.dump(), host.dump())
+    for seed, n in [(1, 0), (2, 1), (3, 2), (4, 3), (5, 64), (6, 1500)]:
+        tris = sd.random_triangles(n, seed=seed) if n else np.zeros((0, 18), np.float32)
+        _same_tree(rt.Mesh.from_triangles(tris, gpu_build=True).dump(), rt.Mesh.from_triangles(tris).dump())
+    base = sd.random_triangles(6, seed=3, spread=0.5, size=0.6)
+    dup = np.concatenate([np.repeat(base[:1], 40, axis=0), np.repeat(base[1:2], 33, axis=0), base[2:]])
+    _same_tree(rt.Mesh.from_triangles(dup, gpu_build=True).dump(), rt.Mesh.from_triangles(dup).dump())
+    chain = sd.deep_stack_scene(28).meshes[0][1]
+    d = rt.Mesh.from_triangles(chain, gpu_build=True)
+    assert d.max_level == 28
+    _same_tree(d.dump(), rt.Mesh.from_triangles(chain).dump())
+
+
+def test_gpu_built_mesh_renders_identically(rt, orc, scenes, blob5k):
+    """A scene whose mesh BVH was built on the GPU renders the oracle's frame and visit counts."""
+    desc = sd.blob_scene(scenes, blob5k)
+    so = desc.build_oracle(orc)
+    W, H = 320, 180
+    K, pose = scenes.scaled_K(W), scenes.C2_CAMERAS["mid"]
+    ref = so.render(W, H, K, scenes.D_REF, pose, threads=8)
+    sp = rt.Scene()
+    sp.add_material(scenes.C2["albedo"])
+    sp.add_mesh(rt.Mesh.load_obj(blob5k, gpu_build=True))
+    sp.add_mesh_instance(0, 0)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose(pose)
+    dbg = rt.render_debug(sp, cam)
+    assert np.array_equal(dbg["img"], ref["img"]) and np.array_equal(dbg["pops"], ref["pops"]) and np.array_equal(dbg["hit_tri"], ref["hit_tri"])
