@@ -1,8 +1,12 @@
-// Scene.h -- host scene graph with the reference's interface (Scene.h:19-28).  upload_to_device()
-// flattens everything and hands it to rt_scene_upload (include/rt_hip.h); the device buffers are
-// owned by the library behind `d_scene` instead of the three raw device pointers of Scene.h:23-25.
+// Scene.h -- the host scene graph: what was added, and the device copy made from it.
+//
+// Same calls as the reference's Scene (Scene.h:19-28): add_* store by value and hand back nothing (indices are the
+// insertion order), upload_to_device() (re)builds the device scene, update_mesh_instance() re-poses one instance
+// without rebuilding.  The device side is owned by librt_hip.so behind `d_scene` (an RtScene*, see include/rt_hip.h)
+// instead of the reference's three raw device pointers.
 #pragma once
 #include <vector>
+
 #include "Material.hpp"
 #include "MeshInstance.hpp"
 #include "MeshPrimitive.h"
@@ -10,25 +14,28 @@
 struct RtScene;
 
 class Scene {
-    std::vector<Material> materials;
-    std::vector<MeshPrimitive> meshes;
-    std::vector<MeshInstance> mesh_instances;
-
 public:
     Scene();
-    ~Scene();
-    Scene(const Scene&) = delete;
+    ~Scene();                                       // releases the device scene
+    Scene(const Scene&) = delete;                   // owns device memory
     Scene& operator=(const Scene&) = delete;
 
-    void add_material(Material material);
+    // ---- what the scene contains (host side) ----
     void add_mesh(MeshPrimitive mesh);
+    void add_material(Material material);
     void add_mesh_instance(MeshInstance mesh_instance);
     int num_materials() const { return (int)materials.size(); }
     Material& material(int index) { return materials[index]; }      // edit before upload_to_device()
 
+    // ---- device side ----
+    void upload_to_device();                        // flatten everything and call rt_scene_upload (Scene.cpp:25-65)
+    void update_mesh_instance(int index, MeshInstance mesh_instance);   // rt_scene_update_instance (Scene.cpp:67-74)
     RtScene* d_scene = nullptr;
     int num_mesh_instances = 0;
-    int last_error = 0;                            // rt_hip.h status of the last device call
-    void upload_to_device();
-    void update_mesh_instance(int index, MeshInstance mesh_instance);
+    int last_error = 0;                             // rt_hip.h status of the last device call (the reference ignores errors)
+
+private:
+    std::vector<MeshPrimitive> meshes;
+    std::vector<Material> materials;
+    std::vector<MeshInstance> mesh_instances;
 };
