@@ -422,3 +422,34 @@ def test_gpu_built_mesh_renders_identically(rt, orc, scenes, blob5k):
     cam.set_pose(pose)
     dbg = rt.render_debug(sp, cam)
     assert np.array_equal(dbg["img"], ref["img"]) and np.array_equal(dbg["pops"], ref["pops"]) and np.array_equal(dbg["hit_tri"], ref["hit_tri"])
+
+
+def test_8k_frame_bands(rt, orc, scenes, blob70k):
+    """BASELINE.json configs[4] resolution (7680x4320, 1 primary ray/pixel): three 24-row bands of the GPU frame against
+    the oracle (RGB + hit ids + pops), and the striped 8-rank rendering of the full frame against the single launch."""
+    import importlib
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    W, H = 7680, 4320
+    desc = sd.blob_scene(scenes, blob70k)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    K, pose = scenes.scaled_K(W), scenes.C2_CAMERAS["mid"]
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose(pose)
+    dbg = rt.render_debug(sp, cam)
+    so = desc.build_oracle(orc)
+    for y0 in (0, 2148, H - 24):
+        ref = so.render(W, H, K, scenes.D_REF, pose, y0=y0, y1=y0 + 24, threads=24)
+        for k in ("img", "hit_tri", "pops"):
+            assert np.array_equal(dbg[k][y0:y0 + 24], ref[k][y0:y0 + 24]), (k, y0)
+    so.close()
+    world, stripe, pitch = 8, 16, W * 3
+    max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+    gathered = rt.DeviceBuffer(nbytes=world * max_rows * pitch)
+    for r in range(world):
+        cam.render_scene_stripes(sp, gathered.ptr.value + r * max_rows * pitch, pitch, stripe, r, world)
+    out = rt.DeviceBuffer(width_bytes=pitch, height=H)
+    rt.check(h.rt_unstripe(gathered.ptr, pitch, max_rows * pitch, out.ptr, out.pitch, W, H, stripe, world, None))
+    rt.check(h.rt_device_synchronize())
+    assert np.array_equal(out.to_host().reshape(H, W, 3), dbg["img"])
