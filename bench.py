@@ -7,7 +7,8 @@ casts exactly one ray per pixel: raycast.cu:204), scene resident in HBM before t
 
   python bench.py [--gpus N --steps K --warmup W] [--camera far|mid|near] [--no-cpu-baseline]
 
-Frames are issued in groups of --frames-per-launch F (default 8, the maximum) through Camera::render_scene_batch /
+Frames are issued in groups of F (default: up to 8 per GPU-share of a frame, i.e. 8 / 16 / 32 / 32 for 1 / 2 / 4 / 8 GPUs,
+reduced to a divisor of K) through Camera::render_scene_batch /
 rt_render_batch: one launch renders F complete frames into F buffers, so the last long rays of one frame
 overlap the bulk of the next (the reference's own loop issues two renders per synchronise,
 kernel.cu:277-279).  K steps = K frames = K/F launches; F = 1 gives one launch per frame.
@@ -99,8 +100,10 @@ def main():
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
     ap.add_argument("--width", type=int, default=scenes.C2["width"])
     ap.add_argument("--height", type=int, default=scenes.C2["height"])
-    ap.add_argument("--frames-per-launch", type=int, default=8)
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = 8 per GPU-share: 8, 16, 32, 32 for 1, 2, 4, 8 GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 logic with host-staged gathers (several ranks may share one GPU); never for numbers")
     ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
     args = ap.parse_args()
 
@@ -113,11 +116,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    rehearsal = world > 1 and args.debug_backend == "gloo"
+    if rehearsal:
+        local_rank %= max(torch.cuda.device_count(), 1)          # ranks may share a device in the rehearsal
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     rt.build()
     rt.libs()
@@ -141,8 +150,11 @@ def main():
     cam.set_stream(stream)
 
     import math
-    F = max(1, min(args.frames_per_launch, 8))
-    F = math.gcd(F, args.steps) if args.steps > 0 else F        # K frames in exactly K / F launches
+    # A launch should carry several frames' worth of work for THIS GPU (a rank renders 1/N of each frame), so the
+    # group grows with N; F is then the largest divisor of K not above it: K frames in exactly K / F launches.
+    f_max = args.frames_per_launch if args.frames_per_launch > 0 else 8 * min(world, 4)
+    f_max = max(1, min(f_max, 32))
+    F = max(d for d in range(1, f_max + 1) if args.steps % d == 0) if args.steps > 0 else f_max
     warmup_req = args.warmup
     if args.warmup % F:
         args.warmup += F - args.warmup % F                       # whole groups: at least the requested warm-up
@@ -160,11 +172,17 @@ def main():
         # per buffer: F frames x this rank's (padded) stripe rows
         local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
         gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
+        if rehearsal:                                            # gloo cannot gather device tensors: stage through the host
+            local_dev, gathered_dev = local, gathered
+            local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8) for _ in range(2)]
+            gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8) if rank == 0 else None for _ in range(2)]
 
     timer = rt.Timer()
 
     frame_ptrs = [frames[f].data_ptr() for f in range(F)]
-    local_ptrs = [tiling.batch_local_ptrs(local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if world > 1 else None
+    dev_local = (local_dev if rehearsal else local) if world > 1 else None
+    dev_gathered = (gathered_dev if rehearsal else gathered) if world > 1 else None
+    local_ptrs = [tiling.batch_local_ptrs(dev_local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if world > 1 else None
 
     render_group_single = cam.prepared_batch(scene, poses, frame_ptrs, pitch)
     render_local_calls = [cam.prepared_batch(scene, poses, local_ptrs[b], pitch, stripes=(STRIPE_ROWS, rank, world))
@@ -172,9 +190,13 @@ def main():
 
     def render_local(b):
         render_local_calls[b]()
+        if rehearsal:
+            local[b].copy_(dev_local[b])
 
     def unstripe(b):
-        src, rank_stride = tiling.batch_unstripe_args(gathered[b].data_ptr(), 0, F, max_rows, pitch)
+        if rehearsal:
+            dev_gathered[b].copy_(gathered[b])
+        src, rank_stride = tiling.batch_unstripe_args(dev_gathered[b].data_ptr(), 0, F, max_rows, pitch)
         rt.check(hlib.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch, F,
                                         W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 
@@ -201,7 +223,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -251,7 +273,7 @@ def main():
         out = {
             "metric": "Mrays/sec + ms/frame, 70k-tri OBJ at 1920x1080 1spp; 1/2/4/8 MI355X",
             "value": round(W * H * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": warmup_req, "warmup_frames_done": args.warmup,
+            "n_gpus": world, **({"REHEARSAL_NOT_A_MEASUREMENT": "gloo backend, host-staged gathers"} if rehearsal else {}), "steps": args.steps, "warmup": warmup_req, "warmup_frames_done": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"

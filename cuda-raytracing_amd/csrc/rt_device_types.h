@@ -53,7 +53,8 @@ struct DevMaterial {            // Material.hpp:6-16
     float roughness, metallic;  // read only by the extension kernel (dead in the reference)
 };
 
-constexpr int kMaxBatch = 8;    // frames per launch (rt_render_batch)
+constexpr int kMaxBatch = 32;   // frames per launch (rt_render_batch); 32 x 88 B of per-frame parameters keep the kernel
+                                // arguments under the 4 KB limit
 
 struct FrameParams {            // what differs between the frames of one batched launch
     float kinv[9];
@@ -88,5 +89,7 @@ struct RenderParams {
     // parity planes (tight [height][width], frame coordinates), any may be null
     int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;
 };
+
+static_assert(sizeof(RenderParams) <= 4096, "kernel arguments must fit in 4 KB");
 
 }  // namespace rt

@@ -135,7 +135,7 @@ int rt_render(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t 
 /* `count` (1..RT_MAX_BATCH) frames of the same size in ONE launch: cams[i] is rendered into d_imgs[i].  A frame
  * stream rendered this way keeps the GPU full while the last long rays of one frame finish (the reference's own
  * loop issues two renders before it synchronises, kernel.cu:277-279). */
-#define RT_MAX_BATCH 8
+#define RT_MAX_BATCH 32
 int rt_render_batch(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_imgs, size_t pitch, int32_t count,
                     void *stream, int synchronize);
 /* same frame plus the parity planes */

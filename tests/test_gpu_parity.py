@@ -175,7 +175,13 @@ def test_batched_frames_equal_single_frames(rt, orc, scenes, blob5k):
             assert np.array_equal(b.to_host().reshape(H, W, 3), singles[i]), "batch %d frame %d" % (n, i)
             b.free()
     with pytest.raises(rt.RtError):
-        cam.render_scene_batch(sp, poses + poses[:1], [0] * 9, W * 3)
+        cam.render_scene_batch(sp, poses * 5, [1] * 40, W * 3)              # more than RT_MAX_BATCH (32) frames
+    bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(32)]
+    cam.render_scene_batch(sp, poses * 4, [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)
+    for i in (0, 13, 31):
+        assert np.array_equal(bufs[i].to_host().reshape(H, W, 3), singles[i % 8])
+    for b in bufs:
+        b.free()
 
 
 def test_batched_stripes_layout(rt, scenes, blob5k):
