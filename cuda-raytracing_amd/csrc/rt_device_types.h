@@ -81,7 +81,6 @@ struct RenderParams {
     // stripes: local row ly is frame row ((ly / stripe_rows) * num_ranks + rank) * stripe_rows + ly % stripe_rows
     int32_t local_rows, stripe_rows, rank, num_ranks;
     int32_t tiles_x, tiles_y;   // 16x16-pixel workgroup tiles over width x local_rows
-    const int32_t* tile_list;   // optional explicit workgroup -> tile order
     unsigned long long* trace;  // diagnostics: per-wave {start, end, hw id, tile} stamps, or null
     // extension kernel (rt_render_ex): samples per pixel, specular bounces, sun + shadow pass, optional pops plane
     int32_t spp, bounces, lighting;

@@ -6,7 +6,7 @@
 // Results are bit-identical to the reference arithmetic (see rt_math.h); the memory layout and
 // the execution mapping are not the reference's -- see DESIGN.md.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (mandatory: SURVEY.md H3).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (mandatory: SURVEY.md H3) -fno-slp-vectorize (see _build.py).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -27,11 +27,8 @@ using namespace rt;
 
 namespace {
 
-#ifndef RT_BLOCK
-#define RT_BLOCK 256
-#endif
-constexpr int kBlock = RT_BLOCK;  // 256: 4 waves, one 16x16-pixel tile = 2x2 wave tiles of 8x8 pixels; 64: one 8x8 tile
-constexpr int kTile = kBlock == 256 ? 16 : 8;
+constexpr int kBlock = 256;     // 4 waves: one 16x16-pixel tile = 2x2 wave tiles of 8x8 pixels (64-thread groups measured +-2 %)
+constexpr int kTile = 16;
 
 struct Hit {
     float min;                  // HitInfo::min, raycast.cu:12
@@ -368,10 +365,10 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];                          // [min(stack_depth, kLdsStack)][kBlock]
 
-    // Workgroup b renders tile b (row-major) unless an explicit order is given.  Consecutive workgroups are
-    // dealt round-robin to the 8 XCDs, so every XCD sees tiles from the whole frame: measured faster than giving
-    // each XCD one contiguous band (better load balance; the working set is L1/L2 resident either way).
-    const int tile = p.tile_list ? p.tile_list[blockIdx.x] : (int)blockIdx.x;
+    // Workgroup b renders tile b (row-major).  Consecutive workgroups are dealt round-robin to the 8 XCDs, so every
+    // XCD sees tiles from the whole frame: measured faster than giving each XCD one contiguous band (better load
+    // balance; the working set is L1/L2 resident either way).
+    const int tile = (int)blockIdx.x;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
 
     // a wave64 is an 8x8-pixel block: neighbouring rays walk the same nodes (L1 hits, little divergence)

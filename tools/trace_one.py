@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: render one frame per C2 camera with RT_TRACE_FILE set and dump per-wave lifetimes."""
+"""Diagnostic: render one frame per C2 camera with RT_TRACE_FILE set and print per-wave lifetimes, residency over time and,
+with RT_TRACE_PROF=1 in the environment, per-phase cycle shares of the stamped kernel variant.
+   python tools/trace_one.py <outdir>"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,28 +29,5 @@ for name, pose in scenes.C2_CAMERAS.items():
     edges = np.linspace(0, span, 11)
     conc = [(((st - t0) / 100.0 < b) & ((en - t0) / 100.0 > a)).sum() for a, b in zip(edges[:-1], edges[1:])]
     print("   waves alive per tenth:", conc)
-    # experiment: re-render with tiles ordered by measured block duration (longest first)
-    blk = t[:, 3].astype(np.int64); nb = int(blk.max()) + 1
-    bd = np.zeros(nb); np.maximum.at(bd, blk, dur)
-    order = np.argsort(-bd, kind="stable").astype(np.int32)
-    lf = os.path.join(out, "order_%s.bin" % name); order.tofile(lf)
-    tm = rt.Timer()
-    def timeit(n=50):
-        for _ in range(3): cam.render_scene(scene, img.ptr, img.pitch)
-        tm.start()
-        for _ in range(n): cam.render_scene(scene, img.ptr, img.pitch)
-        tm.stop(); return tm.elapsed_ms() / n
-    base = timeit()
-    os.environ["RT_TILE_LIST"] = lf
-    srt = timeit()
-    del os.environ["RT_TILE_LIST"]
-    print("   kernel ms: natural order %.4f, heavy-first order %.4f" % (base, srt))
-    if t[:, 8].max() > 0:
-        heavy = np.argsort(dur)[-5:]
-        for w in heavy:
-            cp, cm, ci, cl, nit, nint, nleaf = [int(v) for v in t[w, 4:11]]
-            print("   heavy wave: dur %.1f us iters %d (int %d leaf %d) cycles: pop %d mem %d int %d leaf %d  per-iter %.0f" % (dur[w], nit, nint, nleaf, cp, cm, ci, cl, (cp+cm+ci+cl)/max(nit,1)))
-        tot = t[:, 4:11].astype(np.float64).sum(0)
-        print("   all waves: iters %.3g int %.3g leaf %.3g; cycle shares pop %.2f mem %.2f int %.2f leaf %.2f; cyc/iter %.0f" % (tot[4], tot[5], tot[6], *(tot[:4]/tot[:4].sum()), tot[:4].sum()/tot[4]))
     late = np.argsort(en)[-5:]
     print("   last finishers: start %s end %s dur %s tile %s" % (((st[late]-t0)/100.0).round(1), ((en[late]-t0)/100.0).round(1), dur[late].round(1), t[late,3]))
