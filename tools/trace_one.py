@@ -29,5 +29,13 @@ for name, pose in scenes.C2_CAMERAS.items():
     edges = np.linspace(0, span, 11)
     conc = [(((st - t0) / 100.0 < b) & ((en - t0) / 100.0 > a)).sum() for a, b in zip(edges[:-1], edges[1:])]
     print("   waves alive per tenth:", conc)
+    if t[:, 8].max() > 0:                                     # RT_TRACE_PROF=1: per-phase cycle stamps of the diagnostic kernel
+        for w in np.argsort(dur)[-3:]:
+            cp, cm, ci, cl, nit, nint, nleaf = [int(v) for v in t[w, 4:11]]
+            print("   heavy wave: dur %.1f us iters %d (with interior lanes %d, with leaf lanes %d) cycles: pop %d fetch %d interior %d leaf %d  per-iter %.0f"
+                  % (dur[w], nit, nint, nleaf, cp, cm, ci, cl, (cp + cm + ci + cl) / max(nit, 1)))
+        tot = t[:, 4:11].astype(np.float64).sum(0)
+        print("   all waves: iters %.3g (interior %.3g, leaf %.3g); cycle shares pop %.2f fetch %.2f interior %.2f leaf %.2f; cycles/iter %.0f"
+              % (tot[4], tot[5], tot[6], *(tot[:4] / tot[:4].sum()), tot[:4].sum() / tot[4]))
     late = np.argsort(en)[-5:]
     print("   last finishers: start %s end %s dur %s tile %s" % (((st[late]-t0)/100.0).round(1), ((en[late]-t0)/100.0).round(1), dur[late].round(1), t[late,3]))
