@@ -459,3 +459,42 @@ def test_8k_frame_bands(rt, orc, scenes, blob70k):
     rt.check(h.rt_unstripe(gathered.ptr, pitch, max_rows * pitch, out.ptr, out.pitch, W, H, stripe, world, None))
     rt.check(h.rt_device_synchronize())
     assert np.array_equal(out.to_host().reshape(H, W, 3), dbg["img"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_random_scenes(rt, orc, scenes, blob5k, seed):
+    """Differential fuzzing: random soups / blob instances with random poses, non-uniform scales, random materials
+    (albedo or texture), random cameras and odd frame sizes; all six parity planes and RGB against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n_mesh = int(rng.integers(1, 4))
+    meshes, materials, instances = [], [], []
+    for _ in range(n_mesh):
+        if rng.random() < 0.35:
+            meshes.append(("obj", blob5k))
+        else:
+            meshes.append(("tris", sd.random_triangles(int(rng.integers(1, 400)), seed=int(rng.integers(1 << 30)),
+                                                       spread=float(rng.uniform(0.3, 1.5)), size=float(rng.uniform(0.05, 0.6)))))
+    for _ in range(int(rng.integers(1, 4))):
+        tex = sd.checker_texture(int(rng.integers(2, 70)), int(rng.integers(2, 50)), seed=int(rng.integers(1 << 30))) if rng.random() < 0.5 else None
+        materials.append((tuple(rng.uniform(0, 1, 3)), tex))
+    for _ in range(int(rng.integers(1, 6))):
+        pose = tuple(np.concatenate([rng.uniform(-1.5, 1.5, 3), rng.uniform(-3.1, 3.1, 3)]))
+        scale = tuple(rng.uniform(0.3, 1.8, 3)) if rng.random() < 0.7 else (1.0, 1.0, 1.0)
+        instances.append((int(rng.integers(n_mesh)), int(rng.integers(len(materials))), pose, scale))
+    W, H = int(rng.integers(20, 200)), int(rng.integers(20, 140))
+    cam_pose = tuple(np.concatenate([rng.uniform(-1, 1, 1), rng.uniform(-5, -2, 1), rng.uniform(-1, 1, 1), rng.uniform(-0.4, 0.4, 3)]))
+    _compare(rt, orc, sd.SceneDesc(materials, meshes, instances), W, H, scenes.scaled_K(W), scenes.D_REF, cam_pose)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_extension_modes(rt, orc, scenes, blob5k, seed):
+    """Random spp / bounces / lighting, random metallic / roughness, rotated and scaled instances: extension kernel vs oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    mats = [(tuple(rng.uniform(0.1, 1, 3)), sd.checker_texture(16, 12, seed=seed) if rng.random() < 0.5 else None,
+             dict(roughness=float(rng.choice([0.0, 0.05, 0.3])), metallic=float(rng.choice([0.0, 0.3, 0.8])))) for _ in range(3)]
+    meshes = [("obj", blob5k), ("tris", sd.random_triangles(120, seed=40 + seed, spread=1.2, size=0.5))]
+    inst = [(int(rng.integers(2)), int(rng.integers(3)), tuple(np.concatenate([rng.uniform(-1.2, 1.2, 3), rng.uniform(-1, 1, 3)])),
+             tuple(rng.uniform(0.5, 1.4, 3))) for _ in range(3)]
+    W, H = 96, 64
+    _compare_ex(rt, orc, sd.SceneDesc(mats, meshes, inst), W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02),
+                int(rng.integers(1, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 2)))
