@@ -7,8 +7,7 @@ casts exactly one ray per pixel: raycast.cu:204), scene resident in HBM before t
 
   python bench.py [--gpus N --steps K --warmup W] [--camera far|mid|near] [--no-cpu-baseline]
 
-Frames are issued in groups of F (default: up to 8 per GPU-share of a frame, i.e. 8 / 16 / 32 / 32 for 1 / 2 / 4 / 8 GPUs,
-reduced to a divisor of K) through Camera::render_scene_batch /
+Frames are issued in groups of F (default: the largest divisor of K that is <= 32, e.g. 25 for K = 200) through Camera::render_scene_batch /
 rt_render_batch: one launch renders F complete frames into F buffers, so the last long rays of one frame
 overlap the bulk of the next (the reference's own loop issues two renders per synchronise,
 kernel.cu:277-279).  K steps = K frames = K/F launches; F = 1 gives one launch per frame.
@@ -100,7 +99,7 @@ def main():
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
     ap.add_argument("--width", type=int, default=scenes.C2["width"])
     ap.add_argument("--height", type=int, default=scenes.C2["height"])
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = 8 per GPU-share: 8, 16, 32, 32 for 1, 2, 4, 8 GPUs")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = as many as one launch takes (32), reduced to a divisor of --steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 logic with host-staged gathers (several ranks may share one GPU); never for numbers")
@@ -150,9 +149,10 @@ def main():
     cam.set_stream(stream)
 
     import math
-    # A launch should carry several frames' worth of work for THIS GPU (a rank renders 1/N of each frame), so the
-    # group grows with N; F is then the largest divisor of K not above it: K frames in exactly K / F launches.
-    f_max = args.frames_per_launch if args.frames_per_launch > 0 else 8 * min(world, 4)
+    # A launch should carry several frames' worth of work for THIS GPU (with N GPUs a rank renders only 1/N of each
+    # frame), so groups are as large as one launch allows (RT_MAX_BATCH = 32); F is the largest divisor of K not above
+    # that: K frames in exactly K / F launches.
+    f_max = args.frames_per_launch if args.frames_per_launch > 0 else 32
     f_max = max(1, min(f_max, 32))
     F = max(d for d in range(1, f_max + 1) if args.steps % d == 0) if args.steps > 0 else f_max
     warmup_req = args.warmup

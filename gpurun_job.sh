@@ -1,2 +1,2 @@
-cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+rm -rf gpurun_out/prof_v6
+bash tools/profile_bench.sh gpurun_out/prof_v6 | tail -1 | cut -c1-100
