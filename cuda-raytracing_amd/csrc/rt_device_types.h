@@ -29,7 +29,7 @@ constexpr int kMaxStack = 64;
 //   t3 = dot00 dot01 dot11 invDenom   (TrianglePrimitive.hpp:158-164: ray-independent, so
 //                                      precomputed on the host with the same fp32 operations)
 
-struct DevInstance {            // 128 B
+struct DevInstance {            // 144 B
     Q4 q_rot;                   // euler2quat(rotation)          raycast.cu:33
     Q4 q_pose;                  // euler2quat(pose ypr)          raycast.cu:40
     Q4 q_inv_pose;              // euler2quat(inv_pose ypr)      raycast.cu:102
@@ -42,6 +42,8 @@ struct DevInstance {            // 128 B
     int32_t material_index;
     int32_t mesh_index;
     int32_t exact_uv;           // mesh has uv values that could make uv.x == FLT_MAX (raycast.cu:96)
+    int32_t identity_inv;       // scale == 1, inv_pose == 0, q_inv_pose == (1,0,0,0): mesh -> world is the identity
+    int32_t pad_[3];
 };
 
 struct DevMaterial {            // Material.hpp:6-16

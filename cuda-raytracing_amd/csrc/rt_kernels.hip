@@ -191,9 +191,15 @@ __device__ __forceinline__ void triangle_step(const RenderParams& p, const DevIn
         }
         if (ok) {
             if constexpr (DEBUG) cnt.inside++;
-            // raycast.cu:98-104
-            V3 loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
-            loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
+            // raycast.cu:98-104.  For an instance whose mesh -> world transform is exactly the identity (scale 1,
+            // translation 0, quaternion (1,0,0,0): the common case) the scale / translate / rotate sequence returns
+            // pt itself up to the sign of zero components, which the squares in magnitude() cannot see -- so the
+            // production kernel skips it.  (The extension kernel keeps it: it stores `loc`.)
+            V3 loc = pt;
+            if (EX || !in.identity_inv) {
+                loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
+                loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
+            }
             float distance = magnitude(loc - org);
             // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
             const bool accept = denom < 0 && (hit.min == FLT_MAX || distance < hit.min);
@@ -545,6 +551,9 @@ DevInstance make_dev_instance(const RtInstanceDesc& d, const RtScene& s)
         o.pose_xyz[k] = d.pose[k]; o.inv_pose_xyz[k] = d.inv_pose[k];
         o.scale[k] = d.scale[k]; o.inv_scale[k] = d.inv_scale[k];
     }
+    o.identity_inv = 1;
+    for (int k = 0; k < 3; k++) if (!(d.scale[k] == 1.0f && d.inv_pose[k] == 0.0f)) o.identity_inv = 0;
+    if (!(o.q_inv_pose.x == 1.0f && o.q_inv_pose.y == 0.0f && o.q_inv_pose.z == 0.0f && o.q_inv_pose.w == 0.0f)) o.identity_inv = 0;
     o.root_ref = s.mesh_root_ref[d.mesh_index];
     o.exact_uv = s.mesh_exact_uv[d.mesh_index];
     o.material_index = d.material_index;
