@@ -89,17 +89,36 @@ __global__ void init_level_kernel(BuildNode* nodes, Bins* bins, int level_begin,
         }
 }
 
-// BVHTree.hpp:206-209: grow the node's box over its triangles
+__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+
+// BVHTree.hpp:206-209: grow the node's box over its triangles.  Near the root every lane of a wave belongs to the same
+// node (ranges are contiguous), so the wave reduces first and issues 6 atomics instead of 384 on one address.
 __global__ void bounds_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
                               const float* __restrict__ tbox, BuildNode* nodes, int level_begin)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const int k = node_of[p];
-    if (k < level_begin) return;                                 // its node was finished on an earlier level
-    const float* tb = tbox + 6 * (size_t)order[p];
-    BuildNode& nd = nodes[k];
-    for (int c = 0; c < 3; c++) { atomic_min_f(&nd.mn[c], tb[c]); atomic_max_f(&nd.mx[c], tb[3 + c]); }
+    int k = p < n ? node_of[p] : -1;
+    const bool valid = k >= level_begin;                         // else: past the end, or its node was finished earlier
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0) return;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (valid) {
+        const float* tb = tbox + 6 * (size_t)order[p];
+        for (int c = 0; c < 3; c++) { lo[c] = tb[c]; hi[c] = tb[3 + c]; }
+    }
+    const int first = __ffsll((long long)vm) - 1;
+    const int k0 = __shfl(k, first);
+    if (__ballot(valid && k != k0) == 0) {                       // one node for the whole wave
+        for (int c = 0; c < 3; c++) { lo[c] = wave_min(lo[c]); hi[c] = wave_max(hi[c]); }
+        if ((int)(threadIdx.x & 63) == first) {
+            BuildNode& nd = nodes[k0];
+            for (int c = 0; c < 3; c++) { atomic_min_f(&nd.mn[c], lo[c]); atomic_max_f(&nd.mx[c], hi[c]); }
+        }
+    } else if (valid) {
+        BuildNode& nd = nodes[k];
+        for (int c = 0; c < 3; c++) { atomic_min_f(&nd.mn[c], lo[c]); atomic_max_f(&nd.mx[c], hi[c]); }
+    }
 }
 
 __device__ __forceinline__ float plane_pos(float mn, float mx, int s)
@@ -108,26 +127,51 @@ __device__ __forceinline__ float plane_pos(float mn, float mx, int s)
     return mn + (mx - mn) * (split_t);                           // BVHTree.hpp:318
 }
 
-// evaluate_split's partition (BVHTree.hpp:324-348), binned: bin = number of planes the centroid lies beyond
+// evaluate_split's partition (BVHTree.hpp:324-348), binned: bin = number of planes the centroid lies beyond.
+// Same wave-level pre-reduction as bounds_kernel when the whole wave works on one node.
 __global__ void bins_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
                             const float* __restrict__ centroid, const float* __restrict__ tbox,
                             const BuildNode* __restrict__ nodes, Bins* bins, int level_begin, int max_depth)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const int k = node_of[p];
-    if (k < level_begin) return;
-    const BuildNode& nd = nodes[k];
-    if (nd.depth >= max_depth || nd.count <= 1) return;          // BVHTree.hpp:211-215: no split evaluated
-    const int t = order[p];
-    const float* tb = tbox + 6 * (size_t)t;
-    Bins& b = bins[k - level_begin];
+    int k = p < n ? node_of[p] : -1;
+    bool valid = k >= level_begin;
+    if (valid) {
+        const BuildNode& nd = nodes[k];
+        valid = !(nd.depth >= max_depth || nd.count <= 1);       // BVHTree.hpp:211-215: no split evaluated
+    }
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0) return;
+    const int first = __ffsll((long long)vm) - 1;
+    const int k0 = __shfl(k, first);
+    const bool uniform = __ballot(valid && k != k0) == 0;
+    const int t = valid ? order[p] : 0;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (valid) { const float* tb = tbox + 6 * (size_t)t; for (int q = 0; q < 3; q++) { lo[q] = tb[q]; hi[q] = tb[3 + q]; } }
+    const BuildNode& nd = nodes[valid ? k : k0];
+    Bins& b = bins[(valid ? k : k0) - level_begin];
     for (int a = 0; a < 3; a++) {
-        const float c = centroid[3 * (size_t)t + a];
         int s = 0;
-        while (s < 5 && !(c <= plane_pos(nd.mn[a], nd.mx[a], s))) s++;
-        for (int q = 0; q < 3; q++) { atomic_min_f(&b.mn[a][s][q], tb[q]); atomic_max_f(&b.mx[a][s][q], tb[3 + q]); }
-        atomicAdd(&b.cnt[a][s], 1);
+        if (valid) {
+            const float c = centroid[3 * (size_t)t + a];
+            while (s < 5 && !(c <= plane_pos(nd.mn[a], nd.mx[a], s))) s++;
+        }
+        if (uniform) {
+            for (int bin = 0; bin < 6; bin++) {
+                const unsigned long long m = __ballot(valid && s == bin);
+                if (m == 0) continue;
+                const bool mine = valid && s == bin;
+                float rl[3], rh[3];
+                for (int q = 0; q < 3; q++) { rl[q] = wave_min(mine ? lo[q] : FLT_MAX); rh[q] = wave_max(mine ? hi[q] : -FLT_MAX); }
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+                    for (int q = 0; q < 3; q++) { atomic_min_f(&b.mn[a][bin][q], rl[q]); atomic_max_f(&b.mx[a][bin][q], rh[q]); }
+                    atomicAdd(&b.cnt[a][bin], __popcll(m));
+                }
+            }
+        } else if (valid) {
+            for (int q = 0; q < 3; q++) { atomic_min_f(&b.mn[a][s][q], lo[q]); atomic_max_f(&b.mx[a][s][q], hi[q]); }
+            atomicAdd(&b.cnt[a][s], 1);
+        }
     }
 }
 
