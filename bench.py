@@ -7,7 +7,7 @@ casts exactly one ray per pixel: raycast.cu:204), scene resident in HBM before t
 
   python bench.py [--gpus N --steps K --warmup W] [--camera far|mid|near] [--no-cpu-baseline]
 
-Frames are issued in groups of F (default: the largest divisor of K that is <= 32, e.g. 25 for K = 200) through Camera::render_scene_batch /
+Frames are issued in groups of F = min(32, K) (K // F full groups plus one shorter last group) through Camera::render_scene_batch /
 rt_render_batch: one launch renders F complete frames into F buffers, so the last long rays of one frame
 overlap the bulk of the next (the reference's own loop issues two renders per synchronise,
 kernel.cu:277-279).  K steps = K frames = K/F launches; F = 1 gives one launch per frame.
@@ -148,20 +148,18 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     cam.set_stream(stream)
 
-    import math
     # A launch should carry several frames' worth of work for THIS GPU (with N GPUs a rank renders only 1/N of each
-    # frame), so groups are as large as one launch allows (RT_MAX_BATCH = 32); F is the largest divisor of K not above
-    # that: K frames in exactly K / F launches.
+    # frame), so frames go in groups as large as one launch allows (RT_MAX_BATCH = 32): K frames = K // F full groups
+    # plus one last group of K % F frames.
     f_max = args.frames_per_launch if args.frames_per_launch > 0 else 32
-    f_max = max(1, min(f_max, 32))
-    F = max(d for d in range(1, f_max + 1) if args.steps % d == 0) if args.steps > 0 else f_max
+    F = max(1, min(f_max, 32, args.steps if args.steps > 0 else 1))
+    groups = [F] * (args.steps // F) + ([args.steps % F] if args.steps % F else [])
     warmup_req = args.warmup
-    if args.warmup % F:
-        args.warmup += F - args.warmup % F                       # whole groups: at least the requested warm-up
+    warm_groups = [F] * ((args.warmup + F - 1) // F)             # whole groups: at least the requested warm-up
+    args.warmup = len(warm_groups) * F
     pitch = W * 3
     frames = torch.empty((F, H, pitch), dtype=torch.uint8, device=dev)      # rank 0: the finished frames of one group
     hlib = rt.libs()[0]
-    poses = [pose] * F
     if world > 1:
         rows = []
         for r in range(world):
@@ -184,12 +182,14 @@ def main():
     dev_gathered = (gathered_dev if rehearsal else gathered) if world > 1 else None
     local_ptrs = [tiling.batch_local_ptrs(dev_local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if world > 1 else None
 
-    render_group_single = cam.prepared_batch(scene, poses, frame_ptrs, pitch)
-    render_local_calls = [cam.prepared_batch(scene, poses, local_ptrs[b], pitch, stripes=(STRIPE_ROWS, rank, world))
-                          for b in range(2)] if world > 1 else None
+    counts = sorted(set(groups + [F]))                           # a full group and, possibly, the shorter last one
+    render_single_calls = {c: cam.prepared_batch(scene, [pose] * c, frame_ptrs[:c], pitch) for c in counts}
+    render_local_calls = {(b, c): cam.prepared_batch(scene, [pose] * c, local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
+                          for b in range(2) for c in counts} if world > 1 else None
+    group_count = [F, F]                                         # frames in the group that currently occupies buffer b
 
     def render_local(b):
-        render_local_calls[b]()
+        render_local_calls[(b, group_count[b])]()
         if rehearsal:
             local[b].copy_(dev_local[b])
 
@@ -197,15 +197,17 @@ def main():
         if rehearsal:
             dev_gathered[b].copy_(gathered[b])
         src, rank_stride = tiling.batch_unstripe_args(dev_gathered[b].data_ptr(), 0, F, max_rows, pitch)
-        rt.check(hlib.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch, F,
+        rt.check(hlib.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch, group_count[b],
                                         W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 
     pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe) if world > 1 else None
 
-    def step_group(i):
+    def step_group(i, count):
         if world == 1:
-            render_group_single()
+            render_single_calls[count]()
         else:
+            pipe._finish(i & 1)                                  # buffer i & 1 is about to be reused: its count changes below
+            group_count[i & 1] = count
             pipe.step(i)
 
     def sync():
@@ -214,12 +216,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup // F):
-        step_group(i)
+    for i, c in enumerate(warm_groups):
+        step_group(i, c)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps // F):
-        step_group(i)
+    for i, c in enumerate(groups):
+        step_group(i, c)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -230,12 +232,13 @@ def main():
     # ---- kernel-only duration with hipEvents on the launch stream (roofline numerator) ----
     kernel_ms = None
     if rank == 0:
-        n = max(10, min(args.steps // F, 100))
+        n = max(10, min(len(groups), 100))
+        group_count[0] = F
         torch.cuda.synchronize()
         timer.start(stream)
         for _ in range(n):
             if world == 1:
-                render_group_single()
+                render_single_calls[F]()
             else:
                 render_local(0)
         timer.stop(stream)
@@ -258,8 +261,9 @@ def main():
         dbg = rt.render_debug(scene, cam)
         st = {"rays": W * H, "pops": int(dbg["pops"].sum()), "aabb": int(dbg["aabb"].sum()), "tris": int(dbg["tris"].sum()),
               "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
+        last = groups[-1] if groups else F                   # the last group wrote this many frames
         frames_host = frames.cpu().numpy().reshape(F, H, W, 3)
-        frame_ok = bool(all(np.array_equal(frames_host[f], dbg["img"]) for f in range(F)))
+        frame_ok = bool(all(np.array_equal(frames_host[f], dbg["img"]) for f in range(last)))
         alg_bytes = algorithmic_bytes(st)                   # per frame
         share = F / world                                   # one launch = F frames; rank 0's stripes ~ 1/N of each
         achieved = alg_bytes * share / (kernel_ms * 1e-3) / 1e9
