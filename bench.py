@@ -48,16 +48,21 @@ def algorithmic_bytes(st):
     return 24 * st["aabb"] + 8 * interior + 8 * leaf + 52 * st["tris"] + 24 * st["inside"] + 3 * st["rays"]
 
 
-def scene_path():
+def scene_path(workload="c2"):
     d = os.path.join(ROOT, ".scene_cache")
     os.makedirs(d, exist_ok=True)
+    if workload == "c4":
+        p = os.path.join(d, "atrium.obj")
+        if not os.path.exists(p):
+            scenes.write_atrium_obj(p)
+        return p
     p = os.path.join(d, "blob70k.obj")
     if not os.path.exists(p):
         scenes.write_blob_obj(p, *scenes.blob_dims_for(scenes.C2["n_tris"]))
     return p
 
 
-def cpu_baseline(obj, W, H, K, D, pose, gpu_stats):
+def cpu_baseline(obj, W, H, K, D, pose, gpu_stats, albedo):
     """The oracle (oracle/rt_oracle.c, kind "port") timed on this host: one full frame of the same
     workload, single-threaded and on all cores (row bands).  Also cross-checks the GPU's counters."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -66,7 +71,7 @@ def cpu_baseline(obj, W, H, K, D, pose, gpu_stats):
     o = orc.oracle()
     m = o.obj_load(obj)
     s = orc.OracleScene(o)
-    s.add_material(scenes.C2["albedo"])
+    s.add_material(albedo)
     s.add_mesh(m)
     s.add_instance(0, 0)
     rows1 = max(8, H // 8)                                 # 1/8 of the frame, centred, single thread
@@ -96,9 +101,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
+                    help="c2 = the metric's workload (70k-triangle blob, 1920x1080); c4 = BASELINE configs[3] scene (260k-triangle atrium, 3840x2160)")
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
-    ap.add_argument("--width", type=int, default=scenes.C2["width"])
-    ap.add_argument("--height", type=int, default=scenes.C2["height"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = as many as one launch takes (32), reduced to a divisor of --steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-backend", default="nccl", choices=["nccl", "gloo"],
@@ -129,17 +136,19 @@ def main():
 
     rt.build()
     rt.libs()
-    W, H = args.width, args.height
-    K, D, pose = scenes.scaled_K(W), scenes.D_REF, scenes.C2_CAMERAS[args.camera]
-    obj = scene_path() if rank == 0 else None
+    wl = scenes.C4 if args.workload == "c4" else scenes.C2
+    W, H = args.width or wl["width"], args.height or wl["height"]
+    K, D = scenes.scaled_K(W), scenes.D_REF
+    pose = scenes.C4["cam_pose"] if args.workload == "c4" else scenes.C2_CAMERAS[args.camera]
+    obj = scene_path(args.workload) if rank == 0 else None
     if world > 1:
         dist.barrier()
-        obj = scene_path()
+        obj = scene_path(args.workload)
 
     # ---- scene: the reference's call sequence (kernel.cu:166-243) through the host C++ API ----
     mesh = rt.Mesh.load_obj(obj)
     scene = rt.Scene()
-    scene.add_material(scenes.C2["albedo"])
+    scene.add_material(wl["albedo"])
     scene.add_mesh(mesh)
     scene.add_mesh_instance(0, 0)
     scene.upload_to_device()
@@ -271,7 +280,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("%s_%dx%d_f%d" % (args.camera, W, H, F), {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tp)).get("%s_%dx%d_f%d" % (args.camera if args.workload == "c2" else args.workload, W, H, F), {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -280,8 +289,11 @@ def main():
             "n_gpus": world, **({"REHEARSAL_NOT_A_MEASUREMENT": "gloo backend, host-staged gathers"} if rehearsal else {}), "steps": args.steps, "warmup": warmup_req, "warmup_frames_done": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"
-                                   % (W, H, args.camera, str(tuple(pose[:3]))),
+            "config": {"workload": ("C4 Sponza-class atrium OBJ (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera inside %s"
+                                    % (mesh.num_triangles, mesh.num_nodes, W, H, str(tuple(pose[:3]))))
+                                   if args.workload == "c4" else
+                                   ("C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"
+                                    % (W, H, args.camera, str(tuple(pose[:3])))),
                        "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
                                       % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per %d frames" % F if world > 1 else ""),
                        "frames_per_launch": F, "single_frame_launch_ms": None if single_ms is None else round(single_ms, 4),
@@ -295,7 +307,7 @@ def main():
             "frame_matches_debug_kernel": frame_ok,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(obj, W, H, K, D, pose, st)
+            out["cpu_baseline"] = cpu_baseline(obj, W, H, K, D, pose, st, wl["albedo"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
