@@ -86,6 +86,9 @@ struct RenderParams {
     unsigned long long* trace;  // diagnostics: per-wave {start, end, hw id, tile} stamps, or null
     // extension kernel (rt_render_ex): samples per pixel, specular bounces, sun + shadow pass, optional pops plane
     int32_t spp, bounces, lighting;
+    int32_t sample_base;        // this launch renders sample indices sample_base + blockIdx.y
+    float4* ex_samples;         // [chunk][local_rows * width] radiance xyz + node pops (int bits) of one sample
+    float4* ex_acc;             // [local_rows * width] running sums between chunks
     int32_t* total_pops;
     // parity planes (tight [height][width], frame coordinates), any may be null
     int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;

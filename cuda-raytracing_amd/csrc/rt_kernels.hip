@@ -424,7 +424,12 @@ __device__ __forceinline__ V3 hit_normal(const RenderParams& p, const Hit& hit)
     return normalize(n);
 }
 
-__global__ __launch_bounds__(kBlock) void render_ex_kernel(const RenderParams p)
+// One workgroup = one 16x16 tile of ONE sample index (blockIdx.y): every (pixel, sample) pair has its own random
+// stream, so the samples of a pixel are independent work items and a frame of spp samples is dispatched like a batch
+// of spp frames.  (A pixel's samples used to run as a loop inside its lane: the waves on the silhouette then lived
+// 64 x as long as their neighbours and the kernel spent most of its time waiting for a handful of them.)
+// The sample's radiance and node pops go to ex_samples[sample][local pixel]; resolve_ex_kernel sums them in order.
+__global__ __launch_bounds__(kBlock, 6) void render_ex_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];
     const FrameParams& f = p.frames[0];
@@ -435,62 +440,91 @@ __global__ __launch_bounds__(kBlock) void render_ex_kernel(const RenderParams p)
     const int ly = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     if (x >= p.width || ly >= p.local_rows) return;
     const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;   // stripes: local -> frame row
+    const int s = p.sample_base + (int)blockIdx.y;
+    unsigned long long t_start = 0;
+    if (p.trace) t_start = wall_clock64();
 
     int spill[kMaxStack - kLdsStack];
     Stack stack;
     stack.lds = (lds_int*)lds_stack + tid; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
     Counters<true> cnt;
 
+    // stream of (pixel, sample): the reference's per-pixel seed (raycast.cu:190: int idx * 1000) plus the sample index
     Xorwow rng;
-    xorwow_init(rng, (unsigned long long)(long long)(int32_t)((uint32_t)(y * p.width + x) * 1000u));     // raycast.cu:190
+    xorwow_init(rng, (unsigned long long)((long long)(int32_t)((uint32_t)(y * p.width + x) * 1000u) + (long long)s));
     const V3 sun = normalize(v3(-0.2f, 0.0f, 1.0f));                                                    // raycast.cu:249-250
-    V3 acc = v3(0.0f, 0.0f, 0.0f);
-    for (int s = 0; s < p.spp; s++) {
-        float px = (float)x, py = (float)y;
-        if (s > 0) { px = px + (xorwow_uniform(rng) - 0.5f); py = py + (xorwow_uniform(rng) - 0.5f); }
-        V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
-        V3 dir = camera_direction(f, px, py);
-        V3 weight = v3(1.0f, 1.0f, 1.0f), sample = v3(0.0f, 0.0f, 0.0f);
-        for (int depth = 0; depth <= p.bounces; depth++) {
-            const Hit hit = cast_ray_ex(p, org, dir, stack, cnt);
-            if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); break; }
-            const V3 base = base_colour(p, hit);
-            const V3 n = hit_normal(p, hit);
-            float illum = 1.0f;
-            if (p.lighting) {                                   // raycast.cu:249-287 with the commented lines active
-                const float cos_illum = dot(n, sun);
-                illum = (float)(0.4 * (double)cos_illum);
-                if (dot(n, sun) > 0) {
-                    const Hit sh = cast_ray_ex(p, hit.loc + sun * (float)1e-4, sun, stack, cnt);
-                    if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);
-                }
+    float px = (float)x, py = (float)y;
+    if (s > 0) { px = px + (xorwow_uniform(rng) - 0.5f); py = py + (xorwow_uniform(rng) - 0.5f); }
+    V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
+    V3 dir = camera_direction(f, px, py);
+    V3 weight = v3(1.0f, 1.0f, 1.0f), sample = v3(0.0f, 0.0f, 0.0f);
+    for (int depth = 0; depth <= p.bounces; depth++) {
+        const Hit hit = cast_ray_ex(p, org, dir, stack, cnt);
+        if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); break; }
+        const V3 base = base_colour(p, hit);
+        const V3 n = hit_normal(p, hit);
+        float illum = 1.0f;
+        if (p.lighting) {                                   // raycast.cu:249-287 with the commented lines active
+            const float cos_illum = dot(n, sun);
+            illum = (float)(0.4 * (double)cos_illum);
+            if (dot(n, sun) > 0) {
+                const Hit sh = cast_ray_ex(p, hit.loc + sun * (float)1e-4, sun, stack, cnt);
+                if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);
             }
-            illum = fminf(1.0f, illum);                         // raycast.cu:289-290
-            illum = fmaxf(0.4f, illum);
-            const V3 local = v3(illum * base.x, illum * base.y, illum * base.z);
-            const DevMaterial& mat = p.materials[p.instances[hit.instance].material_index];
-            const float m = depth < p.bounces ? mat.metallic : 0.0f;
-            sample = sample + weight * (local * (1.0f - m));
-            if (!(m > 0.0f)) break;
-            weight = weight * (base * m);
-            const float k = 2.0f * dot(dir, n);
-            V3 r = dir - n * k;
-            if (mat.roughness > 0.0f) {
-                float rx = 2.0f * xorwow_uniform(rng) - 1.0f, ry = 2.0f * xorwow_uniform(rng) - 1.0f, rz = 2.0f * xorwow_uniform(rng) - 1.0f;
-                r = r + v3(rx, ry, rz) * mat.roughness;
-            }
-            r = normalize(r);
-            org = hit.loc + r * (float)1e-4;
-            dir = r;
         }
-        acc = acc + sample;
+        illum = fminf(1.0f, illum);                         // raycast.cu:289-290
+        illum = fmaxf(0.4f, illum);
+        const V3 local = v3(illum * base.x, illum * base.y, illum * base.z);
+        const DevMaterial& mat = p.materials[p.instances[hit.instance].material_index];
+        const float m = depth < p.bounces ? mat.metallic : 0.0f;
+        sample = sample + weight * (local * (1.0f - m));
+        if (!(m > 0.0f)) break;
+        weight = weight * (base * m);
+        const float k = 2.0f * dot(dir, n);
+        V3 r = dir - n * k;
+        if (mat.roughness > 0.0f) {
+            float rx = 2.0f * xorwow_uniform(rng) - 1.0f, ry = 2.0f * xorwow_uniform(rng) - 1.0f, rz = 2.0f * xorwow_uniform(rng) - 1.0f;
+            r = r + v3(rx, ry, rz) * mat.roughness;
+        }
+        r = normalize(r);
+        org = hit.loc + r * (float)1e-4;
+        dir = r;
     }
+    p.ex_samples[(size_t)blockIdx.y * ((size_t)p.local_rows * p.width) + (size_t)ly * p.width + x] =
+        make_float4(sample.x, sample.y, sample.z, __int_as_float(cnt.pops));
+    if (p.trace) {                                              // diagnostic: per-wave lifetime (RT_TRACE_FILE)
+        const unsigned long long active = __ballot(true);
+        if (lane == __ffsll((long long)active) - 1) {
+            unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave) * 16;
+            t[0] = t_start; t[1] = wall_clock64(); t[3] = (unsigned long long)tile;
+        }
+    }
+}
+
+// pixel = u8(sum of its samples in index order / spp * 255); a frame with many samples arrives in several chunks of
+// `count` samples, the running sum (and node-pop total) waits in ex_acc in between.
+__global__ void resolve_ex_kernel(const RenderParams p, int count, int first, int last)
+{
+    const size_t npix = (size_t)p.local_rows * p.width;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    V3 acc = v3(0.0f, 0.0f, 0.0f);
+    int pops = 0;
+    if (!first) { const float4 a = p.ex_acc[i]; acc = v3(a.x, a.y, a.z); pops = __float_as_int(a.w); }
+    for (int k = 0; k < count; k++) {
+        const float4 q = p.ex_samples[(size_t)k * npix + i];
+        acc = acc + v3(q.x, q.y, q.z);
+        pops += __float_as_int(q.w);
+    }
+    if (!last) { p.ex_acc[i] = make_float4(acc.x, acc.y, acc.z, __int_as_float(pops)); return; }
+    const int ly = (int)(i / p.width), x = (int)(i % p.width);
+    const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
     const float nspp = (float)p.spp;
-    uint8_t* out = f.img + (size_t)ly * p.pitch + 3 * (size_t)x;
+    uint8_t* out = p.frames[0].img + (size_t)ly * p.pitch + 3 * (size_t)x;
     out[0] = to_u8(acc.x / nspp * 255.0f);
     out[1] = to_u8(acc.y / nspp * 255.0f);
     out[2] = to_u8(acc.z / nspp * 255.0f);
-    if (p.total_pops) p.total_pops[(size_t)y * p.width + x] = cnt.pops;
+    if (p.total_pops) p.total_pops[(size_t)y * p.width + x] = pops;
 }
 
 // rows of a rank-major gathered buffer back into frame order (rt_unstripe)
@@ -531,6 +565,8 @@ struct RtScene {
     int32_t num_materials = 0;
     int32_t max_stack = 1;
     size_t device_bytes = 0;
+    float4* d_ex_scratch = nullptr;              // extension renders: running sums + one chunk of samples (grow-only)
+    size_t ex_scratch_bytes = 0;
 };
 
 struct RtTimer { hipEvent_t start, stop; };
@@ -608,6 +644,24 @@ int fill_params(RenderParams& p, const RtScene* s, const RtCameraParams* cams, u
     return RT_OK;
 }
 
+// RT_TRACE_FILE diagnostics: a zeroed [waves][16] u64 buffer for the kernel's stamps, written to the file afterwards
+hipError_t trace_begin(RenderParams& p, size_t n)
+{
+    hipError_t e = hipMalloc((void**)&p.trace, n * 8);
+    return e != hipSuccess ? e : hipMemset(p.trace, 0, n * 8);
+}
+hipError_t trace_end(RenderParams& p, size_t n, const char* path, hipStream_t stream)
+{
+    std::vector<unsigned long long> h(n);
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), p.trace, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(p.trace);
+    p.trace = nullptr;
+    if (e == hipSuccess)
+        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
+    return e;
+}
+
 int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
 {
     if (p.width <= 0 || p.local_rows < 0) return RT_E_INVALID;
@@ -618,18 +672,12 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize)
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kBlock);
     const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
     const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
-    if (trace_file) { RT_HIP(hipMalloc((void**)&p.trace, trace_n * 8)); RT_HIP(hipMemset(p.trace, 0, trace_n * 8)); }
+    if (trace_file) RT_HIP(trace_begin(p, trace_n));
     if (trace_file && getenv("RT_TRACE_PROF")) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, stream, p);
     else if (debug) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, stream, p);
     RT_HIP(hipGetLastError());
-    if (trace_file) {
-        std::vector<unsigned long long> h(trace_n);
-        RT_HIP(hipStreamSynchronize(stream));
-        RT_HIP(hipMemcpy(h.data(), p.trace, trace_n * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(p.trace);
-        if (FILE* f = fopen(trace_file, "wb")) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
-    }
+    if (trace_file) RT_HIP(trace_end(p, trace_n, trace_file, stream));
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
 }
@@ -838,6 +886,7 @@ int rt_scene_update_instance(RtScene* s, int32_t index, const RtInstanceDesc* in
 int rt_scene_destroy(RtScene* s)
 {
     if (!s) return RT_OK;
+    (void)hipFree(s->d_ex_scratch);
     (void)hipFree(s->d_inodes); (void)hipFree(s->d_tris); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
     (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
     for (uint8_t* t : s->d_textures) (void)hipFree(t);
@@ -879,16 +928,46 @@ int rt_render_debug(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_
     return launch(p, true, (hipStream_t)stream, synchronize);
 }
 
-static int launch_ex(RenderParams& p, const RtRenderOptions* opts, int32_t* d_total_pops, hipStream_t stream, int synchronize)
+// Samples are rendered in chunks of as many sample indices as fit the scratch budget (all of them up to 4K x 16 spp):
+// one render_ex_kernel launch with grid.y = chunk, one resolve_ex_kernel.
+constexpr size_t kExScratchBudget = (size_t)2 << 30;
+
+static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, int32_t* d_total_pops, hipStream_t stream, int synchronize)
 {
     if (!opts || opts->spp < 1 || opts->bounces < 0) return RT_E_INVALID;
     if (p.local_rows == 0) return RT_OK;
     p.spp = opts->spp; p.bounces = opts->bounces; p.lighting = opts->lighting ? 1 : 0; p.total_pops = d_total_pops;
     p.tiles_x = (p.width + kTile - 1) / kTile;
     p.tiles_y = (p.local_rows + kTile - 1) / kTile;
+    const size_t npix = (size_t)p.local_rows * p.width;
+    size_t budget = kExScratchBudget;
+    if (const char* e = getenv("RT_EX_SCRATCH_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);   // tests: force several chunks
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)p.spp, budget / (npix * sizeof(float4)), (size_t)65535}));
+    const size_t need = (size_t)(chunk + 1) * npix * sizeof(float4);
+    if (s->ex_scratch_bytes < need) {
+        (void)hipFree(s->d_ex_scratch);                                             // (synchronises with renders in flight)
+        s->d_ex_scratch = nullptr; s->ex_scratch_bytes = 0;
+        RT_HIP(hipMalloc((void**)&s->d_ex_scratch, need));
+        s->ex_scratch_bytes = need;
+    }
+    p.ex_acc = s->d_ex_scratch;
+    p.ex_samples = s->d_ex_scratch + npix;
     const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int);
-    hipLaunchKernelGGL(render_ex_kernel, dim3((unsigned)(p.tiles_x * p.tiles_y)), dim3(kBlock), lds, stream, p);
-    RT_HIP(hipGetLastError());
+    const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only: first chunk
+    for (int base = 0; base < p.spp; base += chunk) {
+        const int n = std::min(chunk, p.spp - base);
+        const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)n);
+        const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
+        const bool tracing = trace_file && base == 0;
+        p.sample_base = base;
+        if (tracing) RT_HIP(trace_begin(p, trace_n));
+        hipLaunchKernelGGL(render_ex_kernel, grid, dim3(kBlock), lds, stream, p);
+        RT_HIP(hipGetLastError());
+        if (tracing) RT_HIP(trace_end(p, trace_n, trace_file, stream));
+        hipLaunchKernelGGL(resolve_ex_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, p, n, base == 0 ? 1 : 0,
+                           base + n == p.spp ? 1 : 0);
+        RT_HIP(hipGetLastError());
+    }
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
 }
@@ -899,7 +978,7 @@ int rt_render_ex(RtScene* s, const RtCameraParams* cam, const RtRenderOptions* o
     RenderParams p;
     int rc = fill_params(p, s, cam, &d_img, 1, pitch);
     if (rc) return rc;
-    return launch_ex(p, opts, d_total_pops, (hipStream_t)stream, synchronize);
+    return launch_ex(s, p, opts, d_total_pops, (hipStream_t)stream, synchronize);
 }
 
 int rt_render_ex_stripes(RtScene* s, const RtCameraParams* cam, const RtRenderOptions* opts, uint8_t* d_local, size_t local_pitch,
@@ -911,7 +990,7 @@ int rt_render_ex_stripes(RtScene* s, const RtCameraParams* cam, const RtRenderOp
     int32_t rows = 0;
     if ((rc = rt_stripe_rows(p.height, stripe_rows, rank, num_ranks, &rows))) return rc;
     p.local_rows = rows; p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
-    return launch_ex(p, opts, nullptr, (hipStream_t)stream, synchronize);
+    return launch_ex(s, p, opts, nullptr, (hipStream_t)stream, synchronize);
 }
 
 int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t* rows)

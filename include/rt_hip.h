@@ -145,9 +145,11 @@ int rt_render_debug(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, s
 /* ---- extension (no counterpart in the reference snapshot, whose shadow pass is commented out
  *      at raycast.cu:262-287 and which has no spp / bounce loop).  Semantics: DESIGN.md "Extension".  With
  *      spp = 1, bounces = 0, lighting = 0 the frame equals rt_render's bit for bit.  d_total_pops: optional tight
- *      [height][width] int32 device plane receiving the node pops of all rays of each pixel. ------------------- */
+ *      [height][width] int32 device plane receiving the node pops of all rays of each pixel.  The per-sample
+ *      scratch lives in the scene handle: extension renders on one scene must not overlap on different streams. -- */
 typedef struct RtRenderOptions {
-    int32_t spp;        /* >= 1; sample 0 is the reference's un-jittered ray, samples > 0 are jittered with XORWOW */
+    int32_t spp;        /* >= 1; sample 0 is the reference's un-jittered ray, sample s > 0 is jittered from its own XORWOW
+                           stream (seed = the reference's per-pixel seed + s) */
     int32_t bounces;    /* specular bounces weighted by Material::metallic, perturbed by Material::roughness */
     int32_t lighting;   /* 1 = sun + shadow ray of raycast.cu:249-287, 0 = illumination 1.0 (raycast.cu:282) */
 } RtRenderOptions;

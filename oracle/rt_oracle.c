@@ -991,10 +991,11 @@ int orc_render_ex(const OrcScene *sc, int width, int height, const float *K9, co
         for (x = 0; x < width; x++) {
             xorwow_t rng; f3 acc = mk3(0.0f, 0.0f, 0.0f); int s; int64_t pops = 0, rays = 0;
             float inv_spp;
-            xorwow_init(&rng, (unsigned long long)(long long)(int32_t)((uint32_t)(y * width + x) * 1000u));
             for (s = 0; s < spp; s++) {
                 float px = (float)x, py = (float)y;
                 ray_t ray; f3 weight = mk3(1.0f, 1.0f, 1.0f), sample = mk3(0.0f, 0.0f, 0.0f); int depth;
+                /* one stream per (pixel, sample): the reference's per-pixel seed (raycast.cu:190, int idx * 1000) + s */
+                xorwow_init(&rng, (unsigned long long)((long long)(int32_t)((uint32_t)(y * width + x) * 1000u) + (long long)s));
                 if (s > 0) { px = px + (xorwow_uniform(&rng) - 0.5f); py = py + (xorwow_uniform(&rng) - 0.5f); }
                 ray = camera_ray_at(&cam, px, py);
                 for (depth = 0; depth <= bounces; depth++) {

@@ -320,6 +320,16 @@ def test_ex_modes_match_oracle(rt, orc, scenes, blob5k, spp, bounces, lighting):
                 spp, bounces, lighting)
 
 
+def test_ex_samples_in_chunks(rt, orc, scenes, blob5k, monkeypatch):
+    """A frame whose sample data exceeds the scratch budget is rendered in chunks of sample indices (running sums kept
+    between chunks): forced here with a budget of 3 samples for 10 spp -> chunks of 3, 3, 3, 1; same frame, same pops."""
+    m = sd.SHINY_CAMERA
+    monkeypatch.setenv("RT_EX_SCRATCH_BYTES", str(3 * m["width"] * m["height"] * 16))
+    _compare_ex(rt, orc, sd.shiny_scene(scenes, blob5k), m["width"], m["height"], scenes.scaled_K(m["width"]), m["pose"], 10, 3, 1)
+    monkeypatch.setenv("RT_EX_SCRATCH_BYTES", "1")                      # degenerate budget: one sample per chunk
+    _compare_ex(rt, orc, sd.shiny_scene(scenes, blob5k), m["width"], m["height"], scenes.scaled_K(m["width"]), m["pose"], 4, 2, 1)
+
+
 def test_c3_bunny_64spp_8bounces(rt, orc, scenes, blob70k):
     """BASELINE.json configs[2] shape: the 70k blob, 64 spp, 8 bounces, sun + shadow -- at 480x270 so that the oracle
     finishes in seconds (the semantics are the extension's, parity unpinned)."""

@@ -63,7 +63,13 @@ def main():
         t.stop()
         ms = t.elapsed_ms() / a.iters / a.batch
         line = "%-6s %.4f ms  %.1f Mrays/s" % (name, ms, W * H / ms / 1e3)
-        if a.check:
+        if a.ex:
+            import hashlib
+            import numpy as np
+            ex = rt.render_ex(scene, cam)
+            tp = int(ex["total_pops"].astype(np.int64).sum())
+            line += "  pops/pixel=%.1f  %.1f Gpops/s  img_sha=%s" % (tp / (W * H), tp / ms / 1e6, hashlib.sha1(ex["img"].tobytes()).hexdigest()[:12])
+        if a.check and not a.ex:
             import numpy as np
             dbg = rt.render_debug(scene, cam)
             got = img.to_host().reshape(H, W, 3)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: render one frame per C2 camera with RT_TRACE_FILE set and print per-wave lifetimes, residency over time and,
 with RT_TRACE_PROF=1 in the environment, per-phase cycle shares of the stamped kernel variant.
-   python tools/trace_one.py <outdir>"""
+   python tools/trace_one.py <outdir> [spp,bounces,lighting]      (the optional triple traces the extension kernel)"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,13 +9,15 @@ import numpy as np
 rt = importlib.import_module("cuda-raytracing_amd")
 scenes = importlib.import_module("cuda-raytracing_amd.scenes")
 out = sys.argv[1]
+ex = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None
 mesh = rt.Mesh.load_obj(os.path.join(ROOT, ".scene_cache", "blob70k.obj"))
-scene = rt.Scene(); scene.add_material(scenes.C2["albedo"]); scene.add_mesh(mesh); scene.add_mesh_instance(0, 0); scene.upload_to_device()
+scene = rt.Scene(); scene.add_material(scenes.C2["albedo"], roughness=0.05 if ex else 0.0, metallic=0.4 if ex else 0.0); scene.add_mesh(mesh); scene.add_mesh_instance(0, 0); scene.upload_to_device()
 W, H = 1920, 1080
 img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
 for name, pose in scenes.C2_CAMERAS.items():
     cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF); cam.set_pose(pose)
-    for _ in range(3): cam.render_scene(scene, img.ptr, img.pitch, synchronize=True)
+    if ex: cam.set_options(*ex)
+    for _ in range(1 if ex else 3): cam.render_scene(scene, img.ptr, img.pitch, synchronize=True)
     os.environ["RT_TRACE_FILE"] = os.path.join(out, "trace_%s.bin" % name)
     cam.render_scene(scene, img.ptr, img.pitch, synchronize=True)
     del os.environ["RT_TRACE_FILE"]
@@ -37,5 +39,8 @@ for name, pose in scenes.C2_CAMERAS.items():
         tot = t[:, 4:11].astype(np.float64).sum(0)
         print("   all waves: iters %.3g (interior %.3g, leaf %.3g); cycle shares pop %.2f fetch %.2f interior %.2f leaf %.2f; cycles/iter %.0f"
               % (tot[4], tot[5], tot[6], *(tot[:4] / tot[:4].sum()), tot[:4].sum() / tot[4]))
+    if ex:                                                    # how much of the wave time is spent by waves of which length
+        order = np.argsort(dur); cs = np.cumsum(dur[order]) / dur.sum()
+        print("   wave dur deciles (us):", np.percentile(dur, [10, 30, 50, 70, 90, 95, 99]).round(0), " share of wave-time in the longest 10%% of waves: %.2f" % (1 - cs[int(0.9 * len(dur))]))
     late = np.argsort(en)[-5:]
     print("   last finishers: start %s end %s dur %s tile %s" % (((st[late]-t0)/100.0).round(1), ((en[late]-t0)/100.0).round(1), dur[late].round(1), t[late,3]))
