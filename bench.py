@@ -110,8 +110,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 logic with host-staged gathers (several ranks may share one GPU); never for numbers")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the N > 1 path (stripes, RCCL gather, un-stripe) even with one rank: a check of that path on a one-GPU box, not the N = 1 number")
     ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
     args = ap.parse_args()
+
+    # stdout carries exactly one line, the result: anything libraries print there (RCCL's version banner, for one) goes to
+    # stderr instead -- file descriptor 1 is pointed at stderr and the JSON is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,17 +130,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    rehearsal = world > 1 and args.debug_backend == "gloo"
+    dist_on = world > 1 or args.force_collective                # stripes + gather + un-stripe instead of whole-frame launches
+    rehearsal = dist_on and args.debug_backend == "gloo"
     if rehearsal:
         local_rank %= max(torch.cuda.device_count(), 1)          # ranks may share a device in the rehearsal
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     rt.build()
     rt.libs()
@@ -141,7 +151,7 @@ def main():
     K, D = scenes.scaled_K(W), scenes.D_REF
     pose = scenes.C4["cam_pose"] if args.workload == "c4" else scenes.C2_CAMERAS[args.camera]
     obj = scene_path(args.workload) if rank == 0 else None
-    if world > 1:
+    if dist_on:
         dist.barrier()
         obj = scene_path(args.workload)
 
@@ -169,7 +179,7 @@ def main():
     pitch = W * 3
     frames = torch.empty((F, H, pitch), dtype=torch.uint8, device=dev)      # rank 0: the finished frames of one group
     hlib = rt.libs()[0]
-    if world > 1:
+    if dist_on:
         rows = []
         for r in range(world):
             n = C.c_int32(0)
@@ -187,14 +197,14 @@ def main():
     timer = rt.Timer()
 
     frame_ptrs = [frames[f].data_ptr() for f in range(F)]
-    dev_local = (local_dev if rehearsal else local) if world > 1 else None
-    dev_gathered = (gathered_dev if rehearsal else gathered) if world > 1 else None
-    local_ptrs = [tiling.batch_local_ptrs(dev_local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if world > 1 else None
+    dev_local = (local_dev if rehearsal else local) if dist_on else None
+    dev_gathered = (gathered_dev if rehearsal else gathered) if dist_on else None
+    local_ptrs = [tiling.batch_local_ptrs(dev_local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if dist_on else None
 
     counts = sorted(set(groups + [F]))                           # a full group and, possibly, the shorter last one
     render_single_calls = {c: cam.prepared_batch(scene, [pose] * c, frame_ptrs[:c], pitch) for c in counts}
     render_local_calls = {(b, c): cam.prepared_batch(scene, [pose] * c, local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
-                          for b in range(2) for c in counts} if world > 1 else None
+                          for b in range(2) for c in counts} if dist_on else None
     group_count = [F, F]                                         # frames in the group that currently occupies buffer b
 
     def render_local(b):
@@ -209,10 +219,10 @@ def main():
         rt.check(hlib.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch, group_count[b],
                                         W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 
-    pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe) if world > 1 else None
+    pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe) if dist_on else None
 
     def step_group(i, count):
-        if world == 1:
+        if not dist_on:
             render_single_calls[count]()
         else:
             pipe._finish(i & 1)                                  # buffer i & 1 is about to be reused: its count changes below
@@ -220,7 +230,7 @@ def main():
             pipe.step(i)
 
     def sync():
-        if world > 1:
+        if dist_on:
             pipe.drain()
             dist.barrier()
         torch.cuda.synchronize()
@@ -233,7 +243,7 @@ def main():
         step_group(i, c)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -246,7 +256,7 @@ def main():
         torch.cuda.synchronize()
         timer.start(stream)
         for _ in range(n):
-            if world == 1:
+            if not dist_on:
                 render_single_calls[F]()
             else:
                 render_local(0)
@@ -262,7 +272,7 @@ def main():
             timer.stop(stream)
             single_ms = timer.elapsed_ms() / 20
             one.free()
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     if rank == 0:
@@ -286,7 +296,8 @@ def main():
         out = {
             "metric": "Mrays/sec + ms/frame, 70k-tri OBJ at 1920x1080 1spp; 1/2/4/8 MI355X",
             "value": round(W * H * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": world, **({"REHEARSAL_NOT_A_MEASUREMENT": "gloo backend, host-staged gathers"} if rehearsal else {}), "steps": args.steps, "warmup": warmup_req, "warmup_frames_done": args.warmup,
+            "n_gpus": world, **({"REHEARSAL_NOT_A_MEASUREMENT": "gloo backend, host-staged gathers"} if rehearsal else {}),
+            **({"FORCED_COLLECTIVE_PATH": "N > 1 code path run with one rank"} if args.force_collective and world == 1 else {}), "steps": args.steps, "warmup": warmup_req, "warmup_frames_done": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("C4 Sponza-class atrium OBJ (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera inside %s"
@@ -295,7 +306,7 @@ def main():
                                    ("C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"
                                     % (W, H, args.camera, str(tuple(pose[:3])))),
                        "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
-                                      % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per %d frames" % F if world > 1 else ""),
+                                      % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per %d frames" % F if dist_on else ""),
                        "frames_per_launch": F, "single_frame_launch_ms": None if single_ms is None else round(single_ms, 4),
                        "coverage": round(st["hits"] / st["rays"], 4),
                        "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
@@ -306,10 +317,11 @@ def main():
                          "frames_per_launch": F, "algorithmic_bytes_per_launch": int(alg_bytes * share)},
             "frame_matches_debug_kernel": frame_ok,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(obj, W, H, K, D, pose, st, wl["albedo"])
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
