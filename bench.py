@@ -219,13 +219,15 @@ def main():
         rt.check(hlib.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch, group_count[b],
                                         W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 
-    pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe) if dist_on else None
+    # un-stripe passes run on their own stream: rank 0 renders group i+1 while group i is gathered and re-ordered
+    side = torch.cuda.Stream() if dist_on and not rehearsal else None
+    pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe, side_stream=side) if dist_on else None
 
     def step_group(i, count):
         if not dist_on:
             render_single_calls[count]()
         else:
-            pipe._finish(i & 1)                                  # buffer i & 1 is about to be reused: its count changes below
+            pipe.release(i & 1)                                  # buffer i & 1 is about to be reused: its count changes below
             group_count[i & 1] = count
             pipe.step(i)
 

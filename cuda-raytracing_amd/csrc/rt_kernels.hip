@@ -527,20 +527,23 @@ __global__ void resolve_ex_kernel(const RenderParams p, int count, int first, in
     if (p.total_pops) p.total_pops[(size_t)y * p.width + x] = pops;
 }
 
-// rows of a rank-major gathered buffer back into frame order (rt_unstripe)
+// rows of a rank-major gathered buffer back into frame order (rt_unstripe): a plain row copy, T = uint4 when every
+// address involved is 16-byte aligned (the usual case: tight or hipMallocPitch pitches), bytes otherwise.
+template <class T>
 __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
-                                uint8_t* __restrict__ dst, size_t pitch, size_t dst_frame_stride, int row_bytes, int height,
+                                uint8_t* __restrict__ dst, size_t pitch, size_t dst_frame_stride, int row_units, int height,
                                 int stripe_rows, int num_ranks)
 {
-    const int y = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // unit i of the frame: row i / row_units
+    const int y = (int)(i / (size_t)row_units), u = (int)(i % (size_t)row_units);
     if (y >= height) return;
     src += (size_t)blockIdx.z * src_frame_stride;               // blockIdx.z = frame of the batch
     dst += (size_t)blockIdx.z * dst_frame_stride;
     const int stripe = y / stripe_rows, rank = stripe % num_ranks;
     const int ly = (stripe / num_ranks) * stripe_rows + y % stripe_rows;
-    const uint8_t* s = src + (size_t)rank * rank_stride + (size_t)ly * local_pitch;
-    uint8_t* d = dst + (size_t)y * pitch;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += gridDim.x * blockDim.x) d[i] = s[i];
+    const T* s = (const T*)(src + (size_t)rank * rank_stride + (size_t)ly * local_pitch);
+    T* d = (T*)(dst + (size_t)y * pitch);
+    d[u] = s[u];
 }
 
 }  // namespace
@@ -1027,9 +1030,16 @@ int rt_unstripe_batch(const uint8_t* d_gathered, size_t local_pitch, size_t rank
 {
     if (!d_gathered || !d_imgs || count < 1 || width <= 0 || height <= 0 || stripe_rows <= 0 || num_ranks <= 0 ||
         local_pitch < (size_t)width * 3 || pitch < (size_t)width * 3) return RT_E_INVALID;
-    dim3 grid(4, (unsigned)height, (unsigned)count), block(256);
-    hipLaunchKernelGGL(unstripe_kernel, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride, src_frame_stride,
-                       d_imgs, pitch, dst_frame_stride, width * 3, height, stripe_rows, num_ranks);
+    const size_t row_bytes = (size_t)width * 3;
+    const bool vec = ((uintptr_t)d_gathered | (uintptr_t)d_imgs | local_pitch | rank_stride | src_frame_stride | pitch | dst_frame_stride | row_bytes) % 16 == 0;
+    const size_t row_units = vec ? row_bytes / 16 : row_bytes;
+    dim3 grid((unsigned)((row_units * (size_t)height + 255) / 256), 1, (unsigned)count), block(256);
+    if (vec)
+        hipLaunchKernelGGL(unstripe_kernel<uint4>, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride, src_frame_stride,
+                           d_imgs, pitch, dst_frame_stride, (int)row_units, height, stripe_rows, num_ranks);
+    else
+        hipLaunchKernelGGL(unstripe_kernel<uint8_t>, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride, src_frame_stride,
+                           d_imgs, pitch, dst_frame_stride, (int)row_units, height, stripe_rows, num_ranks);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

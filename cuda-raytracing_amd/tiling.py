@@ -57,39 +57,62 @@ def gather_stripes(local, gathered, rank, dst=0):
 
 
 class StripePipeline:
-    """Double-buffered frame loop for N ranks: while frame i's stripes are being gathered (on the
-    collective's own stream), frame i+1 is already rendering.  render_fn(b) renders this rank's stripes
-    into local buffer b; unstripe_fn(b) (rank `dst` only) turns gathered buffer b into the frame.
+    """Double-buffered frame loop for N ranks: while group i's stripes are being gathered (on the
+    collective's own stream) and un-striped (on `side_stream`), group i+1 is already rendering.
+    render_fn(b) renders this rank's stripes into local buffer b; unstripe_fn(b) (rank `dst` only) turns gathered
+    buffer b into frames -- it is called with `side_stream` current, so it must launch on torch's current stream.
+    side_stream = None (CPU backends, tests): waits and un-stripes inline.
     Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, rank, world, local, gathered, render_fn, unstripe_fn, dst=0):
+    def __init__(self, rank, world, local, gathered, render_fn, unstripe_fn, dst=0, side_stream=None):
         self.rank, self.world, self.dst = rank, world, dst
         self.local, self.gathered = local, gathered
         self.render_fn, self.unstripe_fn = render_fn, unstripe_fn
+        self.side = side_stream
         self.pending = [None, None]
+        self.side_busy = [False, False]   # buffer b was handed to the side stream and not yet waited for
         self.frames_done = 0
 
     def _finish(self, b):
+        """Order 'wait for gather b, then un-stripe it' -- on the side stream if there is one, so that the stream
+        that renders never waits for a collective or spends time copying rows."""
         work = self.pending[b]
         if work is None:
             return
-        work.wait()                       # stream-ordered for nccl: later work on the current stream waits for the gather
-        if self.rank == self.dst:
-            self.unstripe_fn(b)
+        if self.side is None:
+            work.wait()
+            if self.rank == self.dst:
+                self.unstripe_fn(b)
+        else:
+            import torch
+            with torch.cuda.stream(self.side):
+                work.wait()               # stream-ordered for nccl: only the side stream waits for the gather
+                if self.rank == self.dst:
+                    self.unstripe_fn(b)
+            self.side_busy[b] = True
         self.pending[b] = None
         self.frames_done += 1
+
+    def release(self, b):
+        """Call before buffers b are written again: everything that still reads them is ordered before what the
+        current stream does next."""
+        self._finish(b)
+        if self.side is not None and self.side_busy[b]:
+            import torch
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side_busy = [False, False]
 
     def step(self, i):
         import torch.distributed as dist
         b = i & 1
-        self._finish(b)                   # buffer b was last used by frame i-2
+        self.release(b)                   # buffers b were last used by group i-2
         self.render_fn(b)
         if self.rank == self.dst:
             self.pending[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=self.dst, async_op=True)
         else:
             self.pending[b] = dist.gather(self.local[b], None, dst=self.dst, async_op=True)
-        self._finish(b ^ 1)               # frame i-1: its gather overlapped this frame's render
+        self._finish(b ^ 1)               # group i-1: its gather overlapped this group's render
 
     def drain(self):
-        self._finish(0)
-        self._finish(1)
+        self.release(0)
+        self.release(1)
