@@ -147,71 +147,79 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     return false;
 }
 
+// What a triangle test proposes as the new closest hit.  Deliberately left uninitialised by the callers: it is only
+// read where triangle_test returned true.
+struct Candidate {
+    float dist, u, v;
+    float2 uv;
+    V3 loc;
+};
+
 // One triangle of a leaf (one iteration of raycast.cu:85-136) from its already fetched 64-B record t0..t3.
+// Returns whether the reference would accept it as the new closest hit (raycast.cu:109) and fills `c` in that case;
+// the caller applies the update with selects at the top level of its loop, which keeps the hit record out of the
+// control flow (as branch-merged values it cost two register copies per field per loop iteration).
 template <bool DEBUG, bool EX>
-__device__ __forceinline__ void triangle_step(const RenderParams& p, const DevInstance& in, int inst_index, const MeshRay& r,
-                                              V3 org, int slot, Hit& hit, Counters<DEBUG>& cnt,
-                                              float4 t0, float4 t1, float4 t2, float4 t3)
+__device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevInstance& in, const MeshRay& r,
+                                              V3 org, int slot, float hit_min, Counters<DEBUG>& cnt,
+                                              float4 t0, float4 t1, float4 t2, float4 t3, Candidate& c)
 {
     const bool exact_uv = in.exact_uv != 0;
-    {
-        if constexpr (DEBUG) cnt.tris++;
-        V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
-        // The reference's chain of early returns (TrianglePrimitive.hpp:66,72, raycast.cu:91,96) is evaluated as
-        // one predicate over straight-line code: a wave almost always has some lane that passes each test, so
-        // branching per test only adds exec-mask bookkeeping.  Lanes whose predicate is already false compute
-        // on garbage that is never used.
-        // TrianglePrimitive::ray_intersect, TrianglePrimitive.hpp:62-79
-        float denom = dot(r.rd, nrm);
-        // `abs(denom) < 1e-6` compares in double; 0x358637be is the smallest float whose double value is >= 1e-6,
-        // so this float compare selects exactly the same floats (tests/test_host_logic.py checks the boundary).
-        bool ok = !(fabsf(denom) < __int_as_float(0x358637be));
-        // A candidate is only ever accepted when same_dir = denom < 0 (raycast.cu:107-109); for denom >= 0 (or NaN)
-        // the rest of the test has no observable effect, so the production kernel drops it here.  The debug kernel
-        // goes on because the inside-hit count of raycast.cu:96 is one of the parity planes.
-        if constexpr (!DEBUG) ok = ok && (denom < 0.0f);
-        float tt = dot(v0 - r.ro, nrm) / denom;
-        ok = ok && !(tt < 0.0f);
-        V3 pt = r.ro + tt * r.rd;
-        ok = ok && !(pt.x == FLT_MAX);                          // raycast.cu:91
-        // TrianglePrimitive::point_inside, TrianglePrimitive.hpp:151-185
-        V3 e0 = v3(t1.z, t1.w, t2.x), e1 = v3(t2.y, t2.z, t2.w);
-        V3 e2 = pt - v0;
-        float dot02 = dot(e0, e2), dot12 = dot(e1, e2);
-        float u = (t3.z * dot02 - t3.y * dot12) * t3.w;
-        float v = (t3.x * dot12 - t3.y * dot02) * t3.w;
-        ok = ok && (u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f);
-        float2 uv = make_float2(0.0f, 0.0f);
-        if (exact_uv && ok) {                                   // raycast.cu:96 can only fail for absurd uv data
+    if constexpr (DEBUG) cnt.tris++;
+    V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
+    // The reference's chain of early returns (TrianglePrimitive.hpp:66,72, raycast.cu:91,96) is evaluated as
+    // one predicate over straight-line code: a wave almost always has some lane that passes each test, so
+    // branching per test only adds exec-mask bookkeeping.  Lanes whose predicate is already false compute
+    // on garbage that is never used.
+    // TrianglePrimitive::ray_intersect, TrianglePrimitive.hpp:62-79
+    float denom = dot(r.rd, nrm);
+    // `abs(denom) < 1e-6` compares in double; 0x358637be is the smallest float whose double value is >= 1e-6,
+    // so this float compare selects exactly the same floats (tests/test_host_logic.py checks the boundary).
+    bool ok = !(fabsf(denom) < __int_as_float(0x358637be));
+    // A candidate is only ever accepted when same_dir = denom < 0 (raycast.cu:107-109); for denom >= 0 (or NaN)
+    // the rest of the test has no observable effect, so the production kernel drops it here.  The debug kernel
+    // goes on because the inside-hit count of raycast.cu:96 is one of the parity planes.
+    if constexpr (!DEBUG) ok = ok && (denom < 0.0f);
+    float tt = dot(v0 - r.ro, nrm) / denom;
+    ok = ok && !(tt < 0.0f);
+    V3 pt = r.ro + tt * r.rd;
+    ok = ok && !(pt.x == FLT_MAX);                          // raycast.cu:91
+    // TrianglePrimitive::point_inside, TrianglePrimitive.hpp:151-185
+    V3 e0 = v3(t1.z, t1.w, t2.x), e1 = v3(t2.y, t2.z, t2.w);
+    V3 e2 = pt - v0;
+    float dot02 = dot(e0, e2), dot12 = dot(e1, e2);
+    float u = (t3.z * dot02 - t3.y * dot12) * t3.w;
+    float v = (t3.x * dot12 - t3.y * dot02) * t3.w;
+    ok = ok && (u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f);
+    c.u = u; c.v = v;
+    if (exact_uv) {
+        c.uv = make_float2(0.0f, 0.0f);
+        if (ok) {                                           // raycast.cu:96 can only fail for absurd uv data
             const float* q = p.tri_uv + (size_t)slot * 6;
             float w = 1.0f - u - v;
-            uv.x = (w * q[0] + v * q[2]) + u * q[4];
-            uv.y = (w * q[1] + v * q[3]) + u * q[5];
-            ok = uv.x != FLT_MAX;
-        }
-        if (ok) {
-            if constexpr (DEBUG) cnt.inside++;
-            // raycast.cu:98-104.  For an instance whose mesh -> world transform is exactly the identity (scale 1,
-            // translation 0, quaternion (1,0,0,0): the common case) the scale / translate / rotate sequence returns
-            // pt itself up to the sign of zero components, which the squares in magnitude() cannot see -- so the
-            // production kernel skips it.  (The extension kernel keeps it: it stores `loc`.)
-            V3 loc = pt;
-            if (EX || !in.identity_inv) {
-                loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
-                loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
-            }
-            float distance = magnitude(loc - org);
-            // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
-            const bool accept = denom < 0 && (hit.min == FLT_MAX || distance < hit.min);
-            hit.min = accept ? distance : hit.min;
-            hit.slot = accept ? slot : hit.slot;
-            hit.instance = accept ? inst_index : hit.instance;
-            hit.u = accept ? u : hit.u;
-            hit.v = accept ? v : hit.v;
-            if (exact_uv) { hit.uv.x = accept ? uv.x : hit.uv.x; hit.uv.y = accept ? uv.y : hit.uv.y; }
-            if constexpr (EX) { hit.loc.x = accept ? loc.x : hit.loc.x; hit.loc.y = accept ? loc.y : hit.loc.y; hit.loc.z = accept ? loc.z : hit.loc.z; }
+            c.uv.x = (w * q[0] + v * q[2]) + u * q[4];
+            c.uv.y = (w * q[1] + v * q[3]) + u * q[5];
+            ok = c.uv.x != FLT_MAX;
         }
     }
+    bool accept = false;
+    if (ok) {
+        if constexpr (DEBUG) cnt.inside++;
+        // raycast.cu:98-104.  For an instance whose mesh -> world transform is exactly the identity (scale 1,
+        // translation 0, quaternion (1,0,0,0): the common case) the scale / translate / rotate sequence returns
+        // pt itself up to the sign of zero components, which the squares in magnitude() cannot see -- so the
+        // production kernel skips it.  (The extension kernel keeps it: it stores `loc`.)
+        V3 loc = pt;
+        if (EX || !in.identity_inv) {
+            loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
+            loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
+        }
+        c.dist = magnitude(loc - org);
+        if constexpr (EX) c.loc = loc;
+        // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
+        accept = denom < 0 && (hit_min == FLT_MAX || c.dist < hit_min);
+    }
+    return accept;
 }
 
 // One instance of raycast.cu:26-139.
@@ -233,15 +241,14 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
     // One iteration = one interior node or ONE triangle of a leaf (a leaf with k triangles takes k iterations and
     // keeps `cur` pointing at its next slot), so the loop has no inner loop and every record -- node or triangle,
     // first or later -- comes through the same fetch below.
+    // The loop is bottom-tested (the pop and the stack-empty exit of raycast.cu:60-61 close the iteration) so that the
+    // hit record leaves the loop after its update: with the exit at the top it was live across the back edge in two
+    // copies.
+    const bool exact_uv = in.exact_uv != 0;
     while (true) {
-        if constexpr (PROF) t0 = __builtin_amdgcn_s_memtime();
-        if (!have) {
-            if (stack.sp == 0) break;
-            cur = stack.pop();                                  // raycast.cu:61
-        }
+        if constexpr (PROF) t1 = __builtin_amdgcn_s_memtime();
         const bool interior = cur >= 0;
         if constexpr (DEBUG) cnt.pops += (interior || rem < 0) ? 1 : 0;
-        if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t1 = __builtin_amdgcn_s_memtime(); }
         // About half of all wave iterations (three quarters for close-up views) find every active lane holding
         // the SAME entry -- coherent rays walk the top of the tree in lockstep.  Those iterations fetch the record
         // once per wave through the scalar cache (s_load_dwordx16) instead of 64 x 64 B through the vector memory
@@ -267,21 +274,39 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         }
         if (interior) have = interior_apply<DEBUG>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t3 = __builtin_amdgcn_s_memtime(); }
+        bool accept = false;
+        Candidate c;                                            // uninitialised on purpose, see Candidate
+        const int slot = cur & kSlotMask;
         if (!interior) {                                        // leaf: contiguous triangle slots, raycast.cu:83-137
-            const int slot = cur & kSlotMask;
             if (rem < 0) {                                      // first visit: decode the triangle count
                 rem = (cur >> kSlotBits) & 31;
                 if (rem == 31) rem = p.leaf_count[slot];
             }
-            if (rem > 0) triangle_step<DEBUG, EX>(p, in, inst_index, r, org, slot, hit, cnt, r0, r1, r2, r3);
+            if (rem > 0) accept = triangle_test<DEBUG, EX>(p, in, r, org, slot, hit.min, cnt, r0, r1, r2, r3, c);
             rem--;
             have = rem > 0;
             cur = have ? cur + 1 : cur;                         // next slot of the same leaf (the slot field never overflows)
             rem = have ? rem : -1;
         }
+        hit.min = accept ? c.dist : hit.min;
+        hit.slot = accept ? slot : hit.slot;
+        hit.instance = accept ? inst_index : hit.instance;
+        hit.u = accept ? c.u : hit.u;
+        hit.v = accept ? c.v : hit.v;
+        if (exact_uv) { hit.uv.x = accept ? c.uv.x : hit.uv.x; hit.uv.y = accept ? c.uv.y : hit.uv.y; }
+        if constexpr (EX) { hit.loc.x = accept ? c.loc.x : hit.loc.x; hit.loc.y = accept ? c.loc.y : hit.loc.y; hit.loc.z = accept ? c.loc.z : hit.loc.z; }
+        if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t0 = __builtin_amdgcn_s_memtime(); }
+        if (!have) {
+            if (stack.sp == 0) break;
+            cur = stack.pop();                                  // raycast.cu:61
+        }
+        // One latch for both ways round (popped / kept going): a convergent no-op that the optimiser may not clone.
+        // Without it the two back edges are split into nested loops ("iterate while nobody pops" inside "pop"),
+        // i.e. lanes that need a pop wait for every lane that does not: +50 % time on views with sky.
+        __builtin_amdgcn_wave_barrier();
         if constexpr (PROF) {
             __builtin_amdgcn_s_waitcnt(0);
-            c_pop += t1 - t0; c_mem += t2 - t1; c_int += t3 - t2; c_leaf += __builtin_amdgcn_s_memtime() - t3;
+            c_mem += t2 - t1; c_int += t3 - t2; c_leaf += t0 - t3; c_pop += __builtin_amdgcn_s_memtime() - t0;
         }
     }
     if constexpr (PROF) {
