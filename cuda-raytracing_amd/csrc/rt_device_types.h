@@ -6,8 +6,8 @@
 namespace rt {
 
 // Traversal-stack entry / child reference, 32 bits:
-//   >= 0                      interior node index into Scene::inodes (scene-wide)
-//   bit 31 set                leaf: bits 0..25 = first triangle slot (scene-wide),
+//   >= 0                      interior node: index of its record (scene-wide record array)
+//   bit 31 set                leaf: bits 0..25 = index of its first triangle record in the same array,
 //                             bits 26..30 = triangle count 0..30, or 31 = read leaf_count[slot]
 constexpr int32_t kLeafFlag = (int32_t)0x80000000u;
 constexpr int kSlotBits = 26;
@@ -70,8 +70,7 @@ struct RenderParams {
     int32_t width, height;
     int32_t num_frames;         // grid.y
     FrameParams frames[kMaxBatch];
-    const float4* inodes;
-    const float4* tris;
+    const float4* records;      // interior-node and triangle records (64 B each), one index space
     const float* tri_uv;        // [slot][3][2]
     const int32_t* tri_id;      // [slot] -> caller's triangle index within its mesh
     const int32_t* leaf_count;  // [slot] count of the leaf that starts at slot (only read for count > 30)

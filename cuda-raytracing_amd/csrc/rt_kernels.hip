@@ -256,7 +256,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         float4 r0, r1, r2, r3;
         const int32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
         if (!PROF && __ballot(cur != cur0) == 0ull) {
-            const float4* g = cur0 >= 0 ? p.inodes + (size_t)cur0 * 4 : p.tris + (size_t)(cur0 & kSlotMask) * 4;
+            const float4* g = p.records + (size_t)(cur0 & kSlotMask) * 4;
             typedef float f16v __attribute__((ext_vector_type(16)));
             f16v w;
             // inline asm: hipcc would otherwise merge this load with the per-lane one below into a single vector load
@@ -264,7 +264,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             r0 = make_float4(w[0], w[1], w[2], w[3]);   r1 = make_float4(w[4], w[5], w[6], w[7]);
             r2 = make_float4(w[8], w[9], w[10], w[11]); r3 = make_float4(w[12], w[13], w[14], w[15]);
         } else {
-            const float4* rec = interior ? p.inodes + (size_t)cur * 4 : p.tris + (size_t)(cur & kSlotMask) * 4;
+            const float4* rec = p.records + (size_t)(cur & kSlotMask) * 4;     // node or triangle: one array, one index space
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
         }
         if constexpr (PROF) {
@@ -442,7 +442,7 @@ __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir
 __device__ __forceinline__ V3 hit_normal(const RenderParams& p, const Hit& hit)
 {
     const DevInstance& in = p.instances[hit.instance];
-    const float4* t = p.tris + (size_t)hit.slot * 4;
+    const float4* t = p.records + (size_t)hit.slot * 4;
     float4 t0 = t[0], t1 = t[1];
     V3 n = apply_quat(in.q_inv_rot, v3(t0.w, t1.x, t1.y));
     n.x *= in.scale[0]; n.y *= in.scale[1]; n.z *= in.scale[2];
@@ -579,8 +579,7 @@ __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pi
 
 struct RtScene {
     int device = 0;
-    float4* d_inodes = nullptr;
-    float4* d_tris = nullptr;
+    float4* d_records = nullptr;                 // interior-node and triangle records, one index space
     float* d_tri_uv = nullptr;
     int32_t* d_tri_id = nullptr;
     int32_t* d_leaf_count = nullptr;
@@ -662,7 +661,7 @@ int fill_params(RenderParams& p, const RtScene* s, const RtCameraParams* cams, u
         f.q_cam = euler2quat(v3(cam->inv_camera_pose[3], cam->inv_camera_pose[4], cam->inv_camera_pose[5]));
         f.img = d_imgs[i];
     }
-    p.inodes = s->d_inodes; p.tris = s->d_tris; p.tri_uv = s->d_tri_uv; p.tri_id = s->d_tri_id;
+    p.records = s->d_records; p.tri_uv = s->d_tri_uv; p.tri_id = s->d_tri_id;
     p.leaf_count = s->d_leaf_count;
     p.instances = s->d_instances; p.materials = s->d_materials;
     p.num_instances = (int32_t)s->instances.size();
@@ -775,7 +774,9 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     RtScene* s = new (std::nothrow) RtScene;
     if (!s) return RT_E_NOMEM;
     int rc = RT_OK;
-    std::vector<float4> inodes, tris;
+    // One record array and one index space for the whole scene: per mesh its interior nodes, then its triangles in
+    // leaf order.  The per-triangle side arrays use the same index (their entries at interior records are unused).
+    std::vector<float4> records;
     std::vector<float> tri_uv;
     std::vector<int32_t> tri_id, leaf_count;
     try {
@@ -786,8 +787,10 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                 (m.num_triangles && (!m.vertices || !m.normals || !m.uvs)) || (m.num_leaf_indices && !m.leaf_indices)) {
                 rc = RT_E_INVALID; break;
             }
-            const int64_t node_base = (int64_t)inodes.size() / 4, slot_base = (int64_t)tri_id.size();
-            if (slot_base + m.num_leaf_indices > kSlotMask) { rc = RT_E_INVALID; break; }
+            int64_t mesh_interior = 0;
+            for (int i = 0; i < m.num_nodes; i++) mesh_interior += m.node_children[2 * i] > 0 ? 1 : 0;
+            const int64_t node_base = (int64_t)records.size() / 4, slot_base = node_base + mesh_interior;
+            if (slot_base + m.num_leaf_indices + 1 > kSlotMask) { rc = RT_E_INVALID; break; }
             // pass 1: entry of every node (interior -> running interior index, leaf -> slot range), levels
             std::vector<int32_t> entry((size_t)m.num_nodes), level((size_t)m.num_nodes, 0);
             int64_t n_int = 0, n_slot = 0;
@@ -813,13 +816,16 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             s->max_stack = std::max(s->max_stack, max_level);
             // pass 2: emit records
             bool exact_uv = false;
-            inodes.resize(inodes.size() + (size_t)n_int * 4);
+            records.resize(records.size() + (size_t)n_int * 4);
+            tri_uv.resize(tri_uv.size() + (size_t)n_int * 6, 0.0f);
+            tri_id.resize(tri_id.size() + (size_t)n_int, -1);
+            leaf_count.resize(leaf_count.size() + (size_t)n_int, 0);
             for (int i = 0; i < m.num_nodes && rc == RT_OK; i++) {
                 const int a = m.node_children[2 * i], b = m.node_children[2 * i + 1];
                 if (a > 0) {
                     const float* A = m.node_bounds + 6 * (size_t)a;
                     const float* B = m.node_bounds + 6 * (size_t)b;
-                    float4* q = &inodes[(size_t)entry[i] * 4];
+                    float4* q = &records[(size_t)entry[i] * 4];
                     q[0] = make_float4(A[0], A[1], A[2], A[3]);
                     q[1] = make_float4(A[4], A[5], B[0], B[1]);
                     q[2] = make_float4(B[2], B[3], B[4], B[5]);
@@ -836,10 +842,10 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                         V3 e0 = v2 - v0, e1 = v1 - v0;                      // TrianglePrimitive.hpp:154-155
                         float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1);
                         float inv = 1.0f / (d00 * d11 - d01 * d01);        // TrianglePrimitive.hpp:164
-                        tris.push_back(make_float4(v0.x, v0.y, v0.z, nn[0]));
-                        tris.push_back(make_float4(nn[1], nn[2], e0.x, e0.y));
-                        tris.push_back(make_float4(e0.z, e1.x, e1.y, e1.z));
-                        tris.push_back(make_float4(d00, d01, d11, inv));
+                        records.push_back(make_float4(v0.x, v0.y, v0.z, nn[0]));
+                        records.push_back(make_float4(nn[1], nn[2], e0.x, e0.y));
+                        records.push_back(make_float4(e0.z, e1.x, e1.y, e1.z));
+                        records.push_back(make_float4(d00, d01, d11, inv));
                         for (int c = 0; c < 6; c++) {
                             tri_uv.push_back(uv[c]);
                             if (!(fabsf(uv[c]) < 1e37f)) exact_uv = true;  // also catches NaN / inf
@@ -870,9 +876,8 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     auto fail = [&](int code) { rt_scene_destroy(s); return code; };
     hipError_t he = hipGetDevice(&s->device);
     if (he != hipSuccess) return fail(he == hipErrorNoDevice ? RT_E_NODEVICE : (int)he);
-    if ((rc = upload(&s->d_inodes, inodes, s->device_bytes))) return fail(rc);
-    for (int k = 0; k < 4; k++) tris.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));     // padding record (see leaf_step)
-    if ((rc = upload(&s->d_tris, tris, s->device_bytes))) return fail(rc);
+    for (int k = 0; k < 4; k++) records.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));  // padding: a leaf's last iteration looks one record ahead
+    if ((rc = upload(&s->d_records, records, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_tri_uv, tri_uv, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_tri_id, tri_id, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_leaf_count, leaf_count, s->device_bytes))) return fail(rc);
@@ -915,7 +920,7 @@ int rt_scene_destroy(RtScene* s)
 {
     if (!s) return RT_OK;
     (void)hipFree(s->d_ex_scratch);
-    (void)hipFree(s->d_inodes); (void)hipFree(s->d_tris); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
+    (void)hipFree(s->d_records); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
     (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
     for (uint8_t* t : s->d_textures) (void)hipFree(t);
     delete s;
