@@ -39,18 +39,30 @@ struct Hit {
     V3 loc;                     // world-space location of the accepted hit (extension kernel only)
 };
 
-// d_BVHTree::ray_intersects, BVHTree.hpp:40-54
-__device__ __forceinline__ float slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                      V3 o, V3 dinv)
+// d_BVHTree::ray_intersects, BVHTree.hpp:40-54, from the six differences (box min - origin, box max - origin):
+// the subtraction is done where the record is fetched, see trace_instance.
+__device__ __forceinline__ float slab(float dnx, float dny, float dnz, float dxx, float dxy, float dxz, V3 dinv)
 {
-    float tminx = (mnx - o.x) * dinv.x, tminy = (mny - o.y) * dinv.y, tminz = (mnz - o.z) * dinv.z;
-    float tmaxx = (mxx - o.x) * dinv.x, tmaxy = (mxy - o.y) * dinv.y, tmaxz = (mxz - o.z) * dinv.z;
+    float tminx = dnx * dinv.x, tminy = dny * dinv.y, tminz = dnz * dinv.z;
+    float tmaxx = dxx * dinv.x, tmaxy = dxy * dinv.y, tmaxz = dxz * dinv.z;
     float t1x = fminf(tminx, tmaxx), t1y = fminf(tminy, tmaxy), t1z = fminf(tminz, tmaxz);
     float t2x = fmaxf(tminx, tmaxx), t2y = fmaxf(tminy, tmaxy), t2z = fmaxf(tminz, tmaxz);
     float dst_far = fminf(fminf(t2x, t2y), t2z);
     float dst_near = fmaxf(fmaxf(t1x, t1y), t1z);
     bool hit = dst_far >= dst_near && dst_far > 0.0f;
     return hit ? dst_near : FLT_MAX;
+}
+
+// The first twelve words of an interior record are the two child boxes (min xyz, max xyz each); this turns them into
+// box - origin, written over the record's registers q0..q2.  W = the record itself, or the 16-word scalar-register
+// vector of a wave-uniform fetch: the subtraction then takes its box operand from the scalar register directly and the
+// record never has to be copied into vector registers.
+template <class W>
+__device__ __forceinline__ void box_differences(const W& w, V3 o, float4& q0, float4& q1, float4& q2)
+{
+    q0 = make_float4(w[0] - o.x, w[1] - o.y, w[2] - o.z, w[3] - o.x);
+    q1 = make_float4(w[4] - o.y, w[5] - o.z, w[6] - o.x, w[7] - o.y);
+    q2 = make_float4(w[8] - o.z, w[9] - o.x, w[10] - o.y, w[11] - o.z);
 }
 
 // Primary ray direction of pixel (x, y): raycast.cu:159-188
@@ -129,8 +141,8 @@ template <bool DEBUG>
 __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, float4 q3, const MeshRay& r, float hit_min,
                                                int32_t& cur, Stack& stack, Counters<DEBUG>& cnt)
 {
-    float da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.ro, r.dinv);
-    float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.ro, r.dinv);
+    float da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.dinv);       // q0..q2: box - origin (box_differences)
+    float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.dinv);
     int32_t ra = __float_as_int(q3.x), rb = __float_as_int(q3.y);
     if constexpr (DEBUG) cnt.aabb += 2;
     // push order of raycast.cu:72-79: `first` is pushed first, `second` last (= popped next)
@@ -253,7 +265,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         // the SAME entry -- coherent rays walk the top of the tree in lockstep.  Those iterations fetch the record
         // once per wave through the scalar cache (s_load_dwordx16) instead of 64 x 64 B through the vector memory
         // path, which is otherwise the busiest unit of the kernel (-9..-13 % frame time).
-        float4 r0, r1, r2, r3;
+        float4 r0, r1, r2, r3;          // the record; for interior lanes r0..r2 become child boxes - ray origin
         const int32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
         if (!PROF && __ballot(cur != cur0) == 0ull) {
             const float4* g = p.records + (size_t)(cur0 & kSlotMask) * 4;
@@ -261,11 +273,26 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             f16v w;
             // inline asm: hipcc would otherwise merge this load with the per-lane one below into a single vector load
             asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(g) : "memory");
-            r0 = make_float4(w[0], w[1], w[2], w[3]);   r1 = make_float4(w[4], w[5], w[6], w[7]);
-            r2 = make_float4(w[8], w[9], w[10], w[11]); r3 = make_float4(w[12], w[13], w[14], w[15]);
+            if (cur0 >= 0) {                                    // (a scalar branch: the whole wave holds this interior node)
+                box_differences(w, r.ro, r0, r1, r2);
+            } else {
+                // (a triangle record is used as it is.  The copies go through an OR with a zero the optimiser cannot
+                // see through: as plain copies they are hoisted above the branch and run for interior nodes too.)
+                int z;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                auto keep = [z](float f) { return __int_as_float(__float_as_int(f) | z); };
+                r0 = make_float4(keep(w[0]), keep(w[1]), keep(w[2]), keep(w[3]));
+                r1 = make_float4(keep(w[4]), keep(w[5]), keep(w[6]), keep(w[7]));
+                r2 = make_float4(keep(w[8]), keep(w[9]), keep(w[10]), keep(w[11]));
+            }
+            r3 = make_float4(w[12], w[13], w[14], w[15]);
         } else {
             const float4* rec = p.records + (size_t)(cur & kSlotMask) * 4;     // node or triangle: one array, one index space
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+            if (interior) {
+                const float w[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                box_differences(w, r.ro, r0, r1, r2);
+            }
         }
         if constexpr (PROF) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -288,13 +315,15 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             cur = have ? cur + 1 : cur;                         // next slot of the same leaf (the slot field never overflows)
             rem = have ? rem : -1;
         }
-        hit.min = accept ? c.dist : hit.min;
-        hit.slot = accept ? slot : hit.slot;
-        hit.instance = accept ? inst_index : hit.instance;
-        hit.u = accept ? c.u : hit.u;
-        hit.v = accept ? c.v : hit.v;
-        if (exact_uv) { hit.uv.x = accept ? c.uv.x : hit.uv.x; hit.uv.y = accept ? c.uv.y : hit.uv.y; }
-        if constexpr (EX) { hit.loc.x = accept ? c.loc.x : hit.loc.x; hit.loc.y = accept ? c.loc.y : hit.loc.y; hit.loc.z = accept ? c.loc.z : hit.loc.z; }
+        if (__ballot(accept) != 0ull) {                         // (wave-level: most iterations accept nothing)
+            hit.min = accept ? c.dist : hit.min;
+            hit.slot = accept ? slot : hit.slot;
+            hit.instance = accept ? inst_index : hit.instance;
+            hit.u = accept ? c.u : hit.u;
+            hit.v = accept ? c.v : hit.v;
+            if (exact_uv) { hit.uv.x = accept ? c.uv.x : hit.uv.x; hit.uv.y = accept ? c.uv.y : hit.uv.y; }
+            if constexpr (EX) { hit.loc.x = accept ? c.loc.x : hit.loc.x; hit.loc.y = accept ? c.loc.y : hit.loc.y; hit.loc.z = accept ? c.loc.z : hit.loc.z; }
+        }
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t0 = __builtin_amdgcn_s_memtime(); }
         if (!have) {
             if (stack.sp == 0) break;
