@@ -172,11 +172,10 @@ struct Candidate {
 // the caller applies the update with selects at the top level of its loop, which keeps the hit record out of the
 // control flow (as branch-merged values it cost two register copies per field per loop iteration).
 template <bool DEBUG, bool EX>
-__device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevInstance& in, const MeshRay& r,
-                                              V3 org, int slot, float hit_min, Counters<DEBUG>& cnt,
+__device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevInstance& in, bool exact_uv, bool identity_inv,
+                                              const MeshRay& r, V3 org, int slot, float hit_min, Counters<DEBUG>& cnt,
                                               float4 t0, float4 t1, float4 t2, float4 t3, Candidate& c)
 {
-    const bool exact_uv = in.exact_uv != 0;
     if constexpr (DEBUG) cnt.tris++;
     V3 v0 = v3(t0.x, t0.y, t0.z), nrm = v3(t0.w, t1.x, t1.y);
     // The reference's chain of early returns (TrianglePrimitive.hpp:66,72, raycast.cu:91,96) is evaluated as
@@ -222,7 +221,7 @@ __device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevIn
         // pt itself up to the sign of zero components, which the squares in magnitude() cannot see -- so the
         // production kernel skips it.  (The extension kernel keeps it: it stores `loc`.)
         V3 loc = pt;
-        if (EX || !in.identity_inv) {
+        if (EX || !identity_inv) {
             loc = v3(pt.x * in.scale[0], pt.y * in.scale[1], pt.z * in.scale[2]);
             loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
         }
@@ -256,7 +255,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
     // The loop is bottom-tested (the pop and the stack-empty exit of raycast.cu:60-61 close the iteration) so that the
     // hit record leaves the loop after its update: with the exit at the top it was live across the back edge in two
     // copies.
-    const bool exact_uv = in.exact_uv != 0;
+    const bool exact_uv = in.exact_uv != 0, identity_inv = in.identity_inv != 0;    // (read once, not per triangle)
     while (true) {
         if constexpr (PROF) t1 = __builtin_amdgcn_s_memtime();
         const bool interior = cur >= 0;
@@ -271,8 +270,10 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             const float4* g = p.records + (size_t)(cur0 & kSlotMask) * 4;
             typedef float f16v __attribute__((ext_vector_type(16)));
             f16v w;
-            // inline asm: hipcc would otherwise merge this load with the per-lane one below into a single vector load
-            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(g) : "memory");
+            // inline asm: hipcc would otherwise merge this load with the per-lane one below into a single vector load.
+            // No "memory" clobber: the records are read-only, and a clobber makes every other load in the loop
+            // (instance fields, ...) repeat each iteration.
+            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(g));
             if (cur0 >= 0) {                                    // (a scalar branch: the whole wave holds this interior node)
                 box_differences(w, r.ro, r0, r1, r2);
             } else {
@@ -309,7 +310,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
                 rem = (cur >> kSlotBits) & 31;
                 if (rem == 31) rem = p.leaf_count[slot];
             }
-            if (rem > 0) accept = triangle_test<DEBUG, EX>(p, in, r, org, slot, hit.min, cnt, r0, r1, r2, r3, c);
+            if (rem > 0) accept = triangle_test<DEBUG, EX>(p, in, exact_uv, identity_inv, r, org, slot, hit.min, cnt, r0, r1, r2, r3, c);
             rem--;
             have = rem > 0;
             cur = have ? cur + 1 : cur;                         // next slot of the same leaf (the slot field never overflows)
