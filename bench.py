@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 logic with host-staged gathers (several ranks may share one GPU); never for numbers")
+    ap.add_argument("--gather", default="rotate", choices=["rotate", "root0"],
+                    help="N > 1: rotate = the gather's root rotates over the frames of a group, fused into one all-to-all (every rank "
+                         "assembles 1/N of the frames); root0 = every frame is gathered to rank 0")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 path (stripes, RCCL gather, un-stripe) even with one rank: a check of that path on a one-GPU box, not the N = 1 number")
     ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
@@ -177,8 +180,11 @@ def main():
     warm_groups = [F] * ((args.warmup + F - 1) // F)             # whole groups: at least the requested warm-up
     args.warmup = len(warm_groups) * F
     pitch = W * 3
-    frames = torch.empty((F, H, pitch), dtype=torch.uint8, device=dev)      # rank 0: the finished frames of one group
     hlib = rt.libs()[0]
+    rotate = dist_on and args.gather == "rotate"
+    # finished frames of one group that THIS rank holds: all F (one GPU, or root0 on rank 0), or its share of a rotating gather
+    my_frames = (lambda c: tiling.frames_per_rank(c, world)[0][rank]) if rotate else (lambda c: c if (rank == 0 or not dist_on) else 0)
+    frames = torch.empty((max(my_frames(F), 1), H, pitch), dtype=torch.uint8, device=dev)
     if dist_on:
         rows = []
         for r in range(world):
@@ -186,23 +192,26 @@ def main():
             rt.check(hlib.rt_stripe_rows(H, STRIPE_ROWS, r, world, C.byref(n)))
             rows.append(n.value)
         max_rows = max(rows)
-        # per buffer: F frames x this rank's (padded) stripe rows
+        # per buffer: F frames x this rank's (padded) stripe rows; what comes back is source-rank-major
         local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
-        if rehearsal:                                            # gloo cannot gather device tensors: stage through the host
+        if rotate:
+            gathered = [torch.empty((world * max(my_frames(F), 1) * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+        else:
+            gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
+        if rehearsal:                                            # gloo cannot move device tensors: stage through the host
             local_dev, gathered_dev = local, gathered
-            local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8) for _ in range(2)]
-            gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8) if rank == 0 else None for _ in range(2)]
+            local = [torch.zeros_like(t, device="cpu") for t in local_dev]
+            gathered = [torch.empty_like(t, device="cpu") if t is not None else None for t in gathered_dev]
 
     timer = rt.Timer()
 
-    frame_ptrs = [frames[f].data_ptr() for f in range(F)]
+    frame_ptrs = [frames[f].data_ptr() for f in range(F)] if not dist_on else None
     dev_local = (local_dev if rehearsal else local) if dist_on else None
     dev_gathered = (gathered_dev if rehearsal else gathered) if dist_on else None
     local_ptrs = [tiling.batch_local_ptrs(dev_local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if dist_on else None
 
     counts = sorted(set(groups + [F]))                           # a full group and, possibly, the shorter last one
-    render_single_calls = {c: cam.prepared_batch(scene, [pose] * c, frame_ptrs[:c], pitch) for c in counts}
+    render_single_calls = {c: cam.prepared_batch(scene, [pose] * c, frame_ptrs[:c], pitch) for c in counts} if not dist_on else None
     render_local_calls = {(b, c): cam.prepared_batch(scene, [pose] * c, local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
                           for b in range(2) for c in counts} if dist_on else None
     group_count = [F, F]                                         # frames in the group that currently occupies buffer b
@@ -213,15 +222,24 @@ def main():
             local[b].copy_(dev_local[b])
 
     def unstripe(b):
+        count = my_frames(group_count[b])
+        if count == 0:
+            return
         if rehearsal:
             dev_gathered[b].copy_(gathered[b])
-        src, rank_stride = tiling.batch_unstripe_args(dev_gathered[b].data_ptr(), 0, F, max_rows, pitch)
-        rt.check(hlib.rt_unstripe_batch(src, pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch, group_count[b],
-                                        W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
+        # rank r's block holds its stripes of my `count` frames (rotate) or of all F frame slots (root0)
+        rank_stride = (count if rotate else F) * max_rows * pitch
+        rt.check(hlib.rt_unstripe_batch(dev_gathered[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch,
+                                        count, W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 
-    # un-stripe passes run on their own stream: rank 0 renders group i+1 while group i is gathered and re-ordered
+    def exchange(b):
+        if rotate:
+            return tiling.exchange_rotating(local[b], gathered[b], group_count[b], world, max_rows)
+        return tiling.exchange_to_root(local[b], gathered[b], rank)
+
+    # un-stripe passes run on their own stream: a rank renders group i+1 while group i is exchanged and re-ordered
     side = torch.cuda.Stream() if dist_on and not rehearsal else None
-    pipe = tiling.StripePipeline(rank, world, local, gathered, render_local, unstripe, side_stream=side) if dist_on else None
+    pipe = tiling.StripePipeline(render_local, exchange, unstripe, assembles=rotate or rank == 0, side_stream=side) if dist_on else None
 
     def step_group(i, count):
         if not dist_on:
@@ -277,14 +295,20 @@ def main():
     if dist_on:
         dist.barrier()
 
+    # ---- every rank checks the frames it assembled in the last group against the debug kernel's frame ----
+    dbg = rt.render_debug(scene, cam)
+    mine = my_frames(groups[-1] if groups else F)
+    frames_host = frames.cpu().numpy().reshape(-1, H, W, 3)
+    frame_ok = bool(all(np.array_equal(frames_host[f], dbg["img"]) for f in range(mine)))
+    if dist_on:
+        flag = torch.tensor([int(frame_ok)], dtype=torch.int32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        frame_ok = bool(flag.item())
+
     if rank == 0:
         # ---- per-frame work counters from the debug kernel (same traversal, extra stores) ----
-        dbg = rt.render_debug(scene, cam)
         st = {"rays": W * H, "pops": int(dbg["pops"].sum()), "aabb": int(dbg["aabb"].sum()), "tris": int(dbg["tris"].sum()),
               "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
-        last = groups[-1] if groups else F                   # the last group wrote this many frames
-        frames_host = frames.cpu().numpy().reshape(F, H, W, 3)
-        frame_ok = bool(all(np.array_equal(frames_host[f], dbg["img"]) for f in range(last)))
         alg_bytes = algorithmic_bytes(st)                   # per frame
         share = F / world                                   # one launch = F frames; rank 0's stripes ~ 1/N of each
         achieved = alg_bytes * share / (kernel_ms * 1e-3) / 1e9
@@ -308,7 +332,8 @@ def main():
                                    ("C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"
                                     % (W, H, args.camera, str(tuple(pose[:3])))),
                        "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
-                                      % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per %d frames" % F if dist_on else ""),
+                                      % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames)" % F if rotate
+                                                           else ", one RCCL gather to rank 0 per %d frames" % F) if dist_on else ""),
                        "frames_per_launch": F, "single_frame_launch_ms": None if single_ms is None else round(single_ms, 4),
                        "coverage": round(st["hits"] / st["rays"], 4),
                        "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},

@@ -56,38 +56,69 @@ def gather_stripes(local, gathered, rank, dst=0):
         dist.gather(local, None, dst=dst)
 
 
+def frames_per_rank(F, world):
+    """How the F frames of a group are dealt to assembling ranks when the gather's root rotates: rank d assembles the
+    contiguous block of counts[d] frames starting at offsets[d] (blocks as even as possible, earlier ranks first)."""
+    counts = [F // world + (1 if d < F % world else 0) for d in range(world)]
+    offsets = [sum(counts[:d]) for d in range(world)]
+    return counts, offsets
+
+
+def exchange_to_root(local, gathered, rank, dst=0):
+    """Start the gather of a group to one root: local [F * max_rows, pitch] from every rank into
+    gathered [world, F * max_rows, pitch] on `dst` (None elsewhere).  Returns the async work handle."""
+    import torch.distributed as dist
+    if rank == dst:
+        return dist.gather(local, list(gathered.unbind(0)), dst=dst, async_op=True)
+    return dist.gather(local, None, dst=dst, async_op=True)
+
+
+def exchange_rotating(local, received, F, world, max_rows):
+    """Start the gather of a group with a rotating root, fused into ONE all-to-all: the stripes of frame f go to the
+    rank that assembles f (frames_per_rank), so every rank receives 1/world of the pixels and every xGMI link carries
+    the same load in both directions instead of seven links converging on one root.
+    local: [F * max_rows, pitch] (frame-major, so the block for destination d is contiguous);
+    received: [world * counts[me] * max_rows, pitch] (source-major).  Returns the async work handle."""
+    import torch.distributed as dist
+    counts, _ = frames_per_rank(F, world)
+    me = dist.get_rank()
+    return dist.all_to_all_single(received[:world * counts[me] * max_rows], local[:F * max_rows],
+                                  output_split_sizes=[counts[me] * max_rows] * world,
+                                  input_split_sizes=[c * max_rows for c in counts], async_op=True)
+
+
 class StripePipeline:
-    """Double-buffered frame loop for N ranks: while group i's stripes are being gathered (on the
+    """Double-buffered frame loop for N ranks: while group i's stripes are being exchanged (on the
     collective's own stream) and un-striped (on `side_stream`), group i+1 is already rendering.
-    render_fn(b) renders this rank's stripes into local buffer b; unstripe_fn(b) (rank `dst` only) turns gathered
+    render_fn(b) renders this rank's stripes into local buffer b; exchange_fn(b) starts the collective on buffer b
+    and returns its work handle; unstripe_fn(b) (only on ranks for which `assembles` is true) turns received
     buffer b into frames -- it is called with `side_stream` current, so it must launch on torch's current stream.
     side_stream = None (CPU backends, tests): waits and un-stripes inline.
     Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, rank, world, local, gathered, render_fn, unstripe_fn, dst=0, side_stream=None):
-        self.rank, self.world, self.dst = rank, world, dst
-        self.local, self.gathered = local, gathered
-        self.render_fn, self.unstripe_fn = render_fn, unstripe_fn
+    def __init__(self, render_fn, exchange_fn, unstripe_fn, assembles=True, side_stream=None):
+        self.render_fn, self.exchange_fn, self.unstripe_fn = render_fn, exchange_fn, unstripe_fn
+        self.assembles = assembles
         self.side = side_stream
         self.pending = [None, None]
         self.side_busy = [False, False]   # buffer b was handed to the side stream and not yet waited for
         self.frames_done = 0
 
     def _finish(self, b):
-        """Order 'wait for gather b, then un-stripe it' -- on the side stream if there is one, so that the stream
+        """Order 'wait for exchange b, then un-stripe it' -- on the side stream if there is one, so that the stream
         that renders never waits for a collective or spends time copying rows."""
         work = self.pending[b]
         if work is None:
             return
         if self.side is None:
             work.wait()
-            if self.rank == self.dst:
+            if self.assembles:
                 self.unstripe_fn(b)
         else:
             import torch
             with torch.cuda.stream(self.side):
-                work.wait()               # stream-ordered for nccl: only the side stream waits for the gather
-                if self.rank == self.dst:
+                work.wait()               # stream-ordered for nccl: only the side stream waits for the collective
+                if self.assembles:
                     self.unstripe_fn(b)
             self.side_busy[b] = True
         self.pending[b] = None
@@ -103,15 +134,11 @@ class StripePipeline:
             self.side_busy = [False, False]
 
     def step(self, i):
-        import torch.distributed as dist
         b = i & 1
         self.release(b)                   # buffers b were last used by group i-2
         self.render_fn(b)
-        if self.rank == self.dst:
-            self.pending[b] = dist.gather(self.local[b], list(self.gathered[b].unbind(0)), dst=self.dst, async_op=True)
-        else:
-            self.pending[b] = dist.gather(self.local[b], None, dst=self.dst, async_op=True)
-        self._finish(b ^ 1)               # group i-1: its gather overlapped this group's render
+        self.pending[b] = self.exchange_fn(b)
+        self._finish(b ^ 1)               # group i-1: its exchange overlapped this group's render
 
     def drain(self):
         self.release(0)
