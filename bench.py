@@ -183,7 +183,8 @@ def main():
     hlib = rt.libs()[0]
     rotate = dist_on and args.gather == "rotate"
     # finished frames of one group that THIS rank holds: all F (one GPU, or root0 on rank 0), or its share of a rotating gather
-    my_frames = (lambda c: tiling.frames_per_rank(c, world)[0][rank]) if rotate else (lambda c: c if (rank == 0 or not dist_on) else 0)
+    my_frames = (lambda c: tiling.rotating_plan(c, world)[3][rank]) if rotate else (lambda c: c if (rank == 0 or not dist_on) else 0)
+    slots = tiling.rotating_plan(F, world)[0] if rotate else F   # frame slots per local buffer (>= world for the rotating exchange)
     frames = torch.empty((max(my_frames(F), 1), H, pitch), dtype=torch.uint8, device=dev)
     if dist_on:
         rows = []
@@ -193,9 +194,9 @@ def main():
             rows.append(n.value)
         max_rows = max(rows)
         # per buffer: F frames x this rank's (padded) stripe rows; what comes back is source-rank-major
-        local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+        local = [torch.zeros((slots * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
         if rotate:
-            gathered = [torch.empty((world * max(my_frames(F), 1) * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+            gathered = [torch.empty((world * tiling.rotating_plan(F, world)[1][rank] * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
         else:
             gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
         if rehearsal:                                            # gloo cannot move device tensors: stage through the host
@@ -228,7 +229,7 @@ def main():
         if rehearsal:
             dev_gathered[b].copy_(gathered[b])
         # rank r's block holds its stripes of my `count` frames (rotate) or of all F frame slots (root0)
-        rank_stride = (count if rotate else F) * max_rows * pitch
+        rank_stride = (tiling.rotating_plan(group_count[b], world)[1][rank] if rotate else F) * max_rows * pitch
         rt.check(hlib.rt_unstripe_batch(dev_gathered[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch,
                                         count, W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 

@@ -57,11 +57,22 @@ def gather_stripes(local, gathered, rank, dst=0):
 
 
 def frames_per_rank(F, world):
-    """How the F frames of a group are dealt to assembling ranks when the gather's root rotates: rank d assembles the
-    contiguous block of counts[d] frames starting at offsets[d] (blocks as even as possible, earlier ranks first)."""
+    """F frame slots dealt to `world` assembling ranks in contiguous blocks, as even as possible, earlier ranks first:
+    (counts, offsets)."""
     counts = [F // world + (1 if d < F % world else 0) for d in range(world)]
     offsets = [sum(counts[:d]) for d in range(world)]
     return counts, offsets
+
+
+def rotating_plan(count, world):
+    """Plan of one rotating-root exchange of a group of `count` frames: (slots, counts, offsets, real).
+    The exchange always moves slots = max(count, world) frame slots (slots past `count` carry stale rows), so that no
+    rank ever sends or receives an empty message whatever the group size; rank d assembles slots
+    [offsets[d], offsets[d] + counts[d]), of which the first real[d] hold frames of the group."""
+    slots = max(count, world)
+    counts, offsets = frames_per_rank(slots, world)
+    real = [min(max(count - offsets[d], 0), counts[d]) for d in range(world)]
+    return slots, counts, offsets, real
 
 
 def exchange_to_root(local, gathered, rank, dst=0):
@@ -73,16 +84,16 @@ def exchange_to_root(local, gathered, rank, dst=0):
     return dist.gather(local, None, dst=dst, async_op=True)
 
 
-def exchange_rotating(local, received, F, world, max_rows):
+def exchange_rotating(local, received, count, world, max_rows):
     """Start the gather of a group with a rotating root, fused into ONE all-to-all: the stripes of frame f go to the
-    rank that assembles f (frames_per_rank), so every rank receives 1/world of the pixels and every xGMI link carries
+    rank that assembles f (rotating_plan), so every rank receives 1/world of the pixels and every xGMI link carries
     the same load in both directions instead of seven links converging on one root.
-    local: [F * max_rows, pitch] (frame-major, so the block for destination d is contiguous);
-    received: [world * counts[me] * max_rows, pitch] (source-major).  Returns the async work handle."""
+    local: [>= slots * max_rows, pitch] (frame-major, so the block for destination d is contiguous);
+    received: [>= world * counts[me] * max_rows, pitch] (filled source-major).  Returns the async work handle."""
     import torch.distributed as dist
-    counts, _ = frames_per_rank(F, world)
+    slots, counts, _, _ = rotating_plan(count, world)
     me = dist.get_rank()
-    return dist.all_to_all_single(received[:world * counts[me] * max_rows], local[:F * max_rows],
+    return dist.all_to_all_single(received[:world * counts[me] * max_rows], local[:slots * max_rows],
                                   output_split_sizes=[counts[me] * max_rows] * world,
                                   input_split_sizes=[c * max_rows for c in counts], async_op=True)
 

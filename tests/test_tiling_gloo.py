@@ -111,9 +111,9 @@ def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, ou
     poses = [(0.02 * f, -1.6 - 0.05 * f, 0.2, 0.01 * f, 0, 0) for f in range(nframes)]
     rows = tiling.frame_rows_of(H, stripe, rank, world)
     max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
-    cmax = tiling.frames_per_rank(F, world)[0][rank]
-    local = [torch.zeros((F * max_rows, W * 3), dtype=torch.uint8) for _ in range(2)]
-    received = [torch.zeros((world * max(cmax, 1) * max_rows, W * 3), dtype=torch.uint8) for _ in range(2)]
+    slots_max, counts_max, _, _ = tiling.rotating_plan(F, world)
+    local = [torch.zeros((slots_max * max_rows, W * 3), dtype=torch.uint8) for _ in range(2)]
+    received = [torch.zeros((world * counts_max[rank] * max_rows, W * 3), dtype=torch.uint8) for _ in range(2)]
     mine, state, group_of = {}, {"frame": 0}, [None, None]
 
     def render_fn(b):
@@ -127,10 +127,10 @@ def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, ou
 
     def unstripe_fn(b):
         first, count = group_of[b]
-        counts, offsets = tiling.frames_per_rank(count, world)
+        _, counts, offsets, real = tiling.rotating_plan(count, world)
         c = counts[rank]
         got = received[b][:world * c * max_rows].numpy().reshape(world, c, max_rows, W * 3)
-        for k in range(c):
+        for k in range(real[rank]):
             mine[first + offsets[rank] + k] = tiling.unstripe_host(got[:, k], H, stripe, world).copy()
 
     pipe = tiling.StripePipeline(render_fn, exchange_fn, unstripe_fn)
@@ -169,10 +169,11 @@ def test_two_rank_frame_pipeline(blob5k, tmp_path):
     assert ok == 1 and n == 5
 
 
-@pytest.mark.parametrize("world,F,ngroups,last", [(2, 4, 2, 3), (3, 4, 1, 1)])
+@pytest.mark.parametrize("world,F,ngroups,last", [(2, 4, 2, 3), (3, 4, 1, 1), (3, 2, 2, 0)])
 def test_rotating_root_pipeline(blob5k, tmp_path, world, F, ngroups, last):
     """Every frame of every group is assembled exactly once, on some rank, and equals the single-process frame --
-    including groups whose frame count is not a multiple of the world size and ranks that get no frame of a group."""
+    including groups whose frame count is not a multiple of the world size, ranks that get no frame of a group and groups
+    smaller than the world (the exchange then moves padding slots: no rank ever sends or receives an empty message)."""
     out = str(tmp_path / "rot.npy")
     mp.spawn(_rotating_worker, args=(world, _free_port(), blob5k, 40, 64, 8, F, ngroups, last, out), nprocs=world, join=True)
     ok, n = np.load(out)
