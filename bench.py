@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--gather", default="rotate", choices=["rotate", "root0"],
                     help="N > 1: rotate = the gather's root rotates over the frames of a group, fused into one all-to-all (every rank "
                          "assembles 1/N of the frames); root0 = every frame is gathered to rank 0")
+    ap.add_argument("--one-stream", action="store_true", help="launch every group on the same stream (no overlap of consecutive launches)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 path (stripes, RCCL gather, un-stripe) even with one rank: a check of that path on a one-GPU box, not the N = 1 number")
     ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
@@ -169,6 +170,16 @@ def main():
     cam.set_pose(pose)
     stream = torch.cuda.current_stream().cuda_stream
     cam.set_stream(stream)
+    # Consecutive groups are launched on two alternating streams (one camera object bound to each): the last waves of a
+    # launch -- a few long silhouette rays on an otherwise empty chip -- then overlap the first waves of the next one.
+    two = not args.one_stream and not rehearsal              # (the rehearsal stages through the host on one stream)
+    cstreams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else None
+    cams = [cam, cam]
+    if two:
+        cams = [rt.Camera(W, H, K, D), rt.Camera(W, H, K, D)]
+        for c_, s_ in zip(cams, cstreams):
+            c_.set_pose(pose)
+            c_.set_stream(s_.cuda_stream)
 
     # A launch should carry several frames' worth of work for THIS GPU (with N GPUs a rank renders only 1/N of each
     # frame), so frames go in groups as large as one launch allows (RT_MAX_BATCH = 32): K frames = K // F full groups
@@ -186,6 +197,7 @@ def main():
     my_frames = (lambda c: tiling.rotating_plan(c, world)[3][rank]) if rotate else (lambda c: c if (rank == 0 or not dist_on) else 0)
     slots = tiling.rotating_plan(F, world)[0] if rotate else F   # frame slots per local buffer (>= world for the rotating exchange)
     frames = torch.empty((max(my_frames(F), 1), H, pitch), dtype=torch.uint8, device=dev)
+    frames_b = [frames, torch.empty_like(frames)] if not dist_on else None   # one GPU: groups alternate between two frame sets
     if dist_on:
         rows = []
         for r in range(world):
@@ -206,15 +218,18 @@ def main():
 
     timer = rt.Timer()
 
-    frame_ptrs = [frames[f].data_ptr() for f in range(F)] if not dist_on else None
+    frame_ptrs = [[fb[f].data_ptr() for f in range(F)] for fb in frames_b] if not dist_on else None
     dev_local = (local_dev if rehearsal else local) if dist_on else None
     dev_gathered = (gathered_dev if rehearsal else gathered) if dist_on else None
     local_ptrs = [tiling.batch_local_ptrs(dev_local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if dist_on else None
 
     counts = sorted(set(groups + [F]))                           # a full group and, possibly, the shorter last one
-    render_single_calls = {c: cam.prepared_batch(scene, [pose] * c, frame_ptrs[:c], pitch) for c in counts} if not dist_on else None
-    render_local_calls = {(b, c): cam.prepared_batch(scene, [pose] * c, local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
+    render_single_calls = {(b, c): cams[b].prepared_batch(scene, [pose] * c, frame_ptrs[b][:c], pitch)
+                           for b in range(2) for c in counts} if not dist_on else None
+    render_local_calls = {(b, c): cams[b].prepared_batch(scene, [pose] * c, local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
                           for b in range(2) for c in counts} if dist_on else None
+    timing_call = (cam.prepared_batch(scene, [pose] * F, local_ptrs[0][:F], pitch, stripes=(STRIPE_ROWS, rank, world)) if dist_on else
+                   cam.prepared_batch(scene, [pose] * F, frame_ptrs[0][:F], pitch))      # on `stream`, for the hipEvent timing below
     group_count = [F, F]                                         # frames in the group that currently occupies buffer b
 
     def render_local(b):
@@ -240,11 +255,12 @@ def main():
 
     # un-stripe passes run on their own stream: a rank renders group i+1 while group i is exchanged and re-ordered
     side = torch.cuda.Stream() if dist_on and not rehearsal else None
-    pipe = tiling.StripePipeline(render_local, exchange, unstripe, assembles=rotate or rank == 0, side_stream=side) if dist_on else None
+    pipe = tiling.StripePipeline(render_local, exchange, unstripe, assembles=rotate or rank == 0, side_stream=side,
+                                 compute_streams=cstreams) if dist_on else None
 
     def step_group(i, count):
         if not dist_on:
-            render_single_calls[count]()
+            render_single_calls[(i & 1, count)]()
         else:
             pipe.release(i & 1)                                  # buffer i & 1 is about to be reused: its count changes below
             group_count[i & 1] = count
@@ -277,10 +293,7 @@ def main():
         torch.cuda.synchronize()
         timer.start(stream)
         for _ in range(n):
-            if not dist_on:
-                render_single_calls[F]()
-            else:
-                render_local(0)
+            timing_call()
         timer.stop(stream)
         kernel_ms = timer.elapsed_ms() / n                      # one launch = F frames (this rank's stripes of them)
         single_ms = None
@@ -299,7 +312,8 @@ def main():
     # ---- every rank checks the frames it assembled in the last group against the debug kernel's frame ----
     dbg = rt.render_debug(scene, cam)
     mine = my_frames(groups[-1] if groups else F)
-    frames_host = frames.cpu().numpy().reshape(-1, H, W, 3)
+    last_frames = frames if dist_on else frames_b[(len(groups) - 1) & 1]
+    frames_host = last_frames.cpu().numpy().reshape(-1, H, W, 3)
     frame_ok = bool(all(np.array_equal(frames_host[f], dbg["img"]) for f in range(mine)))
     if dist_on:
         flag = torch.tensor([int(frame_ok)], dtype=torch.int32, device="cpu" if rehearsal else dev)

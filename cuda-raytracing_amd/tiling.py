@@ -105,12 +105,16 @@ class StripePipeline:
     and returns its work handle; unstripe_fn(b) (only on ranks for which `assembles` is true) turns received
     buffer b into frames -- it is called with `side_stream` current, so it must launch on torch's current stream.
     side_stream = None (CPU backends, tests): waits and un-stripes inline.
+    compute_streams = (s0, s1): buffer b's render launch and collective are issued with s_b current (render_fn(b) must
+    launch on s_b), so consecutive render kernels sit on different streams and the tail of one overlaps the start of
+    the next; None = everything on the caller's current stream.
     Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, render_fn, exchange_fn, unstripe_fn, assembles=True, side_stream=None):
+    def __init__(self, render_fn, exchange_fn, unstripe_fn, assembles=True, side_stream=None, compute_streams=None):
         self.render_fn, self.exchange_fn, self.unstripe_fn = render_fn, exchange_fn, unstripe_fn
         self.assembles = assembles
         self.side = side_stream
+        self.compute = compute_streams
         self.pending = [None, None]
         self.side_busy = [False, False]   # buffer b was handed to the side stream and not yet waited for
         self.frames_done = 0
@@ -144,11 +148,19 @@ class StripePipeline:
             torch.cuda.current_stream().wait_stream(self.side)
             self.side_busy = [False, False]
 
-    def step(self, i):
-        b = i & 1
+    def _issue(self, b):
         self.release(b)                   # buffers b were last used by group i-2
         self.render_fn(b)
         self.pending[b] = self.exchange_fn(b)
+
+    def step(self, i):
+        b = i & 1
+        if self.compute is None:
+            self._issue(b)
+        else:
+            import torch
+            with torch.cuda.stream(self.compute[b]):
+                self._issue(b)
         self._finish(b ^ 1)               # group i-1: its exchange overlapped this group's render
 
     def drain(self):
