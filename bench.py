@@ -278,6 +278,7 @@ def main():
     t0 = time.perf_counter()
     for i, c in enumerate(groups):
         step_group(i, c)
+    t_issue = time.perf_counter() - t0                           # host time to issue all groups (must stay below the GPU's)
     sync()
     dt = time.perf_counter() - t0
     if dist_on:
@@ -349,7 +350,7 @@ def main():
                        "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
                                       % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames)" % F if rotate
                                                            else ", one RCCL gather to rank 0 per %d frames" % F) if dist_on else ""),
-                       "frames_per_launch": F, "single_frame_launch_ms": None if single_ms is None else round(single_ms, 4),
+                       "frames_per_launch": F, "host_issue_ms_per_launch": round(t_issue / max(len(groups), 1) * 1e3, 3), "single_frame_launch_ms": None if single_ms is None else round(single_ms, 4),
                        "coverage": round(st["hits"] / st["rays"], 4),
                        "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
                        "algorithmic_bytes_per_ray": round(alg_bytes / st["rays"], 1)},

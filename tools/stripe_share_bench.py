@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What one rank of an N-GPU run does between collectives, timed on one GPU: rank 0's stripes of F frames per launch,
-launches issued back to back on one stream or alternating between two.   python tools/stripe_share_bench.py [N] [F]"""
+launches issued back to back on one stream or alternating between two.   python tools/stripe_share_bench.py [N] [F] [stripe_rows]"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,8 @@ scenes = importlib.import_module("cuda-raytracing_amd.scenes")
 tiling = importlib.import_module("cuda-raytracing_amd.tiling")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-W, H, stripe = 1920, 1080, 16
+W, H = 1920, 1080
+stripe = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 mesh = rt.Mesh.load_obj(os.path.join(ROOT, ".scene_cache", "blob70k.obj"))
 scene = rt.Scene(); scene.add_material(scenes.C2["albedo"]); scene.add_mesh(mesh); scene.add_mesh_instance(0, 0); scene.upload_to_device()
 max_rows = max(tiling.stripe_rows(H, stripe, r, N) for r in range(N))
