@@ -70,6 +70,21 @@ def test_stripe_rows_python_mirror(rt):
         assert tot == H
 
 
+def test_rotating_gather_plan():
+    """tiling.rotating_plan: every frame of a group has exactly one assembling rank, blocks are contiguous and as even as
+    possible, and a group smaller than the world is padded so that no rank gets an empty message."""
+    import importlib
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    for world in (1, 2, 3, 4, 8):
+        for count in (1, 2, 3, 7, 8, 20, 31, 32):
+            slots, counts, offsets, real = tiling.rotating_plan(count, world)
+            assert slots == max(count, world) and sum(counts) == slots and min(counts) >= 1
+            assert max(counts) - min(counts) <= 1 and offsets == [sum(counts[:d]) for d in range(world)]
+            assert sum(real) == count and all(0 <= r <= c for r, c in zip(real, counts))
+            owners = [d for f in range(count) for d in range(world) if offsets[d] <= f < offsets[d] + real[d]]
+            assert len(owners) == count and owners == sorted(owners)
+
+
 def test_host_math_golden(rt):
     _, s = rt.libs()
     g = np.load(os.path.join(GOLDEN, "l0_math.npz"))
