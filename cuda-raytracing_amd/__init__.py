@@ -74,6 +74,7 @@ RT_HOST_SYMBOLS = [
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
     "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
     "rth_camera_render_scene_ex", "rth_xorwow", "rth_save_png", "rth_write_png_bgr",
+    "rth_read_image_bgr", "rth_zlib_inflate", "rth_overlay_text_bgr", "rth_display_image", "rth_on_mouse", "rth_on_key",
     "rth_camera_params", "rth_q_rsqrt", "rth_atanf", "rth_normalize", "rth_invert_lre", "rth_apply_lre", "rth_euler2quat",
     "rth_apply_quat", "rth_invert_intrinsic", "rth_last_error"]
 
@@ -167,6 +168,15 @@ def _declare(h, s):
     s.rth_camera_render_scene_ex.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int]
     s.rth_save_png.argtypes = [C.c_char_p, _vp, C.c_int32, C.c_int32, C.c_size_t]
     s.rth_write_png_bgr.argtypes = [C.c_char_p, _vp, C.c_int32, C.c_int32, C.c_size_t]
+    s.rth_read_image_bgr.argtypes = [C.c_char_p, _vp, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    s.rth_zlib_inflate.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    s.rth_overlay_text_bgr.argtypes = [_vp, C.c_int32, C.c_int32, C.c_size_t, C.c_char_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_uint8, C.c_uint8, C.c_uint8]
+    s.rth_overlay_text_bgr.restype = None
+    s.rth_display_image.argtypes = [_vp, C.c_int32, C.c_int32, C.c_size_t, C.c_double, C.c_char_p]
+    s.rth_on_mouse.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]
+    s.rth_on_mouse.restype = None
+    s.rth_on_key.argtypes = [C.POINTER(C.c_float), C.c_int32]
     s.rth_xorwow.restype = C.c_uint32
     s.rth_xorwow.argtypes = [C.c_uint64, C.c_int32, _vp, _vp]
     s.rth_q_rsqrt.restype = C.c_float
@@ -269,17 +279,20 @@ class Scene:
         if not self.h:
             raise RtError("scene creation failed")
 
-    def add_material(self, albedo, texture_bgr=None, ppm=None, roughness=0.0, metallic=0.0, illumination=0.0):
+    def add_material(self, albedo, texture_bgr=None, ppm=None, roughness=0.0, metallic=0.0, illumination=0.0, texture_path=None):
+        """texture_path (or its older name ppm): a PNG, baseline-JPEG or binary-PPM file for Material::upload_texture;
+        texture_bgr: [h, w, 3] uint8 B,G,R pixels."""
         s = libs()[1]
-        self._nmat = getattr(self, "_nmat", 0) + 1
         a = _fa(albedo)
-        if ppm is not None:
-            check(s.rth_scene_add_material_ppm(self.h, _fp(a), os.fsencode(ppm)), "add_material(ppm)")
+        path = texture_path if texture_path is not None else ppm
+        if path is not None:
+            check(s.rth_scene_add_material_ppm(self.h, _fp(a), os.fsencode(path)), "add_material(texture file)")
         elif texture_bgr is not None:
             t = np.ascontiguousarray(texture_bgr, np.uint8)
             check(s.rth_scene_add_material(self.h, _fp(a), t.ctypes.data, t.shape[1], t.shape[0], t.strides[0]), "add_material")
         else:
             check(s.rth_scene_add_material(self.h, _fp(a), None, 0, 0, 0), "add_material")
+        self._nmat = getattr(self, "_nmat", 0) + 1
         check(s.rth_scene_set_material_params(self.h, self._nmat - 1, roughness, metallic, illumination), "set_material_params")
 
     def add_mesh(self, mesh):
@@ -477,6 +490,18 @@ def render_ex(scene, camera):
     out = dict(img=img.to_host().reshape(H, W, 3), total_pops=pops.to_host(np.int32).reshape(H, W))
     img.free()
     pops.free()
+    return out
+
+
+def read_image(path):
+    """PNG / baseline JPEG / binary PPM file -> [h, w, 3] uint8 B,G,R (the decoders behind Material::upload_texture)."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    host = libs()[1]
+    rc = host.rth_read_image_bgr(os.fsencode(path), None, 0, C.byref(w), C.byref(h))
+    if rc:
+        raise RtError("read_image(%s): %s" % (path, host.rth_last_error().decode()))
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    check(host.rth_read_image_bgr(os.fsencode(path), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)), "read_image")
     return out
 
 

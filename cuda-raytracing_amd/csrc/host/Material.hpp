@@ -1,7 +1,7 @@
 // Material.hpp -- surface description (Material.hpp:6-43).  Only albedo and the texture are read
 // by the path today (roughness / metallic / illumination are dead in the reference as well).
 // The texture lives on the host as tight BGR bytes until Scene::upload_to_device copies it;
-// upload_texture() reads binary PPM (P6) because the image has no OpenCV.
+// upload_texture() decodes PNG, baseline JPEG and binary PPM itself (ImageIO.hpp) because the image has no OpenCV.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -18,6 +18,6 @@ struct Material {
     int texture_height = 0;
 
     Material() : roughness(0.0f), albedo(make_float3(1.0f, 1.0f, 1.0f)), metallic(0.0f), illumination(0.0f) {}
-    bool upload_texture(const std::string& path);                               // P6 PPM -> BGR
+    bool upload_texture(const std::string& path);                               // PNG / JPEG / P6 PPM -> BGR
     void set_texture_bgr(const uint8_t* bgr, int width, int height, size_t pitch);
 };

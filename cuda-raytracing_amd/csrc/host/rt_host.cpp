@@ -14,6 +14,7 @@
 
 #include "../../../include/rt_hip.h"
 #include "Camera.h"
+#include "ImageIO.hpp"
 #include "OBJLoader.hpp"
 #include "Scene.h"
 
@@ -231,35 +232,11 @@ void Material::set_texture_bgr(const uint8_t* bgr, int width, int height, size_t
 
 bool Material::upload_texture(const std::string& path)
 {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return false;
-    std::string magic;
-    int w = 0, h = 0, maxv = 0;
-    auto next_token = [&](std::string& out) {
-        out.clear();
-        int c;
-        while ((c = f.get()) != EOF) {
-            if (c == '#') { while ((c = f.get()) != EOF && c != '\n') {} continue; }
-            if (!isspace(c)) { out.push_back((char)c); break; }
-        }
-        while ((c = f.peek()) != EOF && !isspace(c)) out.push_back((char)f.get());
-        return !out.empty();
-    };
-    std::string tok;
-    if (!next_token(magic) || magic != "P6") return false;
-    if (!next_token(tok)) return false;
-    w = atoi(tok.c_str());
-    if (!next_token(tok)) return false;
-    h = atoi(tok.c_str());
-    if (!next_token(tok)) return false;
-    maxv = atoi(tok.c_str());
-    if (w <= 0 || h <= 0 || maxv != 255) return false;
-    f.get();                                                           // single whitespace after maxval
-    std::vector<uint8_t> rgb((size_t)w * h * 3);
-    f.read((char*)rgb.data(), (std::streamsize)rgb.size());
-    if ((size_t)f.gcount() != rgb.size()) return false;
-    texture.resize(rgb.size());
-    for (size_t i = 0; i < (size_t)w * h; i++) { texture[3 * i] = rgb[3 * i + 2]; texture[3 * i + 1] = rgb[3 * i + 1]; texture[3 * i + 2] = rgb[3 * i]; }
+    // Material.hpp:29-43 decodes with cv::imread; here: PNG, baseline JPEG or binary PPM by file signature (ImageIO.hpp)
+    std::vector<uint8_t> bgr;
+    int w = 0, h = 0;
+    if (!read_image_bgr(path, bgr, w, h)) return false;
+    texture.swap(bgr);
     texture_width = w; texture_height = h;
     return true;
 }

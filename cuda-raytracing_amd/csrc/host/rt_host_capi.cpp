@@ -6,6 +6,7 @@
 #include "../../../include/rt_hip.h"
 #include "../../../include/rt_host.h"
 #include "Camera.h"
+#include "ImageIO.hpp"
 #include "OBJLoader.hpp"
 #include "Scene.h"
 
@@ -201,6 +202,62 @@ void rth_camera_params(const RthCamera* c, void* out)
 
 int rth_save_png(const char* path, const void* d_img, int32_t width, int32_t height, size_t pitch)
 { return save_png(path, (const uchar3*)d_img, width, height, pitch, nullptr); }
+int rth_read_image_bgr(const char* path, uint8_t* bgr, size_t capacity, int32_t* width, int32_t* height)
+{
+    if (!path || !width || !height) return RT_E_INVALID;
+    std::vector<uint8_t> px;
+    int w = 0, h = 0;
+    std::string err;
+    if (!read_image_bgr(path, px, w, h, &err)) { g_err = "rth_read_image_bgr: " + err; return RT_E_INVALID; }
+    *width = w; *height = h;
+    if (bgr) {
+        if (capacity < px.size()) return RT_E_INVALID;
+        memcpy(bgr, px.data(), px.size());
+    }
+    return RT_OK;
+}
+int rth_zlib_inflate(const uint8_t* src, size_t n, uint8_t* out, size_t capacity, size_t* out_n)
+{
+    if (!src || !out_n) return RT_E_INVALID;
+    std::vector<uint8_t> o;
+    std::string err;
+    if (!zlib_inflate(src, n, o, &err)) { g_err = "rth_zlib_inflate: " + err; return RT_E_INVALID; }
+    *out_n = o.size();
+    if (out) {
+        if (capacity < o.size()) return RT_E_INVALID;
+        memcpy(out, o.data(), o.size());
+    }
+    return RT_OK;
+}
+void rth_overlay_text_bgr(uint8_t* bgr, int32_t width, int32_t height, size_t pitch, const char* text, int32_t x, int32_t y,
+                          int32_t scale, uint8_t b, uint8_t g, uint8_t r)
+{
+    overlay_text_bgr(bgr, width, height, pitch, text ? text : "", x, y, scale, b, g, r);
+}
+int rth_display_image(const void* d_img, int32_t width, int32_t height, size_t pitch, double fps, const char* path)
+{
+    MouseParams m;
+    m.pose = nullptr;
+    return display_image((const uchar3*)d_img, width, height, pitch, fps, m, path ? path : "out.png");
+}
+void rth_on_mouse(float* pose6, int32_t* state4, int32_t event, int32_t x, int32_t y)
+{
+    lre pose = LRE(pose6);
+    MouseParams m;
+    m.last_x = state4[0]; m.last_y = state4[1]; m.has_last = state4[2] != 0; m.is_down = state4[3] != 0; m.pose = &pose;
+    on_mouse(event, x, y, 0, &m);
+    state4[0] = m.last_x; state4[1] = m.last_y; state4[2] = m.has_last ? 1 : 0; state4[3] = m.is_down ? 1 : 0;
+    pose6[0] = pose.x; pose6[1] = pose.y; pose6[2] = pose.z; pose6[3] = pose.yaw; pose6[4] = pose.pitch; pose6[5] = pose.roll;
+}
+int rth_on_key(float* pose6, int32_t key)
+{
+    lre pose = LRE(pose6);
+    MouseParams m;
+    m.pose = &pose;
+    const bool go_on = on_key(key, m);
+    pose6[0] = pose.x; pose6[1] = pose.y; pose6[2] = pose.z; pose6[3] = pose.yaw; pose6[4] = pose.pitch; pose6[5] = pose.roll;
+    return go_on ? 1 : 0;
+}
 int rth_write_png_bgr(const char* path, const uint8_t* bgr, int32_t width, int32_t height, size_t pitch)
 { return write_png_bgr(path, bgr, width, height, pitch); }
 float rth_q_rsqrt(float x) { return Q_rsqrt(x); }

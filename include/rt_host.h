@@ -85,6 +85,22 @@ void rth_camera_params(const RthCamera *c, void *out_RtCameraParams);
 int rth_save_png(const char *path, const void *d_img, int32_t width, int32_t height, size_t pitch);
 int rth_write_png_bgr(const char *path, const uint8_t *bgr, int32_t width, int32_t height, size_t pitch);
 
+/* ---- image files and the display step without OpenCV (csrc/host/ImageIO.hpp) ----
+ * rth_read_image_bgr: PNG / baseline JPEG / binary PPM by signature (the decoders behind Material::upload_texture, which
+ * the reference does with cv::imread, Material.hpp:29-43).  bgr may be NULL to query the size only; otherwise it
+ * receives width*height*3 tight B,G,R bytes if `capacity` allows (RT_E_INVALID if not, or if the file is refused). */
+int rth_read_image_bgr(const char *path, uint8_t *bgr, size_t capacity, int32_t *width, int32_t *height);
+int rth_zlib_inflate(const uint8_t *src, size_t n, uint8_t *out, size_t capacity, size_t *out_n);
+/* text with its bottom-left corner at (x, y), built-in 5x7 font scaled by `scale` (the cv::putText of kernel.cu:41) */
+void rth_overlay_text_bgr(uint8_t *bgr, int32_t width, int32_t height, size_t pitch, const char *text, int32_t x, int32_t y,
+                          int32_t scale, uint8_t b, uint8_t g, uint8_t r);
+/* display_image (kernel.cu:30-43): download, "FPS: ..." overlay, PNG file */
+int rth_display_image(const void *d_img, int32_t width, int32_t height, size_t pitch, double fps, const char *path);
+/* on_mouse (kernel.cu:112-139) / the key handling of kernel.cu:51-103 on a pose (6 floats) and the handler's state
+ * {last_x, last_y, has_last, is_down}; rth_on_key returns 0 for 'q' (quit), 1 otherwise */
+void rth_on_mouse(float *pose6, int32_t *state4, int32_t event, int32_t x, int32_t y);
+int rth_on_key(float *pose6, int32_t key);
+
 /* host math with the reference's names, for parity tests (utils.hpp / transforms.hpp) */
 float rth_q_rsqrt(float x);
 float rth_atanf(float x);                       /* the restated atanf the kernels use */

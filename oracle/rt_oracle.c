@@ -1055,6 +1055,35 @@ void orc_apply_quat(const float *q, const float *v, float *o)
 void orc_apply_euler(const float *e, const float *v, float *o) { f3 r = apply_euler(mk3(e[0], e[1], e[2]), mk3(v[0], v[1], v[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
 void orc_invert_lre(const float *l, float *o) { lre_t a, r; memcpy(&a, l, sizeof a); r = invert_lre(a); memcpy(o, &r, sizeof r); }
 void orc_apply_lre(const float *l, const float *v, float *o) { lre_t a; f3 r; memcpy(&a, l, sizeof a); r = apply_lre(a, mk3(v[0], v[1], v[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+/* on_mouse, kernel.cu:112-139: state4 = {last_x, last_y, has_last, is_down}; cv::EVENT_MOUSEMOVE 0, LBUTTONDOWN 1, LBUTTONUP 4 */
+void orc_on_mouse(float *pose6, int32_t *state4, int event, int x, int y)
+{
+    if (event == 1) state4[3] = 1;
+    else if (event == 4) state4[3] = 0;
+    else if (event == 0) {
+        if (state4[2] && state4[3]) {
+            int dx = x - state4[0], dy = y - state4[1];
+            pose6[3] = (float)((double)pose6[3] + dx * 0.001);          /* pose->yaw += dx * 0.001 */
+            pose6[4] = (float)((double)pose6[4] + dy * -0.001);         /* pose->pitch += dy * -0.001 */
+        }
+        state4[0] = x; state4[1] = y; state4[2] = 1;
+    }
+}
+/* the key handling of kernel.cu:51-103 (commented out in the snapshot): returns 0 for 'q', 1 otherwise */
+int orc_on_key(float *pose6, int key)
+{
+    f3 step, np; lre_t pose, inv;
+    if (key == 'w') step = mk3(0.0f, 0.1f, 0.0f);
+    else if (key == 's') step = mk3(0.0f, -0.1f, 0.0f);
+    else if (key == 'a') step = mk3(-0.1f, 0.0f, 0.0f);
+    else if (key == 'd') step = mk3(0.1f, 0.0f, 0.0f);
+    else return key == 'q' ? 0 : 1;
+    memcpy(&pose, pose6, sizeof pose);
+    inv = invert_lre(pose);
+    np = apply_lre(inv, step);
+    pose6[0] = np.x; pose6[1] = np.y; pose6[2] = np.z;
+    return 1;
+}
 void orc_lre2homo(const float *l, float *o16) { lre_t a; m44 h; memcpy(&a, l, sizeof a); h = lre2homo(a); memcpy(o16, &h, sizeof h); }
 void orc_invert_intrinsic(const float *K9, float *o9) { m33 k, r; memcpy(&k, K9, sizeof k); r = invert_intrinsic(&k); memcpy(o9, &r, sizeof r); }
 float orc_aabb_ray_intersects(const float *bmin, const float *bmax, const float *o, const float *d)

@@ -69,6 +69,35 @@ def test_multi_instance_textured(rt, orc, scenes, blob5k):
              scenes.D_REF, m["pose"])
 
 
+def test_texture_files_and_display_image(rt, orc, scenes, blob5k, tmp_path):
+    """Material::upload_texture from a JPEG / PNG file (the reference: cv::imread) renders the same frame as the oracle
+    given the decoded pixels; display_image (kernel.cu:30-43) writes that frame with the FPS overlay as a PNG."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "images")
+    W, H = 320, 200
+    K, pose = scenes.scaled_K(W), sd.MULTI_CAMERA["pose"]
+    for name in ("jpg_420_q35_opt.jpg", "png_P.png"):
+        tex = rt.read_image(os.path.join(gold, name))
+        so = sd.SceneDesc([((1.0, 1.0, 1.0), tex)], [("obj", blob5k)], [(0, 0, (0,) * 6, (1, 1, 1))]).build_oracle(orc)
+        ref = so.render(W, H, K, scenes.D_REF, pose, threads=8)["img"]
+        sp = rt.Scene()
+        sp.add_material((1.0, 1.0, 1.0), texture_path=os.path.join(gold, name))
+        sp.add_mesh(rt.Mesh.load_obj(blob5k))
+        sp.add_mesh_instance(0, 0)
+        sp.upload_to_device()
+        cam = _camera(rt, scenes, W, H, K, pose)
+        img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+        cam.render_scene(sp, img.ptr, img.pitch, synchronize=True)
+        got = img.to_host().reshape(H, W, 3)
+        assert np.array_equal(got, ref), name
+        assert len(np.unique(got.reshape(-1, 3), axis=0)) > 20                  # the texture really is on screen
+    out = str(tmp_path / "out.png")
+    rt.check(rt.libs()[1].rth_display_image(img.ptr, W, H, img.pitch, 123.456789, os.fsencode(out)))
+    shown = rt.read_image(out)
+    expect = got.copy()
+    rt.libs()[1].rth_overlay_text_bgr(expect.ctypes.data, W, H, expect.strides[0], b"FPS: 123.456789", 10, 30, 3, 0, 255, 0)
+    assert np.array_equal(shown, expect) and not np.array_equal(shown, got)
+
+
 def test_ragged_sizes(rt, orc, scenes, blob5k):
     """Widths/heights that are not multiples of the 16x16 tile, down to 1x1."""
     for w, h in [(1, 1), (17, 9), (250, 131)]:

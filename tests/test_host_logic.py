@@ -325,3 +325,103 @@ def test_scene_upload_validates_its_input(rt, blob5k):
     tex = np.zeros((4, 4, 3), np.uint8)
     bad_mat = rt.RtMaterialDesc(0.0, (C.c_float * 3)(1, 1, 1), 0.0, 0.0, tex.ctypes.data, 4, 4, 5)   # pitch < width * 3
     assert upload(d, material=bad_mat) == -1
+
+
+# ---------------------------------------------------------------- image files, overlay, interaction
+
+def test_image_decoders_match_committed_fixtures(rt):
+    """PNG (all colour types Pillow writes, 1/8/16 bit) and baseline JPEG (4:4:4, 4:2:2, 4:2:0, grey, custom Huffman
+    tables, restart intervals, 1x1) decode to exactly the bytes libpng / libjpeg-turbo produce
+    (tests/golden/make_image_fixtures.py); progressive JPEG is refused."""
+    d = os.path.join(GOLDEN, "images")
+    exp = np.load(os.path.join(d, "images_expected.npz"))
+    assert len(exp.files) >= 14
+    for name in exp.files:
+        got = rt.read_image(os.path.join(d, name))
+        assert got.shape == exp[name].shape and np.array_equal(got, exp[name]), name
+    with pytest.raises(rt.RtError, match="progressive"):
+        rt.read_image(os.path.join(d, "refused_progressive.jpg"))
+    with pytest.raises(rt.RtError):
+        rt.read_image(os.path.join(d, "images_expected.npz"))
+
+
+def test_image_decoders_against_pillow_live(rt, tmp_path):
+    """The same comparison on freshly written files of odd sizes, when Pillow is importable (it is in this image)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11)
+    for k, (w, h) in enumerate([(23, 40), (96, 8), (8, 96), (129, 67)]):
+        rgb = np.clip(rng.normal(128, 60, (h, w, 3)) * 0.3 + np.linspace(0, 255, w)[None, :, None] * 0.7, 0, 255).astype(np.uint8)
+        for ss in (0, 1, 2):
+            p = str(tmp_path / ("a%d_%d.jpg" % (k, ss)))
+            Image.fromarray(rgb).save(p, quality=40 + 20 * ss, subsampling=ss)
+            assert np.array_equal(rt.read_image(p), np.asarray(Image.open(p).convert("RGB"))[..., ::-1]), (w, h, ss)
+        p = str(tmp_path / ("a%d.png" % k))
+        Image.fromarray(rgb).save(p, compress_level=k * 3)               # level 0 = stored blocks, 9 = dynamic Huffman
+        assert np.array_equal(rt.read_image(p), rgb[..., ::-1])
+
+
+def test_zlib_inflate_against_zlib(rt):
+    import zlib
+    host = rt.libs()[1]
+    rng = np.random.default_rng(3)
+    for data in [b"", b"a", b"abc" * 1000, rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(), bytes(range(256)) * 300,
+                 rng.integers(0, 4, 50000, dtype=np.uint8).tobytes()]:
+        for level in (0, 1, 6, 9):
+            z = zlib.compress(data, level)
+            src = np.frombuffer(z, np.uint8)
+            out = np.zeros(max(len(data), 1), np.uint8)
+            n = C.c_size_t(0)
+            rt.check(host.rth_zlib_inflate(src.ctypes.data, len(z), out.ctypes.data, out.nbytes, C.byref(n)))
+            assert n.value == len(data) and out[:n.value].tobytes() == data
+    bad = bytearray(zlib.compress(b"hello world, hello world, hello world", 6))
+    bad[-1] ^= 1                                                       # checksum
+    n = C.c_size_t(0)
+    assert host.rth_zlib_inflate(np.frombuffer(bytes(bad), np.uint8).ctypes.data, len(bad), None, 0, C.byref(n)) != 0
+
+
+def test_texture_from_png_and_jpeg(rt, tmp_path):
+    """Material::upload_texture takes PNG / JPEG / PPM by signature (the reference: cv::imread, Material.hpp:29-43)."""
+    d = os.path.join(GOLDEN, "images")
+    sc = rt.Scene()
+    for name in ("png_RGB.png", "jpg_420_q75.jpg"):
+        sc.add_material((1, 1, 1), texture_path=os.path.join(d, name))
+    with pytest.raises(rt.RtError):
+        sc.add_material((1, 1, 1), texture_path=os.path.join(d, "refused_progressive.jpg"))
+
+
+def test_overlay_text(rt):
+    host = rt.libs()[1]
+    img = np.zeros((40, 200, 3), np.uint8)
+    host.rth_overlay_text_bgr(img.ctypes.data, 200, 40, img.strides[0], b"FPS: 12.5", 10, 30, 3, 0, 255, 0)
+    on = (img == (0, 255, 0)).all(-1)
+    assert on.any() and not img[..., 0].any() and not img[..., 2].any()
+    ys, xs = np.nonzero(on)
+    assert ys.min() == 30 - 21 and ys.max() == 29 and xs.min() == 10 and xs.max() < 10 + 9 * 18   # 7 rows x scale 3 above y = 30
+    cell = on[9:30, 10:25]                                              # 'F': full top row, full left column
+    assert cell[0].all() and cell[:, 0].all() and not cell[20, 6:].any()
+    clipped = np.zeros((10, 10, 3), np.uint8)
+    host.rth_overlay_text_bgr(clipped.ctypes.data, 10, 10, clipped.strides[0], b"W?", -4, 5, 2, 9, 9, 9)  # partly outside: no fault
+    assert clipped.any()
+
+
+def test_interaction_handlers_match_oracle(rt, oracle):
+    """on_mouse (kernel.cu:112-139) and the WASD handling (kernel.cu:51-103): same pose bits as the oracle."""
+    host, olib = rt.libs()[1], oracle.lib
+    olib.orc_on_mouse.restype = None
+    olib.orc_on_key.restype = C.c_int
+    rng = np.random.default_rng(8)
+    pose_a = np.array([0.3, -2.0, 0.7, 0.4, -0.2, 0.1], np.float32)
+    pose_b = pose_a.copy()
+    st_a, st_b = np.zeros(4, np.int32), np.zeros(4, np.int32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    events = [(0, 100, 100), (1, 100, 100)] + [(0, int(x), int(y)) for x, y in rng.integers(0, 800, (40, 2))] + [(4, 0, 0), (0, 5, 5), (0, 700, 20)]
+    for ev, x, y in events:
+        host.rth_on_mouse(fp(pose_a), ip(st_a), ev, x, y)
+        olib.orc_on_mouse(fp(pose_b), ip(st_b), ev, x, y)
+        assert pose_a.tobytes() == pose_b.tobytes() and np.array_equal(st_a, st_b)
+    assert pose_a[3] != np.float32(0.4) and st_a[3] == 0
+    for key in "wwadsdwq x":
+        ra = host.rth_on_key(fp(pose_a), ord(key))
+        rb = olib.orc_on_key(fp(pose_b), ord(key))
+        assert ra == rb == (0 if key == "q" else 1) and pose_a.tobytes() == pose_b.tobytes()
