@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--scene", default="blob70k", choices=["blob70k", "blob5k", "atrium"])
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (rt_render_batch)")
     ap.add_argument("--ex", default=None, help="spp,bounces,lighting: time the extension kernel (rt_render_ex) instead")
+    ap.add_argument("--streams", type=int, default=1, help="issue successive launches round-robin on this many HIP streams (torch streams)")
     ap.add_argument("--check", action="store_true", help="compare the frame hash with the debug kernel's")
     a = ap.parse_args()
     rt.build()
@@ -50,18 +51,44 @@ def main():
             spp, bounces, lighting = (int(v) for v in a.ex.split(","))
             cam.set_options(spp, bounces, lighting)
 
-        def go():
-            if a.ex or a.batch == 1:
-                cam.render_scene(scene, img.ptr, img.pitch)
-            else:
-                cam.render_scene_batch(scene, [pose] * a.batch, ptrs, img.pitch)
+        if a.streams > 1:                                  # one camera object (and frame set) per stream
+            import torch
+            streams = [torch.cuda.Stream() for _ in range(a.streams)]
+            cams, sets = [], []
+            for st in streams:
+                c = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+                c.set_pose(pose)
+                c.set_stream(st.cuda_stream)
+                cams.append(c)
+                sets.append([rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(a.batch)])
+            calls = [c.prepared_batch(scene, [pose] * a.batch, [b.ptr for b in bs], img.pitch) for c, bs in zip(cams, sets)]
+            state = {"i": 0}
+
+            def go():
+                calls[state["i"] % a.streams]()
+                state["i"] += 1
+        else:
+            def go():
+                if a.ex or a.batch == 1:
+                    cam.render_scene(scene, img.ptr, img.pitch)
+                else:
+                    cam.render_scene_batch(scene, [pose] * a.batch, ptrs, img.pitch)
         for _ in range(5):
             go()
-        t.start()
-        for _ in range(a.iters):
-            go()
-        t.stop()
-        ms = t.elapsed_ms() / a.iters / a.batch
+        if a.streams > 1:                                  # events on one stream cannot bracket several: wall clock
+            import time
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.iters):
+                go()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / a.iters / a.batch
+        else:
+            t.start()
+            for _ in range(a.iters):
+                go()
+            t.stop()
+            ms = t.elapsed_ms() / a.iters / a.batch
         line = "%-6s %.4f ms  %.1f Mrays/s" % (name, ms, W * H / ms / 1e3)
         if a.ex:
             import hashlib
