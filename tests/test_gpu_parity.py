@@ -113,6 +113,58 @@ def test_large_leaves_and_duplicates(rt, orc, scenes):
     _compare(rt, orc, d, 160, 120, scenes.scaled_K(160), scenes.D_REF, (0.0, -2.5, 0.0, 0, 0, 0))
 
 
+@pytest.mark.parametrize("kind", ["degenerate", "axis_aligned", "huge", "tiny", "mixed"])
+def test_degenerate_and_extreme_geometry(rt, orc, scenes, kind):
+    """Inputs on which the arithmetic leaves the comfortable range -- zero-area triangles (NaN normals), triangles and rays
+    exactly parallel to the axes (0 * inf in the slab test), coordinates near 1e18 (squares overflow) and near 1e-20
+    (products underflow to denormals): every plane and the RGB must still equal the oracle's bit for bit."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    rng = np.random.default_rng({"degenerate": 1, "axis_aligned": 2, "huge": 3, "tiny": 4, "mixed": 5}[kind])
+
+    def tris_from(v):
+        out = np.stack([o.tri_from_vertices(np.asarray(t, np.float32).ravel()) for t in v])
+        out[:, 12:18] = rng.uniform(0, 1, (len(out), 6)).astype(np.float32)
+        return out
+
+    normal = sd.random_triangles(40, seed=77, spread=0.8, size=0.4)
+    pose, scale = (0.0, -3.0, 0.0, 0, 0, 0), (1, 1, 1)
+    if kind == "degenerate":
+        v = rng.uniform(-1, 1, (30, 3, 3)).astype(np.float32)
+        v[:10, 1] = v[:10, 0]                                            # two equal vertices
+        v[10:20, 2] = v[10:20, 0] + 2 * (v[10:20, 1] - v[10:20, 0])      # collinear
+        v[20:25] = v[20:25, :1]                                          # a point
+        tris = np.concatenate([tris_from(v), normal])
+    elif kind == "axis_aligned":
+        v = np.zeros((24, 3, 3), np.float32)
+        for i in range(24):
+            ax = i % 3
+            p = rng.integers(-2, 3, (3, 3)).astype(np.float32) * 0.5
+            p[:, ax] = np.float32(rng.integers(-1, 2)) * 0.5             # the triangle lies in a plane x / y / z = const: flat boxes
+            v[i] = p
+        tris = tris_from(v)
+        pose = (0.0, -3.0, 0.0, 0, 0, 0)
+    elif kind == "huge":
+        v = (rng.uniform(-1, 1, (30, 3, 3)) * 1e18).astype(np.float32)
+        v[:, :, 1] += np.float32(2e18)
+        tris = np.concatenate([tris_from(v), normal])
+    elif kind == "tiny":
+        v = (rng.uniform(-1, 1, (30, 3, 3)) * 1e-20).astype(np.float32)
+        v[:, :, 1] += np.float32(1e-19)
+        tris = tris_from(v)
+        pose = (0.0, -1e-19, 0.0, 0, 0, 0)
+    else:
+        v = rng.uniform(-1, 1, (40, 3, 3)).astype(np.float32)
+        v[:8] *= np.float32(1e12); v[8:16] *= np.float32(1e-12); v[16:20, 1] = v[16:20, 0]
+        tris = np.concatenate([tris_from(v), normal])
+        scale = (0.5, 1.0, 2.0)
+    d = sd.SceneDesc([((0.3, 0.6, 0.9), sd.checker_texture(8, 8, seed=1))], [("tris", tris)], [(0, 0, (0,) * 6, scale)])
+    img, ref = _compare(rt, orc, d, 96, 64, scenes.scaled_K(96), scenes.D_REF, pose)
+    hits = int((ref["hit_tri"] >= 0).sum())
+    print(kind, "hits", hits, "tri tests", int(ref["tris"].sum()), "inside", int(ref["inside"].sum()))
+    assert ref["tris"].sum() > 0 and (hits > 0 or kind == "tiny")
+
+
 def test_exact_uv_path(rt, orc, scenes):
     """uv values near FLT_MAX switch the kernel to the per-candidate uv test of raycast.cu:96."""
     tris = sd.random_triangles(50, seed=5, spread=0.6, size=0.5)
