@@ -328,13 +328,22 @@ def main():
         alg_bytes = algorithmic_bytes(st)                   # per frame
         share = F / world                                   # one launch = F frames; rank 0's stripes ~ 1/N of each
         achieved = alg_bytes * share / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # committed rocprofv3 PMC summary of this workload (tools/profile_bench.sh -> profiles/r01_traffic.json), if there is one:
+        # physical HBM bytes per launch, and what actually limits the kernel (VALU issue slots, lanes active per instruction)
+        traffic, pmc = None, {}
         tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("%s_%dx%d_f%d" % (args.camera if args.workload == "c2" else args.workload, W, H, F), {}).get("hbm_bytes_per_launch")
+                entry = json.load(open(tp)).get("%s_%dx%d_f%d" % (args.camera if args.workload == "c2" else args.workload, W, H, F), {})
+                traffic = entry.get("hbm_bytes_per_launch")
+                c = {k: v["mean"] for k, v in entry.get("counters", {}).items()}
+                if all(k in c for k in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")):
+                    # 1024 SIMDs, 2 cycles per wave64 VALU instruction; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                    pmc = {"limiter": "valu_issue", "valu_issue_frac_profiled": round(c["SQ_INSTS_VALU"] * 2 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3),
+                           "lanes_active_per_valu_profiled": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 1),
+                           "profile": entry.get("tag")}
             except Exception:
-                traffic = None
+                traffic, pmc = None, {}
         out = {
             "metric": "Mrays/sec + ms/frame, 70k-tri OBJ at 1920x1080 1spp; 1/2/4/8 MI355X",
             "value": round(W * H * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
@@ -357,7 +366,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "render_kernel<false,false>", "kernel_ms": round(kernel_ms, 4),
-                         "frames_per_launch": F, "algorithmic_bytes_per_launch": int(alg_bytes * share)},
+                         "frames_per_launch": F, "algorithmic_bytes_per_launch": int(alg_bytes * share), **pmc},
             "frame_matches_debug_kernel": frame_ok,
         }
         if not dist_on and not args.no_cpu_baseline:
