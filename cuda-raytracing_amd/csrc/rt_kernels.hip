@@ -235,9 +235,9 @@ __device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevIn
 
 // One instance of raycast.cu:26-139.
 //
-// Interior nodes and triangles are both 64-B records, so every lane issues the same four 16-B loads from a
-// selected base ("unified fetch") and the wave waits for memory once per iteration, whatever mix of interior
-// and leaf entries its lanes hold.  Each lane still visits exactly the reference's sequence of nodes.
+// Interior nodes and triangles are both 64-B records of ONE array, so every lane issues the same four 16-B loads at
+// `records + (entry << 6)` ("unified fetch") and the wave waits for memory once per iteration, whatever mix of
+// interior and leaf entries its lanes hold.  Each lane still visits exactly the reference's sequence of nodes.
 // PROF = diagnostic copy with s_memtime stamps per phase (RT_TRACE_FILE); its frames are never timed.
 template <bool DEBUG, bool PROF, bool EX = false>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
