@@ -150,13 +150,9 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     const int32_t first = a_near ? rb : ra, second = a_near ? ra : rb;
     const float d_first = a_near ? db : da, d_second = a_near ? da : db;
     const bool pf = d_first < hit_min, ps = d_second < hit_min;
-    if (ps) {
-        if (pf) stack.push(first);
-        cur = second;
-        return true;
-    }
-    if (pf) { cur = first; return true; }
-    return false;
+    if (pf && ps) stack.push(first);                            // the only entry that really goes through the stack
+    cur = ps ? second : first;                                  // (not used when neither passed: the caller pops)
+    return pf || ps;
 }
 
 // What a triangle test proposes as the new closest hit.  Deliberately left uninitialised by the callers: it is only
