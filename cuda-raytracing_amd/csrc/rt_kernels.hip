@@ -148,7 +148,7 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     // push order of raycast.cu:72-79: `first` is pushed first, `second` last (= popped next)
     const bool a_near = da < db;
     const int32_t first = a_near ? rb : ra, second = a_near ? ra : rb;
-    const float d_first = a_near ? db : da, d_second = a_near ? da : db;
+    const float d_first = fmaxf(da, db), d_second = fminf(da, db);      // (never NaN: slab returns a distance or FLT_MAX)
     const bool pf = d_first < hit_min, ps = d_second < hit_min;
     if (pf && ps) stack.push(first);                            // the only entry that really goes through the stack
     cur = ps ? second : first;                                  // (not used when neither passed: the caller pops)
@@ -312,7 +312,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             cur = have ? cur + 1 : cur;                         // next slot of the same leaf (the slot field never overflows)
             rem = have ? rem : -1;
         }
-        if (__ballot(accept) != 0ull) {                         // (wave-level: most iterations accept nothing)
+        if (__builtin_amdgcn_ballot_w64(accept) != 0ull) {                         // (wave-level: most iterations accept nothing)
             hit.min = accept ? c.dist : hit.min;
             hit.slot = accept ? slot : hit.slot;
             hit.instance = accept ? inst_index : hit.instance;
