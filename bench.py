@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--gather", default="rotate", choices=["rotate", "root0"],
                     help="N > 1: rotate = the gather's root rotates over the frames of a group, fused into one all-to-all (every rank "
                          "assembles 1/N of the frames); root0 = every frame is gathered to rank 0")
-    ap.add_argument("--one-stream", action="store_true", help="launch every group on the same stream (no overlap of consecutive launches)")
+    ap.add_argument("--one-stream", action="store_true", help="N > 1: launch every group on the same stream (no overlap of consecutive launches)")
+    ap.add_argument("--two-streams", action="store_true", help="one GPU: alternate consecutive groups between two streams as the N > 1 path does")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 path (stripes, RCCL gather, un-stripe) even with one rank: a check of that path on a one-GPU box, not the N = 1 number")
     ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
@@ -170,9 +171,12 @@ def main():
     cam.set_pose(pose)
     stream = torch.cuda.current_stream().cuda_stream
     cam.set_stream(stream)
-    # Consecutive groups are launched on two alternating streams (one camera object bound to each): the last waves of a
-    # launch -- a few long silhouette rays on an otherwise empty chip -- then overlap the first waves of the next one.
-    two = not args.one_stream and not rehearsal              # (the rehearsal stages through the host on one stream)
+    # N > 1: consecutive groups are launched on two alternating streams (one camera object bound to each): the last waves
+    # of a launch -- a few long silhouette rays on an otherwise empty chip -- then overlap the first waves of the next one,
+    # which matters when a rank's share of a group is short.  One GPU keeps everything on one stream by default (worth 1-4 %
+    # there, --two-streams): rocprofv3's per-kernel durations then stay comparable with the hipEvent figure below, while
+    # overlapping launches each look longer than they cost.
+    two = (dist_on or args.two_streams) and not args.one_stream and not rehearsal   # (the rehearsal stages through the host on one stream)
     cstreams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else None
     cams = [cam, cam]
     if two:
