@@ -62,14 +62,14 @@ class RtSceneDesc(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
+    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
     "rt_render_debug", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
     "rth_obj_load", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
     "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
     "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
-    "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance",
+    "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance", "rth_scene_update_mesh_instance_async",
     "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
     "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
@@ -114,6 +114,7 @@ def _declare(h, s):
     h.rt_scene_upload.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(_vp)]
     h.rt_scene_info.argtypes = [_vp, C.POINTER(C.c_size_t), _i]
     h.rt_scene_update_instance.argtypes = [_vp, C.c_int32, _vp]
+    h.rt_scene_update_instance_async.argtypes = [_vp, C.c_int32, _vp, _vp]
     h.rt_scene_destroy.argtypes = [_vp]
     h.rt_render.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, C.c_int]
     h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
@@ -153,6 +154,7 @@ def _declare(h, s):
     s.rth_scene_add_mesh.argtypes = [_vp, _vp]
     s.rth_scene_add_mesh_instance.argtypes = [_vp, C.c_int32, C.c_int32, _f, _f]
     s.rth_scene_update_mesh_instance.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _f, _f]
+    s.rth_scene_update_mesh_instance_async.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _f, _f, _vp]
     s.rth_instance_build.argtypes = [_f, _f, _f]
     s.rth_camera_create.argtypes = [C.c_int32, C.c_int32, _f, _f]
     s.rth_camera_set_pose.argtypes = [_vp, _f]
@@ -304,9 +306,15 @@ class Scene:
     def upload_to_device(self):
         check(libs()[1].rth_scene_upload_to_device(self.h), "Scene::upload_to_device")
 
-    def update_mesh_instance(self, index, mesh, material, pose, scale=(1, 1, 1)):
-        check(libs()[1].rth_scene_update_mesh_instance(self.h, index, mesh, material, _fp(_fa(pose)), _fp(_fa(scale))),
-              "Scene::update_mesh_instance")
+    def update_mesh_instance(self, index, mesh, material, pose, scale=(1, 1, 1), stream=False):
+        """stream=False: synchronising update (the reference's cudaMemcpy, Scene.cpp:67-74); a stream handle (or None for
+        the default stream): ordered on that stream, no host wait."""
+        if stream is False:
+            check(libs()[1].rth_scene_update_mesh_instance(self.h, index, mesh, material, _fp(_fa(pose)), _fp(_fa(scale))),
+                  "Scene::update_mesh_instance")
+        else:
+            check(libs()[1].rth_scene_update_mesh_instance_async(self.h, index, mesh, material, _fp(_fa(pose)), _fp(_fa(scale)), stream),
+                  "Scene::update_mesh_instance(stream)")
 
     @property
     def device_handle(self):

@@ -30,6 +30,8 @@ public:
     // ---- device side ----
     void upload_to_device();                        // flatten everything and call rt_scene_upload (Scene.cpp:25-65)
     void update_mesh_instance(int index, MeshInstance mesh_instance);   // rt_scene_update_instance (Scene.cpp:67-74)
+    // the same, ordered on a stream instead of synchronising (rt_scene_update_instance_async): for per-frame animation
+    void update_mesh_instance(int index, MeshInstance mesh_instance, void* stream);
     RtScene* d_scene = nullptr;
     int num_mesh_instances = 0;
     int last_error = 0;                             // rt_hip.h status of the last device call (the reference ignores errors)

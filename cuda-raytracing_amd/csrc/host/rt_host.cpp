@@ -329,6 +329,15 @@ void Scene::update_mesh_instance(int index, MeshInstance mesh_instance)
     last_error = d_scene ? rt_scene_update_instance(d_scene, index, &d) : RT_E_INVALID;
 }
 
+void Scene::update_mesh_instance(int index, MeshInstance mesh_instance, void* stream)
+{
+    if (index < 0 || index >= (int)mesh_instances.size()) { last_error = RT_E_INVALID; return; }
+    mesh_instances[index] = mesh_instance;
+    mesh_instances[index].build_inv();
+    RtInstanceDesc d = to_desc(mesh_instances[index]);
+    last_error = d_scene ? rt_scene_update_instance_async(d_scene, index, &d, stream) : RT_E_INVALID;
+}
+
 // -------------------------------------------------------------------------------- Camera
 
 Camera::Camera(int width, int height, float3x3 K, float4 D) : width(width), height(height), K(K), D(D)

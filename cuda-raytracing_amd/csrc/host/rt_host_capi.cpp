@@ -136,6 +136,9 @@ int rth_scene_upload_to_device(RthScene* s)
 { try { s->scene.upload_to_device(); return s->scene.last_error; } catch (const std::exception& e) { g_err = e.what(); return RT_E_NOMEM; } }
 int rth_scene_update_mesh_instance(RthScene* s, int32_t index, int32_t mesh, int32_t material, const float* pose6, const float* scale3)
 { s->scene.update_mesh_instance(index, MeshInstance(mesh, material, LRE(pose6), F3(scale3))); return s->scene.last_error; }
+int rth_scene_update_mesh_instance_async(RthScene* s, int32_t index, int32_t mesh, int32_t material, const float* pose6,
+                                         const float* scale3, void* stream)
+{ s->scene.update_mesh_instance(index, MeshInstance(mesh, material, LRE(pose6), F3(scale3)), stream); return s->scene.last_error; }
 int32_t rth_scene_num_mesh_instances(const RthScene* s) { return s->scene.num_mesh_instances; }
 void* rth_scene_device_handle(RthScene* s) { return s->scene.d_scene; }
 void rth_instance_build(const float* pose6, const float* scale3, float* out24)

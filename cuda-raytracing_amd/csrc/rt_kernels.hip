@@ -597,6 +597,10 @@ __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pi
     d[u] = s[u];
 }
 
+// rt_scene_update_instance_async: the new record travels as a kernel argument, so the update is ordered on the stream
+// like any launch and needs no host buffer that outlives the call
+__global__ void set_instance_kernel(DevInstance* dst, const DevInstance value) { *dst = value; }
+
 }  // namespace
 
 // =====================================================================================
@@ -939,6 +943,15 @@ int rt_scene_update_instance(RtScene* s, int32_t index, const RtInstanceDesc* in
     if (!s || !instance || index < 0 || index >= (int)s->instances.size() || !instance_ok(*instance, *s)) return RT_E_INVALID;
     s->instances[index] = make_dev_instance(*instance, *s);
     RT_HIP(hipMemcpy(s->d_instances + index, &s->instances[index], sizeof(DevInstance), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_scene_update_instance_async(RtScene* s, int32_t index, const RtInstanceDesc* instance, void* stream)
+{
+    if (!s || !instance || index < 0 || index >= (int)s->instances.size() || !instance_ok(*instance, *s)) return RT_E_INVALID;
+    s->instances[index] = make_dev_instance(*instance, *s);
+    hipLaunchKernelGGL(set_instance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->d_instances + index, s->instances[index]);
+    RT_HIP(hipGetLastError());
     return RT_OK;
 }
 

@@ -115,6 +115,10 @@ const char *rt_error_string(int code);
 int rt_scene_upload(const RtSceneDesc *desc, RtScene **out);
 /* Scene::update_mesh_instance (Scene.cpp:67-74): re-upload one instance */
 int rt_scene_update_instance(RtScene *scene, int32_t index, const RtInstanceDesc *instance);
+/* the same update ordered on `stream` instead of synchronising with the device: renders issued on that stream before the
+ * call see the old instance, renders issued after it the new one -- an animated instance (the teapot of kernel.cu:272-273)
+ * then costs no host wait per frame.  Renders in flight on OTHER streams are not ordered against it. */
+int rt_scene_update_instance_async(RtScene *scene, int32_t index, const RtInstanceDesc *instance, void *stream);
 int rt_scene_destroy(RtScene *scene);
 /* bytes of device memory the scene holds, and the traversal-stack depth it needs */
 int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);

@@ -53,6 +53,9 @@ int32_t rth_scene_add_mesh(RthScene *s, const RthMesh *m);
 int32_t rth_scene_add_mesh_instance(RthScene *s, int32_t mesh, int32_t material, const float *pose6, const float *scale3);
 int rth_scene_upload_to_device(RthScene *s);                                       /* Scene::upload_to_device */
 int rth_scene_update_mesh_instance(RthScene *s, int32_t index, int32_t mesh, int32_t material, const float *pose6, const float *scale3);
+/* ordered on `stream` instead of synchronising (rt_scene_update_instance_async) */
+int rth_scene_update_mesh_instance_async(RthScene *s, int32_t index, int32_t mesh, int32_t material, const float *pose6,
+                                         const float *scale3, void *stream);
 int32_t rth_scene_num_mesh_instances(const RthScene *s);
 /* the RtScene* behind the Scene (for rt_render_debug etc.), NULL before upload */
 void *rth_scene_device_handle(RthScene *s);

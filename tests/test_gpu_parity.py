@@ -203,6 +203,31 @@ def test_update_mesh_instance(rt, orc, scenes, blob5k):
         assert np.array_equal(dbg[n], ref[n]), n
 
 
+def test_animated_instance_without_host_waits(rt, orc, scenes, blob5k):
+    """The animation loop of kernel.cu:272-277 (re-pose an instance, render, repeat) issued on one stream with no
+    synchronisation in between: update k must be seen by render k and by no earlier one (rt_scene_update_instance_async)."""
+    desc = sd.multi_instance_scene(scenes, blob5k)
+    m = sd.MULTI_CAMERA
+    W, H, K = m["width"], m["height"], scenes.scaled_K(m["width"])
+    so = desc.build_oracle(orc)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = _camera(rt, scenes, W, H, K, m["pose"])
+    nframes = 6
+    poses = [(0.4 - 0.1 * k, 0.2, 0.05 * k, -0.3 + 0.2 * k, 0.2, 0.5) for k in range(nframes)]
+    imgs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(nframes)]
+    for k in range(nframes):
+        sp.update_mesh_instance(0, 0, 2, poses[k], (0.9, 0.8, 1.2), stream=None)      # ordered on the (default) stream
+        cam.render_scene(sp, imgs[k].ptr, imgs[k].pitch)                                # asynchronous
+    rt.check(rt.libs()[0].rt_device_synchronize())
+    frames = [b.to_host().reshape(H, W, 3) for b in imgs]
+    for k in range(nframes):
+        so.update_instance(0, 0, 2, poses[k], (0.9, 0.8, 1.2))
+        ref = so.render(W, H, K, scenes.D_REF, m["pose"], threads=8, planes=False)["img"]
+        assert np.array_equal(frames[k], ref), "frame %d" % k
+    assert not np.array_equal(frames[0], frames[1])
+
+
 def test_stripes_equal_full_frame(rt, orc, scenes, blob5k):
     """Frame tiling: for 1, 2, 3, 4, 8 virtual ranks the un-striped gather equals the 1-GPU frame byte for byte."""
     import ctypes as C
