@@ -303,9 +303,6 @@ __global__ void emit_kernel(const BuildNode* __restrict__ nodes, int num_nodes, 
     leaf_count[o] = leaf ? nd.count : 0;
 }
 
-template <class T>
-hipError_t dmalloc(T** p, size_t count) { return hipMalloc((void**)p, (count ? count : 1) * sizeof(T)); }
-
 }  // namespace
 
 extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth, float* node_bounds, int32_t* node_children,
@@ -324,22 +321,33 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     BuildNode* d_nodes = nullptr;
     Bins* d_bins = nullptr;
     void* d_tmp = nullptr;
+    char* arena = nullptr;
     size_t tmp_bytes = 0;
     std::vector<int> level_begin;
     int cur = 0, total = 1, levels = 0;
     BuildNode root;
 
-    RT_HIP(dmalloc(&d_v, (size_t)n * 9));
-    RT_HIP(dmalloc(&d_centroid, (size_t)n * 3));
-    RT_HIP(dmalloc(&d_tbox, (size_t)n * 6));
-    for (int i = 0; i < 2; i++) { RT_HIP(dmalloc(&d_order[i], (size_t)n)); RT_HIP(dmalloc(&d_nodeof[i], (size_t)n)); }
-    RT_HIP(dmalloc(&d_flags, (size_t)n));
-    RT_HIP(dmalloc(&d_scan, (size_t)n));
-    RT_HIP(dmalloc(&d_counter, 1));
-    RT_HIP(dmalloc(&d_nodes, (size_t)cap + 2));
-    RT_HIP(dmalloc(&d_bins, (size_t)(n > 0 ? n : 1)));          // a level has at most n nodes
-    RT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flags, d_scan, n > 0 ? n : 1));
-    RT_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    // one device allocation for everything (a dozen hipMalloc / hipFree pairs cost more than the build kernels of a
+    // 70 k-triangle mesh): sizes are known up front because a tree over n triangles has at most 2n - 1 nodes
+    {
+        RT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flags, d_scan, n > 0 ? n : 1));
+        const size_t n1 = n > 0 ? (size_t)n : 1;
+        size_t off = 0;
+        auto take = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_v = take(n1 * 9 * 4), o_cen = take(n1 * 3 * 4), o_tbox = take(n1 * 6 * 4), o_ord0 = take(n1 * 4), o_ord1 = take(n1 * 4),
+                     o_nof0 = take(n1 * 4), o_nof1 = take(n1 * 4), o_flags = take(n1 * 4), o_scan = take(n1 * 4), o_counter = take(4),
+                     o_nodes = take(((size_t)cap + 2) * sizeof(BuildNode)), o_bins = take(n1 * sizeof(Bins)), o_tmp = take(tmp_bytes ? tmp_bytes : 1),
+                     o_bounds = take((size_t)cap * 6 * 4), o_children = take((size_t)cap * 2 * 4), o_lfirst = take((size_t)cap * 4),
+                     o_lcount = take((size_t)cap * 4);
+        RT_HIP(hipMalloc((void**)&arena, off));
+        d_v = (float*)(arena + o_v); d_centroid = (float*)(arena + o_cen); d_tbox = (float*)(arena + o_tbox);
+        d_order[0] = (int32_t*)(arena + o_ord0); d_order[1] = (int32_t*)(arena + o_ord1);
+        d_nodeof[0] = (int32_t*)(arena + o_nof0); d_nodeof[1] = (int32_t*)(arena + o_nof1);
+        d_flags = (int32_t*)(arena + o_flags); d_scan = (int32_t*)(arena + o_scan); d_counter = (int32_t*)(arena + o_counter);
+        d_nodes = (BuildNode*)(arena + o_nodes); d_bins = (Bins*)(arena + o_bins); d_tmp = arena + o_tmp;
+        d_bounds = (float*)(arena + o_bounds); d_children = (int32_t*)(arena + o_children);
+        d_lfirst = (int32_t*)(arena + o_lfirst); d_lcount = (int32_t*)(arena + o_lcount);
+    }
 
     if (n > 0) {
         RT_HIP(hipMemcpy(d_v, vertices, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
@@ -387,10 +395,6 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
         const int lb = level_begin[l], le = level_begin[l + 1];
         hipLaunchKernelGGL(preorder_kernel, dim3((le - lb + T - 1) / T), dim3(T), 0, 0, d_nodes, lb, le);
     }
-    RT_HIP(dmalloc(&d_bounds, (size_t)total * 6));
-    RT_HIP(dmalloc(&d_children, (size_t)total * 2));
-    RT_HIP(dmalloc(&d_lfirst, (size_t)total));
-    RT_HIP(dmalloc(&d_lcount, (size_t)total));
     hipLaunchKernelGGL(emit_kernel, dim3((total + T - 1) / T), dim3(T), 0, 0, d_nodes, total, d_bounds, d_children, d_lfirst, d_lcount);
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpy(node_bounds, d_bounds, (size_t)total * 6 * sizeof(float), hipMemcpyDeviceToHost));
@@ -402,9 +406,6 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     if (num_levels) *num_levels = levels;
 
 done:
-    (void)hipFree(d_v); (void)hipFree(d_centroid); (void)hipFree(d_tbox); (void)hipFree(d_bounds);
-    for (int i = 0; i < 2; i++) { (void)hipFree(d_order[i]); (void)hipFree(d_nodeof[i]); }
-    (void)hipFree(d_flags); (void)hipFree(d_scan); (void)hipFree(d_counter); (void)hipFree(d_nodes); (void)hipFree(d_bins);
-    (void)hipFree(d_tmp); (void)hipFree(d_children); (void)hipFree(d_lfirst); (void)hipFree(d_lcount);
+    (void)hipFree(arena);
     return rc;
 }
