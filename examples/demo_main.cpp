@@ -1,12 +1,13 @@
 // demo_main.cpp -- the reference application's flow (kernel.cu:141-302: camera, materials, OBJ meshes, instances,
-// upload, a render loop that issues two frames per synchronise and prints FPS, out.png) written against this
+// upload, a render loop that issues two frames per synchronise, prints FPS and ends every pass with display_image ->
+// out.png with the FPS overlay) written against this
 // project's host API.  It shows what a user of the reference keeps (Scene / Camera / OBJLoader / MeshInstance /
 // Material calls) and what changes (rt_hip.h plumbing instead of cudaMallocPitch / cudaDeviceSynchronize / OpenCV).
 //
 //   g++ -std=c++17 -O2 -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude
 //       -Icuda-raytracing_amd/csrc/host examples/demo_main.cpp -Lcuda-raytracing_amd -lrt_host -lrt_hip
 //       -Wl,-rpath,$PWD/cuda-raytracing_amd -o demo
-//   ./demo mesh.obj [out.png] [iterations] [texture.ppm]
+//   ./demo mesh.obj [out.png] [iterations] [texture.png|.jpg|.ppm]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -14,12 +15,13 @@
 
 #include "rt_hip.h"
 #include "Camera.h"
+#include "ImageIO.hpp"
 #include "OBJLoader.hpp"
 #include "Scene.h"
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { std::cerr << "usage: demo mesh.obj [out.png] [iterations] [texture.ppm]" << std::endl; return 2; }
+    if (argc < 2) { std::cerr << "usage: demo mesh.obj [out.png] [iterations] [texture.png|.jpg|.ppm]" << std::endl; return 2; }
     const char* out_png = argc > 2 ? argv[2] : "out.png";
     const int iterations = argc > 3 ? atoi(argv[3]) : 100;
 
@@ -62,7 +64,11 @@ int main(int argc, char** argv)
     rt_malloc_pitch((void**)&d_img, &pitch, width * sizeof(uchar3), height);
     rt_malloc_pitch((void**)&d_img2, &pitch2, width * sizeof(uchar3), height);
 
+    MouseParams mouse_state;                                    // kernel.cu:258-259 (no window system here: never fed)
+    mouse_state.pose = &camera.pose;
+
     double fps = 0.0;
+    int rc = 0;
     for (int l = 0; l < iterations; l++) {
         auto t0 = std::chrono::steady_clock::now();
         camera.render_scene(scene, d_img, pitch);               // two renders per synchronise, as kernel.cu:277-279
@@ -71,11 +77,11 @@ int main(int argc, char** argv)
         if (camera.last_error) { std::cerr << "render failed: " << rt_error_string(camera.last_error) << std::endl; return 1; }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         fps = 1.0 / dt;
-        if (l % 20 == 0) std::cout << "FPS: " << fps << "\n";
+        std::cout << "FPS: " << fps << "\n";
+        rc = display_image(d_img, width, height, pitch, fps, mouse_state, out_png);    // kernel.cu:298
+        if (rc) break;
     }
     std::cout << "FPS: " << fps << " (" << 2.0 * width * height * fps / 1e6 << " Mrays/s)" << std::endl;
-
-    int rc = save_png(out_png, d_img, width, height, pitch);
     std::cout << (rc ? "could not write " : "wrote ") << out_png << std::endl;
     rt_free(d_img);
     rt_free(d_img2);

@@ -474,9 +474,8 @@ def test_c5_shape_tiled_64spp(rt, orc, scenes, blob5k):
 
 def test_cpp_demo_application(rt, orc, scenes, blob5k, tmp_path):
     """examples/demo_main.cpp (the reference's main() flow written against the host C++ API) builds with plain g++,
-    runs, and its out.png equals the same scene rendered through the oracle."""
+    runs, and its out.png equals the same scene rendered through the oracle -- plus the FPS overlay of display_image."""
     import subprocess
-    from PIL import Image
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "demo")
     pkg = os.path.join(root, "cuda-raytracing_amd")
@@ -492,12 +491,17 @@ def test_cpp_demo_application(rt, orc, scenes, blob5k, tmp_path):
     r = subprocess.run([exe, blob5k, png, "3", ppm], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Number of nodes" in r.stdout and "FPS" in r.stdout
-    got = np.asarray(Image.open(png).convert("RGB"))[:, :, ::-1]
+    got = rt.read_image(png)
     desc = sd.SceneDesc([((0.9, 0.5, 0.2), None), ((1.0, 1.0, 1.0), tex)], [("obj", blob5k)],
                         [(0, 1, (0,) * 6, (1, 1, 1)), (0, 0, (-0.6, 1.48, 0.73, 0, 0, 0), (0.4, 0.4, 0.4))])
     so = desc.build_oracle(orc)
-    ref = so.render(1920, 1080, scenes.K_1080, scenes.D_REF, (0.0, -1.6, 0.2, 0, 0, 0), planes=False, threads=16)
-    assert np.array_equal(got, ref["img"])
+    ref = so.render(1920, 1080, scenes.K_1080, scenes.D_REF, (0.0, -1.6, 0.2, 0, 0, 0), planes=False, threads=16)["img"]
+    # display_image's "FPS: ..." overlay sits in rows 9..29 from column 10 on; everything else is the rendered frame
+    box = np.zeros(got.shape[:2], bool)
+    box[9:30, 10:10 + 18 * 24] = True
+    assert np.array_equal(got[~box], ref[~box])
+    changed = (got != ref).any(-1)
+    assert changed.any() and (got[changed] == (0, 255, 0)).all() and changed[9:30, 10:25].any()     # the green 'F'
     so.close()
 
 
