@@ -14,9 +14,12 @@ kernel.cu:277-279).  K steps = K frames = K/F launches; F = 1 gives one launch p
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the scene is replicated, every frame is
 cut into 16-row stripes dealt round-robin to the ranks (rt_render_stripes_batch), and every group of F
-frames ends with ONE RCCL gather of the stripes to rank 0 plus rt_unstripe per frame; the gather of
-group i overlaps the render of group i+1.  Total work is fixed, so "scaling" is "strong".
-Rank 0 prints ONE JSON line.
+frames ends with ONE RCCL collective plus rt_unstripe_batch: by default a gather whose root rotates over the
+frames of the group, fused into one all-to-all (each rank assembles F/N frames; --gather root0 gathers every
+frame to rank 0).  Consecutive groups alternate between two compute streams, the collective runs on RCCL's
+stream and the un-stripe pass on a fourth, so the exchange of group i overlaps the render of group i+1.
+Total work is fixed, so "scaling" is "strong".  Every rank checks the frames it assembled; rank 0 prints ONE JSON line
+(stdout carries nothing else: library banners are redirected to stderr).
 """
 import argparse
 import ctypes as C
