@@ -102,8 +102,8 @@ def cpu_baseline(obj, W, H, K, D, pose, gpu_stats, albedo):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=960)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
                     help="c2 = the metric's workload (70k-triangle blob, 1920x1080); c4 = BASELINE configs[3] scene (260k-triangle atrium, 3840x2160)")
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
