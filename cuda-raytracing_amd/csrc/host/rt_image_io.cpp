@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <algorithm>
 
 #include "../../../include/rt_hip.h"
@@ -359,7 +360,7 @@ bool read_ppm_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& width
 }
 
 bool read_image_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& width, int& height, std::string* error)
-{
+try {
     uint8_t head[4] = {0, 0, 0, 0};
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return fail(error, "cannot open file");
@@ -369,6 +370,8 @@ bool read_image_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& wid
     if (n >= 2 && head[0] == 0xFF && head[1] == 0xD8) return read_jpeg_bgr(path, bgr, width, height, error);
     if (n >= 2 && head[0] == 'P' && head[1] == '6') return read_ppm_bgr(path, bgr, width, height, error);
     return fail(error, "unknown image format (PNG, baseline JPEG and binary PPM are supported)");
+} catch (const std::bad_alloc&) {
+    return fail(error, "out of memory while decoding the image");
 }
 
 // --------------------------------------------------------------------------------------------------------- overlay
@@ -649,6 +652,7 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
             H = be16(&s[1]); W = be16(&s[3]);
             const int nc = s[5];
             if (W <= 0 || H <= 0 || (nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc) return fail(error, "unsupported JPEG frame (grey or 3 components)");
+            if ((size_t)W * (size_t)H > ((size_t)1 << 28)) return fail(error, "JPEG frame too large");
             comps.assign(nc, JpegComponent());
             for (int c = 0; c < nc; c++) {
                 comps[c].id = s[6 + 3 * c]; comps[c].h = s[7 + 3 * c] >> 4; comps[c].v = s[7 + 3 * c] & 15; comps[c].tq = s[8 + 3 * c];
