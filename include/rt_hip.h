@@ -8,6 +8,10 @@
  * torch types; every function returns 0 on success, a positive hipError_t, or a negative
  * RT_E_* code, and never throws.  The caller owns image buffers; the library owns scene
  * buffers.  All `stream` arguments are a hipStream_t passed as void* (NULL = default stream).
+ *
+ * Environment (diagnostics and tests only): RT_TRACE_FILE=<path> makes every render launch synchronise and write
+ * per-wave start / end stamps there (tools/trace_one.py), with RT_TRACE_PROF=1 through a stamped copy of the kernel;
+ * RT_EX_SCRATCH_BYTES=<n> overrides the scratch budget of rt_render_ex (forces the chunked path).
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -24,7 +28,7 @@ enum {
     RT_OK = 0,
     RT_E_INVALID = -1,      /* bad argument (null pointer, size, index out of range) */
     RT_E_NOMEM = -2,
-    RT_E_DEPTH = -3,        /* BVH deeper than the 32-entry traversal stack of raycast.cu:54 */
+    RT_E_DEPTH = -3,        /* BVH deeper than 64 levels (the reference's traversal stack holds 32 entries, raycast.cu:54) */
     RT_E_NODEVICE = -4
 };
 
