@@ -480,7 +480,7 @@ __device__ __forceinline__ V3 hit_normal(const RenderParams& p, const Hit& hit)
 // of spp frames.  (A pixel's samples used to run as a loop inside its lane: the waves on the silhouette then lived
 // 64 x as long as their neighbours and the kernel spent most of its time waiting for a handful of them.)
 // The sample's radiance and node pops go to ex_samples[sample][local pixel]; resolve_ex_kernel sums them in order.
-__global__ __launch_bounds__(kBlock, 6) void render_ex_kernel(const RenderParams p)
+__global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];
     const FrameParams& f = p.frames[0];
