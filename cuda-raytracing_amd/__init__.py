@@ -63,7 +63,7 @@ RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
     "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
-    "rt_render_debug", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
+    "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
     "rth_obj_load", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
@@ -118,6 +118,7 @@ def _declare(h, s):
     h.rt_scene_destroy.argtypes = [_vp]
     h.rt_render.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, C.c_int]
     h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
+    h.rt_render_ids.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, _vp, _vp, C.c_int]
     h.rt_stripe_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i]
     h.rt_render_stripes.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int]
     h.rt_unstripe.argtypes = [_vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
@@ -476,6 +477,21 @@ def render_debug(scene, camera):
         out[n] = b.to_host(np.int32).reshape(H, W)
         b.free()
     img.free()
+    return out
+
+
+def render_ids(scene, camera):
+    """One frame through rt_render_ids (the PRODUCTION kernel plus its hit-id planes) -> dict(img, hit_inst, hit_tri)."""
+    h = libs()[0]
+    W, H = camera.width, camera.height
+    img = DeviceBuffer(width_bytes=W * 3, height=H)
+    inst, tri = DeviceBuffer(nbytes=W * H * 4), DeviceBuffer(nbytes=W * H * 4)
+    p = camera.params()
+    check(h.rt_render_ids(scene.device_handle, C.byref(p), img.ptr, img.pitch, inst.ptr, tri.ptr, None, 1), "rt_render_ids")
+    out = dict(img=img.to_host().reshape(H, W, 3), hit_inst=inst.to_host(np.int32).reshape(H, W),
+               hit_tri=tri.to_host(np.int32).reshape(H, W))
+    for b in (img, inst, tri):
+        b.free()
     return out
 
 

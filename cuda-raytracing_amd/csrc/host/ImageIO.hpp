@@ -27,8 +27,10 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
 // by file signature (PNG / JPEG / P6)
 bool read_image_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& width, int& height, std::string* error = nullptr);
 
-// zlib stream -> bytes (used by the PNG reader; exposed for tests)
-bool zlib_inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string* error = nullptr);
+// zlib stream -> bytes (used by the PNG reader; exposed for tests).  max_out: fail once the output would exceed this
+// many bytes (deflate expands up to ~1000-fold: a reader passes the size its header announces)
+bool zlib_inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string* error = nullptr,
+                  size_t max_out = (size_t)1 << 30);
 
 // ---- overlay: `text` with its baseline-left corner at (x, y) like cv::putText's `org`, glyph cell 5x7 scaled by `scale`
 void overlay_text_bgr(uint8_t* bgr, int width, int height, size_t pitch, const std::string& text, int x, int y, int scale,
@@ -51,6 +53,7 @@ void on_mouse(int event, int x, int y, int flags, void* param);
 bool on_key(int key, MouseParams& mouse_state);
 
 // kernel.cu:30-43: download the frame, overlay "FPS: <std::to_string(fps)>" in green at (10, 30), write out.png.
-// `path` defaults to the reference's file name.  Returns an rt error code.
+// `path` defaults to the reference's file name; `stream` = the stream the frame was rendered on (Camera::stream), the
+// download is ordered behind it.  Returns an rt error code.
 int display_image(const uchar3* d_img, int width, int height, size_t pitch, double fps, MouseParams& mouse_state,
-                  const char* path = "out.png");
+                  const char* path = "out.png", void* stream = nullptr);

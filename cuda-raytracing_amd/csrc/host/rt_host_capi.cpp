@@ -224,7 +224,8 @@ int rth_zlib_inflate(const uint8_t* src, size_t n, uint8_t* out, size_t capacity
     if (!src || !out_n) return RT_E_INVALID;
     std::vector<uint8_t> o;
     std::string err;
-    if (!zlib_inflate(src, n, o, &err)) { g_err = "rth_zlib_inflate: " + err; return RT_E_INVALID; }
+    // with a destination buffer the output is capped at its capacity; the size query is capped at 1 GiB
+    if (!zlib_inflate(src, n, o, &err, out ? capacity : (size_t)1 << 30)) { g_err = "rth_zlib_inflate: " + err; return RT_E_INVALID; }
     *out_n = o.size();
     if (out) {
         if (capacity < o.size()) return RT_E_INVALID;

@@ -101,12 +101,13 @@ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97,
                                 4097, 6145, 8193, 12289, 16385, 24577};
 const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-bool inflate_codes(BitReader& br, const Huffman& lit, const Huffman& dist, std::vector<uint8_t>& out)
+// `limit`: the most bytes the caller is prepared to receive (a deflate stream can expand about 1000-fold)
+bool inflate_codes(BitReader& br, const Huffman& lit, const Huffman& dist, std::vector<uint8_t>& out, size_t limit)
 {
     for (;;) {
         int sym = decode_symbol(br, lit);
         if (sym < 0) return false;
-        if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+        if (sym < 256) { if (out.size() >= limit) return false; out.push_back((uint8_t)sym); continue; }
         if (sym == 256) return true;
         sym -= 257;
         if (sym >= 29) return false;
@@ -114,13 +115,13 @@ bool inflate_codes(BitReader& br, const Huffman& lit, const Huffman& dist, std::
         const int ds = decode_symbol(br, dist);
         if (ds < 0 || ds >= 30) return false;
         const size_t d = kDistBase[ds] + br.bits(kDistExtra[ds]);
-        if (br.overrun || d > out.size()) return false;
+        if (br.overrun || d > out.size() || out.size() + (size_t)len > limit) return false;
         const size_t from = out.size() - d;
         for (int k = 0; k < len; k++) out.push_back(out[from + k]);   // (may overlap: byte by byte)
     }
 }
 
-bool inflate_raw(BitReader& br, std::vector<uint8_t>& out)
+bool inflate_raw(BitReader& br, std::vector<uint8_t>& out, size_t limit)
 {
     for (;;) {
         const int last = (int)br.bits(1), type = (int)br.bits(2);
@@ -130,7 +131,7 @@ bool inflate_raw(BitReader& br, std::vector<uint8_t>& out)
             if (br.pos + 4 > br.n) return false;
             const unsigned len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
             br.pos += 4;
-            if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) return false;
+            if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n || out.size() + len > limit) return false;
             out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
             br.pos += len;
         } else if (type == 1) {                                 // fixed codes
@@ -145,7 +146,7 @@ bool inflate_raw(BitReader& br, std::vector<uint8_t>& out)
             uint8_t dl[30];
             memset(dl, 5, sizeof dl);
             build_huffman(dist, dl, 30);
-            if (!inflate_codes(br, lit, dist, out)) return false;
+            if (!inflate_codes(br, lit, dist, out, limit)) return false;
         } else if (type == 2) {                                 // dynamic codes
             const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
             if (br.overrun || nlen > 286 || ndist > 30) return false;
@@ -174,7 +175,7 @@ bool inflate_raw(BitReader& br, std::vector<uint8_t>& out)
             if (ll[256] == 0) return false;                     // no end-of-block code
             Huffman lit, dist;
             if (!build_huffman(lit, ll, nlen) || !build_huffman(dist, ll + nlen, ndist)) return false;
-            if (!inflate_codes(br, lit, dist, out)) return false;
+            if (!inflate_codes(br, lit, dist, out, limit)) return false;
         } else return false;
         if (last) return true;
     }
@@ -214,13 +215,13 @@ int paeth(int a, int b, int c)
 
 }  // namespace
 
-bool zlib_inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string* error)
+bool zlib_inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string* error, size_t max_out)
 {
     if (n < 6) return fail(error, "zlib stream too short");
     if ((src[0] & 0x0F) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) return fail(error, "not a zlib deflate stream");
     BitReader br(src + 2, n - 2);
     out.clear();
-    if (!inflate_raw(br, out)) return fail(error, "corrupt deflate data");
+    if (!inflate_raw(br, out, max_out)) return fail(error, "corrupt deflate data (or more output than expected)");
     br.align_byte();
     if (br.pos + 4 > br.n || be32(br.p + br.pos) != adler32(out)) return fail(error, "zlib checksum mismatch");
     return true;
@@ -271,8 +272,8 @@ bool read_png_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& width
     if (!depth_ok) return fail(error, "invalid PNG bit depth");
     if (ctype == 3 && (palette.empty() || palette.size() % 3)) return fail(error, "palette PNG without PLTE");
     std::vector<uint8_t> raw;
-    if (!zlib_inflate(idat.data(), idat.size(), raw, error)) return false;
     const size_t row_bytes = ((size_t)w * channels * depth + 7) / 8;
+    if (!zlib_inflate(idat.data(), idat.size(), raw, error, (size_t)h * (row_bytes + 1))) return false;   // no more than IHDR announces
     if (raw.size() < (size_t)h * (row_bytes + 1)) return fail(error, "PNG image data too short");
     const int bpp = std::max(1, channels * depth / 8);          // filter distance in bytes
     // undo the scanline filters in place (PNG spec 9.2)
@@ -471,11 +472,13 @@ bool on_key(int key, MouseParams& mouse_state)
     return true;
 }
 
-int display_image(const uchar3* d_img, int width, int height, size_t pitch, double fps, MouseParams&, const char* path)
+int display_image(const uchar3* d_img, int width, int height, size_t pitch, double fps, MouseParams&, const char* path, void* stream)
 {
     if (!d_img || width <= 0 || height <= 0) return RT_E_INVALID;
     std::vector<uint8_t> host((size_t)width * 3 * (size_t)height);
-    int rc = rt_memcpy2d_d2h(host.data(), (size_t)width * 3, d_img, pitch, (size_t)width * 3, (size_t)height, nullptr);
+    // the copy is ordered on the stream the frame was rendered on (Camera::stream): a non-blocking stream is not ordered
+    // against the null stream, and render_scene() is asynchronous by default (Camera.cu:38-39)
+    int rc = rt_memcpy2d_d2h(host.data(), (size_t)width * 3, d_img, pitch, (size_t)width * 3, (size_t)height, stream);
     if (rc) return rc;
     // cv::putText(img, "FPS: " + std::to_string(fps), Point(10, 30), FONT_HERSHEY_SIMPLEX, 1.0, Scalar(0, 255, 0), 2):
     // Hershey simplex at scale 1 is about 22 pixels tall; the built-in 5x7 font at scale 3 is 21.
@@ -648,7 +651,9 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
                 i += 17 + total;
             }
         } else if (marker == 0xC0 || marker == 0xC1) {          // SOF0 / SOF1: baseline / extended sequential, Huffman
+            if (have_frame) return fail(error, "JPEG with more than one frame header");   // (a stale hmax / vmax would size the planes wrongly)
             if (n < 6 || s[0] != 8) return fail(error, "only 8-bit JPEG is supported");
+            hmax = vmax = 1;
             H = be16(&s[1]); W = be16(&s[3]);
             const int nc = s[5];
             if (W <= 0 || H <= 0 || (nc != 1 && nc != 3) || n < 6 + 3 * (size_t)nc) return fail(error, "unsupported JPEG frame (grey or 3 components)");
@@ -673,6 +678,7 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
             restart_interval = be16(s);
         } else if (marker == 0xDA) {                            // SOS: the one scan of a baseline file
             if (!have_frame) return fail(error, "JPEG scan before frame header");
+            if (n < 1) return fail(error, "bad SOS");
             const int ns = s[0];
             if (ns != (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail(error, "multi-scan JPEG is not supported");
             for (int k = 0; k < ns; k++) {

@@ -406,10 +406,15 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     uint8_t* out = f.img + (size_t)ly * p.pitch + 3 * (size_t)x;
     out[0] = (uint8_t)px; out[1] = (uint8_t)(px >> 8); out[2] = (uint8_t)(px >> 16);
 
-    if constexpr (DEBUG) {
-        size_t o = (size_t)y * p.width + x;
+    // hit-id planes: also available from the production kernel (rt_render_ids), so that the kernel that is timed is the
+    // kernel whose hit ids are checked; a wave-uniform branch on a kernel argument, outside the traversal loop
+    if (p.hit_instance || p.hit_triangle) {
+        const size_t o = (size_t)y * p.width + x;
         if (p.hit_instance) p.hit_instance[o] = hit.instance;
         if (p.hit_triangle) p.hit_triangle[o] = hit.slot >= 0 ? p.tri_id[hit.slot] : -1;
+    }
+    if constexpr (DEBUG) {
+        size_t o = (size_t)y * p.width + x;
         if (p.node_pops) p.node_pops[o] = cnt.pops;
         if (p.aabb_tests) p.aabb_tests[o] = cnt.aabb;
         if (p.tri_tests) p.tri_tests[o] = cnt.tris;
@@ -842,6 +847,9 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                 }
             }
             if (rc != RT_OK) break;
+            // leaf ranges may overlap in a caller-supplied tree, so the slots actually emitted (the sum of the leaf counts)
+            // can exceed num_leaf_indices: the slot field of a ref must still hold them
+            if (slot_base + n_slot + 1 > kSlotMask) { rc = RT_E_INVALID; break; }
             if (max_level > kMaxStack) { rc = RT_E_DEPTH; break; }
             s->max_stack = std::max(s->max_stack, max_level);
             // pass 2: emit records
@@ -986,6 +994,16 @@ int rt_render_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_im
 int rt_render(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, void* stream, int synchronize)
 {
     return rt_render_batch(s, cam, &d_img, pitch, 1, stream, synchronize);
+}
+
+int rt_render_ids(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, int32_t* d_hit_instance,
+                  int32_t* d_hit_triangle, void* stream, int synchronize)
+{
+    RenderParams p;
+    int rc = fill_params(p, s, cam, &d_img, 1, pitch);
+    if (rc) return rc;
+    p.hit_instance = d_hit_instance; p.hit_triangle = d_hit_triangle;
+    return launch(p, false, (hipStream_t)stream, synchronize);
 }
 
 int rt_render_debug(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch,

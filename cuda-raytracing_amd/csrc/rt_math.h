@@ -3,7 +3,7 @@
 // Every function restates one reference function bit-for-bit (fp32, written association
 // order, no contraction: all translation units that include this are built with
 // -ffp-contract=off).  Reference lines are relative to /root/reference/CudaRaytracer/.
-// Parity is tested against the oracle (tests/test_host_math.py, tests/test_gpu_parity.py).
+// Parity is tested against the oracle (tests/test_host_logic.py::test_host_math_golden and ::test_atanf_restatement_matches_libm, tests/test_gpu_parity.py).
 #pragma once
 #include <cfloat>
 #include <cmath>
@@ -72,7 +72,7 @@ RT_HD V3 apply_quat(Q4 q, V3 v)
 // atanf as glibc 2.35 computes it (the fdlibm algorithm: reduction to |x| < 7/16 and an
 // odd/even split degree-11 polynomial, all in fp32 with IEEE + - * /).  The reference calls
 // libm's atan(float) per pixel (raycast.cu:170); ROCm's device atanf differs from glibc by
-// ULPs, so the device evaluates this restatement instead.  tests/test_host_math.py checks
+// ULPs, so the device evaluates this restatement instead.  tests/test_host_logic.py checks
 // it against libm atanf over every float in the range ray generation can produce.
 RT_HD float atanf_fdlibm(float x)
 {

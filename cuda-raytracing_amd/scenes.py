@@ -163,4 +163,10 @@ C2_CAMERAS = {"far": (0.0, -2.6, 0.2, 0.0, 0.0, 0.0),     # 24 % coverage
               "near": (0.0, -1.25, 0.2, 0.0, 0.0, 0.0)}   # 100 %
 C2 = dict(width=1920, height=1080, D=D_REF, albedo=(0.9, 0.5, 0.2), n_tris=69936)
 C4 = dict(width=3840, height=2160, D=D_REF, albedo=(0.8, 0.8, 0.7),
-          cam_pose=(0.3, -8.5, 1.7, 0.15, 0.05, 0.0))
+          cam_pose=(0.3, -8.5, 1.7, 0.15, 0.05, 0.0), spp=16, bounces=0, lighting=0)
+# configs[2] / configs[4]: the C2 mesh with a half-mirror, slightly rough material, 64 samples per pixel, 8 specular
+# bounces and the sun + shadow pass (the reference snapshot has none of these: semantics in DESIGN.md section 7)
+C3 = dict(width=1920, height=1080, D=D_REF, albedo=(0.9, 0.5, 0.2), n_tris=69936, roughness=0.05, metallic=0.4,
+          spp=64, bounces=8, lighting=1)
+C5 = dict(C3, width=7680, height=4320)
+WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5}

@@ -78,7 +78,7 @@ int main(int argc, char** argv)
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         fps = 1.0 / dt;
         std::cout << "FPS: " << fps << "\n";
-        rc = display_image(d_img, width, height, pitch, fps, mouse_state, out_png);    // kernel.cu:298
+        rc = display_image(d_img, width, height, pitch, fps, mouse_state, out_png, camera.stream);    // kernel.cu:298
         if (rc) break;
     }
     std::cout << "FPS: " << fps << " (" << 2.0 * width * height * fps / 1e6 << " Mrays/s)" << std::endl;

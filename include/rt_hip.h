@@ -146,7 +146,12 @@ int rt_render(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t 
 #define RT_MAX_BATCH 32
 int rt_render_batch(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_imgs, size_t pitch, int32_t count,
                     void *stream, int synchronize);
-/* same frame plus the parity planes */
+/* the same production kernel as rt_render, additionally storing the accepted hit of every pixel (raycast.cu:107-127):
+ * tight [height][width] int32 DEVICE planes, -1 on a miss, either may be NULL.  For parity tests of the kernel that is
+ * actually timed (rt_render_debug runs an instrumented copy). */
+int rt_render_ids(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch, int32_t *d_hit_instance,
+                  int32_t *d_hit_triangle, void *stream, int synchronize);
+/* same frame plus the parity planes (instrumented copy of the kernel: counts every visit) */
 int rt_render_debug(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch,
                     const RtDebugPlanes *planes, void *stream, int synchronize);
 

@@ -214,8 +214,10 @@ class OracleScene:
         out.update(pl)
         return out
 
-    def render_ex(self, width, height, K, D, cam_pose, spp=1, bounces=0, lighting=0, threads=1):
-        """Extension semantics (oracle/rt_oracle.c orc_render_ex) -> dict(img, total_pops, stats)"""
+    def render_ex(self, width, height, K, D, cam_pose, spp=1, bounces=0, lighting=0, threads=1, y0=0, y1=None):
+        """Extension semantics (oracle/rt_oracle.c orc_render_ex) -> dict(img, total_pops, stats); rows [y0, y1) only
+        (the rest of img / total_pops stays zero)"""
+        y1 = height if y1 is None else y1
         img = np.zeros((height, width, 3), np.uint8)
         pops = np.zeros((height, width), np.int32)
         Kf, Df, Pf = (np.ascontiguousarray(v, np.float32) for v in (K, D, cam_pose))
@@ -227,10 +229,11 @@ class OracleScene:
             assert rc == 0
             return st
         if threads <= 1:
-            st = run(0, height)
+            st = run(y0, y1)
         else:
             from concurrent.futures import ThreadPoolExecutor
-            bands = [(a, min(a + 4, height)) for a in range(0, height, 4)]
+            step = 4 if (y1 - y0) >= 4 * threads else 1
+            bands = [(a, min(a + step, y1)) for a in range(y0, y1, step)]
             with ThreadPoolExecutor(threads) as ex:
                 st = np.sum(list(ex.map(lambda ab: run(*ab), bands)), axis=0)
         return dict(img=img, total_pops=pops, stats=dict(rays=int(st[0]), pops=int(st[1]), hits=int(st[2])))

@@ -1,0 +1,108 @@
+"""BASELINE.json configs[2], [3] and [4] at their STATED sizes through the HIP extension path (rt_render_ex /
+rt_render_ex_stripes, via Camera::render_scene).  The CPU oracle renders row bands of the same frame (a full 64-spp
+frame takes it minutes); the rest of the frame is covered by size-independent properties: the frame stitched from 8
+ranks' stripes equals the single-launch frame byte for byte, and a chunked launch equals an un-chunked one.
+Lighting block: raycast.cu:249-290 (the reference's commented-out sun / shadow pass); semantics DESIGN.md section 7."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import scene_defs as sd
+
+pytestmark = pytest.mark.gpu
+
+
+def _ex_desc(wl, path):
+    extra = dict(roughness=wl.get("roughness", 0.0), metallic=wl.get("metallic", 0.0))
+    return sd.SceneDesc([(wl["albedo"], None, extra)], [("obj", path)], [(0, 0, (0,) * 6, (1, 1, 1))])
+
+
+def _camera(rt, scenes, W, H, pose, spp, bounces, lighting):
+    cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+    cam.set_pose(pose)
+    cam.set_options(spp, bounces, lighting)
+    return cam
+
+
+def _check_bands(so, scenes, got, W, H, pose, spp, bounces, lighting, bands, rows, threads=32):
+    for y0 in bands:
+        ref = so.render_ex(W, H, scenes.scaled_K(W), scenes.D_REF, pose, spp, bounces, lighting, threads=threads, y0=y0, y1=y0 + rows)
+        nbad = int((got["img"][y0:y0 + rows] != ref["img"][y0:y0 + rows]).any(axis=2).sum())
+        assert nbad == 0, "rows %d..%d: %d pixels differ from the oracle" % (y0, y0 + rows, nbad)
+        assert np.array_equal(got["total_pops"][y0:y0 + rows], ref["total_pops"][y0:y0 + rows]), "total_pops rows %d.." % y0
+        assert ref["stats"]["rays"] >= rows * W * spp
+
+
+def _stitched(rt, sp, cam, W, H, world=8, stripe=16):
+    """The frame as `world` ranks would produce it: every virtual rank renders its stripes into its slice of the gathered
+    buffer (what the RCCL gather delivers to the root), then rt_unstripe."""
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    pitch = W * 3
+    max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+    gathered = rt.DeviceBuffer(nbytes=world * max_rows * pitch)
+    for r in range(world):
+        cam.render_scene_stripes(sp, gathered.ptr.value + r * max_rows * pitch, pitch, stripe, r, world, synchronize=True)
+    out = rt.DeviceBuffer(width_bytes=pitch, height=H)
+    rt.check(h.rt_unstripe(gathered.ptr, pitch, max_rows * pitch, out.ptr, out.pitch, W, H, stripe, world, None))
+    rt.check(h.rt_device_synchronize())
+    img = out.to_host().reshape(H, W, 3)
+    gathered.free()
+    out.free()
+    return img
+
+
+@pytest.mark.parametrize("camera", ["mid", "far"])
+def test_c3_full_size_64spp_8bounces(rt, orc, scenes, blob70k, camera):
+    """configs[2]: 70k-triangle blob, 1920x1080, 64 spp, 8 bounces, sun + shadow.  Three 16-row bands (top, silhouette /
+    centre, bottom) against the oracle: RGB and the per-pixel node pops of all rays; full frame == 8-rank stitched frame."""
+    wl = scenes.C3
+    W, H, pose = wl["width"], wl["height"], scenes.C2_CAMERAS[camera]
+    desc = _ex_desc(wl, blob70k)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = _camera(rt, scenes, W, H, pose, wl["spp"], wl["bounces"], wl["lighting"])
+    got = rt.render_ex(sp, cam)
+    assert len(np.unique(got["img"].reshape(-1, 3), axis=0)) > 100
+    so = desc.build_oracle(orc)
+    _check_bands(so, scenes, got, W, H, pose, wl["spp"], wl["bounces"], wl["lighting"], (0, 532, H - 16), 16)
+    so.close()
+    if camera == "mid":
+        assert np.array_equal(_stitched(rt, sp, cam, W, H), got["img"])
+
+
+def test_c4_full_size_atrium_16spp(rt, orc, scenes, atrium):
+    """configs[3]: 260k-triangle atrium, 3840x2160, 16 spp (camera inside, every ray hits): bands against the oracle,
+    for the plain 16-spp frame and for a variant with 2 bounces + shadow rays on a half-mirror material."""
+    wl = scenes.C4
+    W, H, pose = wl["width"], wl["height"], wl["cam_pose"]
+    for extra, (spp, bounces, lighting), bands in ((dict(), (wl["spp"], wl["bounces"], wl["lighting"]), (0, 1072, H - 16)),
+                                                   (dict(roughness=0.1, metallic=0.5), (16, 2, 1), (1200,))):
+        desc = sd.SceneDesc([(wl["albedo"], sd.checker_texture(128, 96, seed=21), extra)], [("obj", atrium)], [(0, 0, (0,) * 6, (1, 1, 1))])
+        sp = desc.build_product(rt)
+        sp.upload_to_device()
+        cam = _camera(rt, scenes, W, H, pose, spp, bounces, lighting)
+        got = rt.render_ex(sp, cam)
+        so = desc.build_oracle(orc)
+        _check_bands(so, scenes, got, W, H, pose, spp, bounces, lighting, bands, 16)
+        so.close()
+        sp.close()
+
+
+def test_c5_full_size_8k_64spp_tiled(rt, orc, scenes, blob70k):
+    """configs[4]: the blob at 7680x4320, 64 spp (8 bounces + shadows as configs[2]), tiled over 8 ranks in 16-row
+    stripes: the stitched frame equals the single-launch frame (itself rendered in chunks of sample indices: 8K x 64 spp
+    exceeds the scratch budget), and three 8-row bands equal the oracle."""
+    wl = scenes.C5
+    W, H, pose = wl["width"], wl["height"], scenes.C2_CAMERAS["mid"]
+    desc = _ex_desc(wl, blob70k)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = _camera(rt, scenes, W, H, pose, wl["spp"], wl["bounces"], wl["lighting"])
+    got = rt.render_ex(sp, cam)
+    so = desc.build_oracle(orc)
+    _check_bands(so, scenes, got, W, H, pose, wl["spp"], wl["bounces"], wl["lighting"], (8, 2160, H - 8), 8)
+    so.close()
+    assert np.array_equal(_stitched(rt, sp, cam, W, H), got["img"])

@@ -30,6 +30,11 @@ def _compare(rt, orc, desc, width, height, K, D, pose, threads=8):
     dbg = rt.render_debug(sp, cam)
     img = rt.render(sp, cam)
     assert np.array_equal(img, dbg["img"]), "debug and production kernels disagree"
+    ids = rt.render_ids(sp, cam)                                # the production (timed) kernel's own hit ids, raycast.cu:107-127
+    assert np.array_equal(ids["img"], img)
+    for n in ("hit_inst", "hit_tri"):
+        bad = int((ids[n] != ref[n]).sum())
+        assert bad == 0, "production kernel %s: %d pixels differ from the oracle" % (n, bad)
     nbad = int((img != ref["img"]).any(axis=2).sum())
     assert nbad == 0, "%d pixels differ from the oracle" % nbad
     for n in PLANES:
@@ -96,6 +101,18 @@ def test_texture_files_and_display_image(rt, orc, scenes, blob5k, tmp_path):
     expect = got.copy()
     rt.libs()[1].rth_overlay_text_bgr(expect.ctypes.data, W, H, expect.strides[0], b"FPS: 123.456789", 10, 30, 3, 0, 255, 0)
     assert np.array_equal(shown, expect) and not np.array_equal(shown, got)
+
+
+def test_identity_instance_with_negative_zeros(rt, orc, scenes, blob5k):
+    """The production kernel skips the mesh -> world transform of raycast.cu:98-104 for instances whose inverse pose is
+    the identity (rt_kernels.hip, triangle_test).  -0.0 components compare equal to 0 and keep that shortcut on, while the
+    oracle runs the full scale / translate / rotate sequence: hit ids, RGB (textured, so uv matters) and counts must agree."""
+    nz = np.float32(-0.0)
+    tex = sd.checker_texture(40, 24, seed=9)
+    for pose in ((nz, 0, nz, 0, 0, 0), (nz, nz, nz, nz, nz, nz), (0, nz, 0, nz, 0, nz)):
+        d = sd.SceneDesc([((1.0, 1.0, 1.0), tex)], [("obj", blob5k)], [(0, 0, pose, (1, 1, 1))])
+        _compare(rt, orc, d, 320, 180, scenes.scaled_K(320), scenes.D_REF, scenes.C2_CAMERAS["mid"])
+        _compare(rt, orc, d, 160, 90, scenes.scaled_K(160), scenes.D_REF, (0.3, -1.4, 0.1, 0.2, -0.1, 0.05))
 
 
 def test_ragged_sizes(rt, orc, scenes, blob5k):
@@ -357,6 +374,8 @@ def test_c4_atrium_4k(rt, orc, scenes, atrium):
     assert np.array_equal(dbg["img"], ref["img"])
     assert np.array_equal(dbg["hit_tri"], ref["hit_tri"]) and np.array_equal(dbg["pops"], ref["pops"])
     assert np.array_equal(rt.render(sp, cam), ref["img"])
+    ids = rt.render_ids(sp, cam)                               # production kernel
+    assert np.array_equal(ids["hit_tri"], ref["hit_tri"]) and np.array_equal(ids["img"], ref["img"])
     # crop property: shifting the principal point by (-x0, -y0) renders the window [x0, x0+w) x [y0, y0+h)
     x0, y0, w, h = 1440, 810, 960, 540
     Kc = list(K)
@@ -564,11 +583,14 @@ def test_8k_frame_bands(rt, orc, scenes, blob70k):
     cam = rt.Camera(W, H, K, scenes.D_REF)
     cam.set_pose(pose)
     dbg = rt.render_debug(sp, cam)
+    ids = rt.render_ids(sp, cam)                               # production kernel
     so = desc.build_oracle(orc)
     for y0 in (0, 2148, H - 24):
         ref = so.render(W, H, K, scenes.D_REF, pose, y0=y0, y1=y0 + 24, threads=24)
         for k in ("img", "hit_tri", "pops"):
             assert np.array_equal(dbg[k][y0:y0 + 24], ref[k][y0:y0 + 24]), (k, y0)
+        for k in ("img", "hit_tri"):
+            assert np.array_equal(ids[k][y0:y0 + 24], ref[k][y0:y0 + 24]), ("production", k, y0)
     so.close()
     world, stripe, pitch = 8, 16, W * 3
     max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))

@@ -379,6 +379,49 @@ def test_zlib_inflate_against_zlib(rt):
     assert host.rth_zlib_inflate(np.frombuffer(bytes(bad), np.uint8).ctypes.data, len(bad), None, 0, C.byref(n)) != 0
 
 
+def test_hostile_image_files_are_refused(rt, tmp_path):
+    """Structurally valid files built to mislead the decoders: a JPEG with a second frame header that changes the
+    sampling factors (the planes would be sized for the first, read for the second), an SOS segment with no payload, and
+    a PNG whose IDAT inflates to far more than IHDR announces (a decompression bomb).  All must be refused, not decoded."""
+    import struct
+    import zlib
+    d = os.path.join(GOLDEN, "images")
+    jpg = open(os.path.join(d, "jpg_420_q75.jpg"), "rb").read()
+    i = jpg.index(b"\xff\xc0")
+    seg_len = struct.unpack(">H", jpg[i + 2:i + 4])[0]
+    sof = bytearray(jpg[i:i + 2 + seg_len])
+    assert sof[9] == 3 and sof[11] == 0x22                              # three components, luma 2x2
+    sof[11] = 0x11                                                      # second frame header says 4:4:4
+    p = str(tmp_path / "double_sof.jpg")
+    open(p, "wb").write(jpg[:i + 2 + seg_len] + bytes(sof) + jpg[i + 2 + seg_len:])
+    with pytest.raises(rt.RtError, match="more than one frame header"):
+        rt.read_image(p)
+    j = jpg.index(b"\xff\xda")
+    p = str(tmp_path / "empty_sos.jpg")
+    open(p, "wb").write(jpg[:j] + b"\xff\xda\x00\x02" + jpg[j:])
+    with pytest.raises(rt.RtError):
+        rt.read_image(p)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    ihdr = struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)                # 4 x 4 RGB: 52 bytes of image data
+    for payload, ok in ((b"\0" * 52, True), (b"\0" * (64 << 20), False)):
+        p = str(tmp_path / ("bomb_%d.png" % ok))
+        open(p, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(payload, 9)) + chunk(b"IEND", b""))
+        if ok:
+            assert rt.read_image(p).shape == (4, 4, 3)
+        else:
+            assert os.path.getsize(p) < 100000
+            with pytest.raises(rt.RtError):
+                rt.read_image(p)
+    # rth_zlib_inflate with a destination buffer stops at its capacity
+    host = rt.libs()[1]
+    z = np.frombuffer(zlib.compress(b"x" * 100000, 9), np.uint8)
+    out = np.zeros(1000, np.uint8)
+    n = C.c_size_t(0)
+    assert host.rth_zlib_inflate(z.ctypes.data, z.size, out.ctypes.data, out.nbytes, C.byref(n)) != 0
+
+
 def test_texture_from_png_and_jpeg(rt, tmp_path):
     """Material::upload_texture takes PNG / JPEG / PPM by signature (the reference: cv::imread, Material.hpp:29-43)."""
     d = os.path.join(GOLDEN, "images")
