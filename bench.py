@@ -1,36 +1,47 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the raycast hot path on MI355X.
+"""bench.py -- the raycast hot path on MI355X, one JSON line per run.
 
-One "step" = one frame of the workload BASELINE.json's metric is quoted on (configs[1]): the
-69 936-triangle synthetic "bunny-class" OBJ, 1920x1080, 1 primary ray per pixel (the reference
-casts exactly one ray per pixel: raycast.cu:204), scene resident in HBM before timing starts.
+  python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|c4|c5] [--camera far|mid|near]
 
-  python bench.py [--gpus N --steps K --warmup W] [--camera far|mid|near] [--no-cpu-baseline]
+Workloads (BASELINE.json configs[1..4]; scenes are synthetic, see cuda-raytracing_amd/scenes.py):
+  c2  70k-triangle blob, 1920x1080, 1 primary ray per pixel -- the workload the metric is quoted on; the default
+  c3  the same mesh, 64 spp, 8 specular bounces, sun + shadow rays     (extension kernel)
+  c4  260k-triangle atrium, 3840x2160, 16 spp                           (--spp 1: the primary kernel at 4K)
+  c5  the c3 workload at 7680x4320, meant for --gpus 8 (frame tiled over the ranks, RCCL gather to rank 0)
+One "step" = one frame.  `value` = primary rays (width x height x spp) per second of wall clock over K steps, scene and
+frame buffers resident in HBM, timed between two barrier + synchronise pairs, max over ranks.
 
-Frames are issued in groups of F = min(32, K) (K // F full groups plus one shorter last group) through Camera::render_scene_batch /
-rt_render_batch: one launch renders F complete frames into F buffers, so the last long rays of one frame
-overlap the bulk of the next (the reference's own loop issues two renders per synchronise,
-kernel.cu:277-279).  K steps = K frames = K/F launches; F = 1 gives one launch per frame.
+c2 (and any 1-spp run) is a frame STREAM: frames are issued in groups of F = min(32, K) through
+Camera::render_scene_batch / rt_render_batch (one launch renders F frames along a short camera path: every frame of a
+group has its own pose), because a single 1080p frame ends in a tail of a few long rays that leaves most of the chip idle.
+The line also carries the latency figures the batch hides (config.latency): one frame per launch, two frames per launch
+and the reference's own loop of two renders per synchronise (kernel.cu:277-279).
+c3 / c4 / c5 render one frame per step (rt_render_ex: spp sample planes per launch, then a resolve pass).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the scene is replicated, every frame is
-cut into 16-row stripes dealt round-robin to the ranks (rt_render_stripes_batch), and every group of F
-frames ends with ONE RCCL collective plus rt_unstripe_batch: by default a gather whose root rotates over the
-frames of the group, fused into one all-to-all (each rank assembles F/N frames; --gather root0 gathers every
-frame to rank 0).  Consecutive groups alternate between two compute streams, the collective runs on RCCL's
-stream and the un-stripe pass on a fourth, so the exchange of group i overlaps the render of group i+1.
-Total work is fixed, so "scaling" is "strong".  Every rank checks the frames it assembled; rank 0 prints ONE JSON line
-(stdout carries nothing else: library banners are redirected to stderr).
+N > 1: the scene is replicated, the frame is cut into 16-row stripes dealt round-robin to the ranks, and the exchange
+step runs over RCCL through the C-ABI (include/rt_hip.h: rt_gather / rt_all_to_all / rt_render_tiled).  Single frames
+(c3-c5) are gathered to rank 0 (Camera::render_scene_tiled).  The c2 stream exchanges once per group of F frames, by
+default with a rotating root (each rank assembles F/N frames; one fused all-to-all, --gather root0 for the plain gather),
+double-buffered so that the exchange of group i overlaps the render of group i + 1 (tiling.StripePipeline).
+torch.distributed carries only the control plane (barriers, the max over ranks, the RCCL unique id).
+`python bench.py --gpus N` started WITHOUT torchrun launches its N ranks itself (fresh child processes via
+torch.distributed.run, before this process touches a GPU) and relays their one line.
+
+stdout carries exactly one line, the result; everything else (library banners included) goes to stderr.
 """
 import argparse
 import ctypes as C
 import importlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch                      # imported BEFORE librt_hip.so so both share one HIP runtime
+import torch                      # imported BEFORE librt_hip.so so both share one HIP runtime (and one RCCL)
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,19 +50,43 @@ rt = importlib.import_module("cuda-raytracing_amd")
 scenes = importlib.import_module("cuda-raytracing_amd.scenes")
 tiling = importlib.import_module("cuda-raytracing_amd.tiling")
 
+METRIC = "Mrays/sec + ms/frame, 70k-tri OBJ at 1920x1080 1spp; 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_HZ = 2.4e9                 # max shader clock
+N_SIMD = 256 * 4
+VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 2 / 1e9     # wave64 VALU instructions per second: 2 cycles each on a SIMD-32 (MICROARCH "Wave scheduling")
+L1_PEAK_GBS = 256 * 64 * CLOCK_HZ / 1e9           # vector L1: one 64-B access per CU per clock
 STRIPE_ROWS = 16
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def camera_path(base, n):
+    """n poses on a small closed loop around `base` (a few millimetres of travel and a fraction of a degree of yaw):
+    every frame of a group is a different frame, the work per frame stays that of the named camera."""
+    out = []
+    for k in range(n):
+        a = 2.0 * math.pi * k / max(n, 1)
+        p = list(base)
+        p[0] += 0.004 * math.sin(a)
+        p[2] += 0.004 * (math.cos(a) - 1.0)                     # (k = 0 is `base` itself: the pinned frame)
+        p[3] += 0.002 * math.sin(a)
+        out.append(tuple(p))
+    return out
 
 
 def algorithmic_bytes(st):
     """bytes = 24*N_aabb + 8*N_interior_pops + 8*N_leaf_pops + 52*N_tri_tests
-    + 24*N_inside_hits + 3*rays, N_interior_pops = N_aabb / 2."""
+    + 24*N_inside_hits + 3*rays, N_interior_pops = N_aabb / 2.  Every fetch counted as if it missed all caches."""
     interior = st["aabb"] // 2
     leaf = st["pops"] - interior
     return 24 * st["aabb"] + 8 * interior + 8 * leaf + 52 * st["tris"] + 24 * st["inside"] + 3 * st["rays"]
 
 
-def scene_path(workload="c2"):
+def scene_path(workload):
     d = os.path.join(ROOT, ".scene_cache")
     os.makedirs(d, exist_ok=True)
     if workload == "c4":
@@ -65,66 +100,170 @@ def scene_path(workload="c2"):
     return p
 
 
-def cpu_baseline(obj, W, H, K, D, pose, gpu_stats, albedo):
-    """The oracle (oracle/rt_oracle.c, kind "port") timed on this host: one full frame of the same
-    workload, single-threaded and on all cores (row bands).  Also cross-checks the GPU's counters."""
+def oracle_scene(obj, wl):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     orc.build_oracle()
     o = orc.oracle()
-    m = o.obj_load(obj)
     s = orc.OracleScene(o)
-    s.add_material(albedo)
-    s.add_mesh(m)
+    s.add_material(wl["albedo"], roughness=wl.get("roughness", 0.0), metallic=wl.get("metallic", 0.0))
+    s.add_mesh(o.obj_load(obj))
     s.add_instance(0, 0)
-    rows1 = max(8, H // 8)                                 # 1/8 of the frame, centred, single thread
-    y0 = (H - rows1) // 2
-    t = time.perf_counter()
-    s.render(W, H, K, D, pose, y0=y0, y1=y0 + rows1, planes=False, threads=1)
-    t1 = time.perf_counter() - t
+    return s
+
+
+def cpu_baseline_stream(obj, wl, W, H, K, D, pose, gpu_stats):
+    """The oracle (oracle/rt_oracle.c, kind "port") timed on this host on the same frame: all cores (row bands, about
+    10 s of work) and one core (one full frame).  Also cross-checks the debug kernel's visit counters."""
+    s = oracle_scene(obj, wl)
     cores = min(os.cpu_count() or 1, 32)
-    reps, tn = 0, 0.0
-    full = None
-    while tn < 10.0 and reps < 20:                         # ~10 s of all-core work
+    reps, tn, full = 0, 0.0, None
+    while tn < 10.0 and reps < 20:
         t = time.perf_counter()
         full = s.render(W, H, K, D, pose, planes=False, threads=cores)
         tn += time.perf_counter() - t
         reps += 1
+    t = time.perf_counter()
+    s.render(W, H, K, D, pose, planes=False, threads=1)
+    t1 = time.perf_counter() - t
     st = full["stats"]
-    counters_match = all(int(st[k]) == int(gpu_stats[k]) for k in ("pops", "aabb", "tris", "inside"))
+    ok = all(int(st[k]) == int(gpu_stats[k]) for k in ("pops", "aabb", "tris", "inside"))
     s.close()
     return {"value": round(W * H * reps / tn / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d full %dx%d frames of the same scene/camera, row bands over %d threads" % (reps, W, H, cores),
-            "value_1core": round(W * rows1 / t1 / 1e6, 3), "sample_1core": "%d centre rows, 1 thread" % rows1,
-            "gpu_counters_match_oracle": bool(counters_match)}
+            "value_1core": round(W * H / t1 / 1e6, 3), "sample_1core": "1 full %dx%d frame, 1 thread" % (W, H),
+            "gpu_counters_match_oracle": bool(ok)}, full["img"]
+
+
+def cpu_baseline_frame(obj, wl, W, H, K, D, pose, opts, gpu_img):
+    """Frame workloads: the oracle renders centred row bands of the same frame (all samples, bounces and shadow rays) on
+    all cores until about 10 s of work are done; the same rows of the GPU frame must be equal."""
+    s = oracle_scene(obj, wl)
+    cores = min(os.cpu_count() or 1, 32)
+    spp, bounces, lighting = opts
+    done, tn, rows, rays_all, ok = 0, 0.0, cores, 0, True
+    y = max(0, H // 2 - cores // 2)
+    while tn < 10.0 and y + rows <= H and done < H:
+        t = time.perf_counter()
+        ref = s.render_ex(W, H, K, D, pose, spp, bounces, lighting, threads=cores, y0=y, y1=y + rows)
+        tn += time.perf_counter() - t
+        ok = ok and np.array_equal(ref["img"][y:y + rows], gpu_img[y:y + rows])
+        rays_all += ref["stats"]["rays"]
+        done += rows
+        y += rows
+        rows = min(rows * 2, H - y) if y < H else 0
+        if rows <= 0:
+            break
+    s.close()
+    return {"value": round(W * done * spp / tn / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d rows of the same %dx%d frame (%d spp, %d bounces, lighting %d: %.1f rays cast per primary ray), row bands over %d threads"
+                      % (done, W, H, spp, bounces, lighting, rays_all / max(W * done * spp, 1), cores),
+            "gpu_rows_match_oracle": bool(ok)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as fresh child processes (nothing in THIS process
+    has touched a GPU) and relay their one result line."""
+    if args.debug_backend == "nccl" and torch.cuda.device_count() < args.gpus:       # (device_count does not initialise HIP)
+        sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith('{"metric"')]
+    for ln in r.stdout.decode(errors="replace").splitlines():
+        if not ln.startswith('{"metric"'):
+            log(ln)
+    if r.returncode != 0 or len(lines) != 1:
+        sys.exit("bench.py: the %d-rank run failed (exit code %d, %d result lines)" % (args.gpus, r.returncode, len(lines)))
+    print(lines[0], flush=True)
+    sys.exit(0)
+
+
+def counters_entry(key):
+    """Committed rocprofv3 PMC summary of this workload, normalised per frame (tools/summarize_profile.py)."""
+    try:
+        return json.load(open(COUNTERS_JSON)).get(key)
+    except Exception:
+        return None
+
+
+def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_frame=None):
+    """What bounds the kernel.  Instruction and cache-access counts per frame are properties of (scene, camera, size) --
+    the kernel's control flow depends on nothing else -- so they come from the committed PMC pass of the same workload
+    (profiles/r02_counters.json); the time they are divided by is measured live, here.  `share` = the fraction of
+    every frame this rank renders."""
+    e = counters_entry(key)
+    sec = kernel_ms * 1e-3
+    out = {"kernel": kernel, "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch, "profile_key": key}
+    if e is None:
+        out.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s", "frac": None,
+                    "traffic": None, "note": "no PMC profile committed for this workload key: only the live kernel time is known"})
+    else:
+        n = frames_per_launch * share
+        valu = e["valu_insts_per_frame"] * n / sec / 1e9
+        out.update({"bound": "valu_issue", "achieved": round(valu, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
+                    "frac": round(valu / VALU_PEAK_GINST, 4),
+                    "traffic": int(e["hbm_bytes_per_frame"] * n) if e.get("hbm_bytes_per_frame") is not None else None,
+                    "lanes_active_per_valu": e.get("lanes_active_per_valu"),
+                    "useful_lane_slot_frac": round(valu / VALU_PEAK_GINST * e["lanes_active_per_valu"] / 64.0, 4) if e.get("lanes_active_per_valu") else None,
+                    "l1_bw_frac": round(e["tcp_accesses_per_frame"] * 64 * n / sec / 1e9 / L1_PEAK_GBS, 4) if e.get("tcp_accesses_per_frame") else None,
+                    "hbm_physical_frac": round(e["hbm_bytes_per_frame"] * n / sec / 1e9 / HBM_PEAK_GBS, 5) if e.get("hbm_bytes_per_frame") is not None else None,
+                    "profile": e.get("tag"),
+                    "peaks": "VALU: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; L1: 256 CUs x 64 B/clk; HBM 8 TB/s"})
+    if alg_bytes_per_frame is not None:
+        a = alg_bytes_per_frame * frames_per_launch * share / sec / 1e9
+        out["hbm_algorithmic"] = {"achieved_GBs": round(a, 1), "frac_of_8TBs": round(a / HBM_PEAK_GBS, 4), "bytes_per_launch": int(alg_bytes_per_frame * frames_per_launch * share),
+                                  "note": "SURVEY 8(d) bytes (every record fetch counted as an HBM miss) / time; exceeds 1 because the working set "
+                                          "is L1/L2/MALL resident -- not a bound, kept for comparison with round 1"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=960)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
-                    help="c2 = the metric's workload (70k-triangle blob, 1920x1080); c4 = BASELINE configs[3] scene (260k-triangle atrium, 3840x2160)")
+    ap.add_argument("--steps", type=int, default=None, help="frames to time (default: 960 for the 1-spp stream, 20 for spp / bounce workloads)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames before (default 64 / 3)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = as many as one launch takes (32), reduced to a divisor of --steps")
+    ap.add_argument("--spp", type=int, default=0, help="0 = the workload's own (c2 1, c3 64, c4 16, c5 64)")
+    ap.add_argument("--bounces", type=int, default=-1)
+    ap.add_argument("--lighting", type=int, default=-1)
+    ap.add_argument("--metallic", type=float, default=-1.0, help="override the workload's Material::metallic (bounce weight)")
+    ap.add_argument("--roughness", type=float, default=-1.0, help="override the workload's Material::roughness")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="stream workloads: 0 = as many as one launch takes (32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the F = 1 / F = 2 latency figures")
     ap.add_argument("--debug-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: rehearsal of the N > 1 logic with host-staged gathers (several ranks may share one GPU); never for numbers")
-    ap.add_argument("--gather", default="rotate", choices=["rotate", "root0"],
-                    help="N > 1: rotate = the gather's root rotates over the frames of a group, fused into one all-to-all (every rank "
-                         "assembles 1/N of the frames); root0 = every frame is gathered to rank 0")
-    ap.add_argument("--one-stream", action="store_true", help="N > 1: launch every group on the same stream (no overlap of consecutive launches)")
-    ap.add_argument("--two-streams", action="store_true", help="one GPU: alternate consecutive groups between two streams as the N > 1 path does")
+                    help="gloo: rehearsal of the N > 1 logic with host-staged exchanges (several ranks may share one GPU); never for numbers")
+    ap.add_argument("--gather", default="auto", choices=["auto", "rotate", "root0"],
+                    help="N > 1 stream workloads: rotate = the gather's root rotates over the frames of a group (one fused all-to-all), "
+                         "root0 = every frame to rank 0; auto = rotate for streams, root0 for single frames")
+    ap.add_argument("--one-stream", action="store_true", help="N > 1: launch every group on the same compute stream")
+    ap.add_argument("--two-streams", action="store_true", help="one GPU: alternate consecutive groups between two streams")
     ap.add_argument("--force-collective", action="store_true",
-                    help="run the N > 1 path (stripes, RCCL gather, un-stripe) even with one rank: a check of that path on a one-GPU box, not the N = 1 number")
-    ap.add_argument("--latency-probe", action="store_true", help="also time 20 single-frame launches (adds launches of the same kernel)")
+                    help="run the N > 1 path (stripes, RCCL exchange, un-stripe) even with one rank: a check of that path on a one-GPU box")
     args = ap.parse_args()
+    wl0 = scenes.WORKLOADS[args.workload]
+    one_spp = ((args.spp or wl0.get("spp", 1)), (args.bounces if args.bounces >= 0 else wl0.get("bounces", 0)),
+               (args.lighting if args.lighting >= 0 else wl0.get("lighting", 0))) == (1, 0, 0)
+    if args.steps is None:
+        args.steps = 960 if one_spp else 20
+    if args.warmup is None:
+        args.warmup = 64 if one_spp else 3
+    if args.steps < 1:
+        sys.exit("bench.py: --steps must be at least 1")
 
-    # stdout carries exactly one line, the result: anything libraries print there (RCCL's version banner, for one) goes to
-    # stderr instead -- file descriptor 1 is pointed at stderr and the JSON is written to the saved descriptor at the end
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+
+    # stdout carries exactly one line, the result: fd 1 is pointed at stderr and the JSON goes to the saved descriptor
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
@@ -132,13 +271,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    dist_on = world > 1 or args.force_collective                # stripes + gather + un-stripe instead of whole-frame launches
+    dist_on = world > 1 or args.force_collective                # stripes + exchange + un-stripe instead of whole-frame launches
     rehearsal = dist_on and args.debug_backend == "gloo"
     if rehearsal:
         local_rank %= max(torch.cuda.device_count(), 1)          # ranks may share a device in the rehearsal
@@ -153,11 +288,23 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     rt.build()
-    rt.libs()
-    wl = scenes.C4 if args.workload == "c4" else scenes.C2
+    hlib = rt.libs()[0]
+    wl = dict(scenes.WORKLOADS[args.workload])
+    if args.metallic >= 0:
+        wl["metallic"] = args.metallic
+    if args.roughness >= 0:
+        wl["roughness"] = args.roughness
     W, H = args.width or wl["width"], args.height or wl["height"]
+    spp = args.spp or wl.get("spp", 1)
+    bounces = args.bounces if args.bounces >= 0 else wl.get("bounces", 0)
+    lighting = args.lighting if args.lighting >= 0 else wl.get("lighting", 0)
+    stream_mode = (spp, bounces, lighting) == (1, 0, 0)           # the primary kernel, frames in groups; else one frame per step
     K, D = scenes.scaled_K(W), scenes.D_REF
-    pose = scenes.C4["cam_pose"] if args.workload == "c4" else scenes.C2_CAMERAS[args.camera]
+    base_pose = wl["cam_pose"] if args.workload == "c4" else scenes.C2_CAMERAS[args.camera]
+    cam_name = "inside" if args.workload == "c4" else args.camera
+    key = "%s_%s_%dx%d_%d_%d_%d" % (args.workload, cam_name, W, H, spp, bounces, lighting)
+    if args.metallic >= 0 or args.roughness >= 0:
+        key += "_m%g_r%g" % (wl.get("metallic", 0.0), wl.get("roughness", 0.0))
     obj = scene_path(args.workload) if rank == 0 else None
     if dist_on:
         dist.barrier()
@@ -166,119 +313,159 @@ def main():
     # ---- scene: the reference's call sequence (kernel.cu:166-243) through the host C++ API ----
     mesh = rt.Mesh.load_obj(obj)
     scene = rt.Scene()
-    scene.add_material(wl["albedo"])
+    scene.add_material(wl["albedo"], roughness=wl.get("roughness", 0.0), metallic=wl.get("metallic", 0.0))
     scene.add_mesh(mesh)
     scene.add_mesh_instance(0, 0)
     scene.upload_to_device()
-    cam = rt.Camera(W, H, K, D)
-    cam.set_pose(pose)
     stream = torch.cuda.current_stream().cuda_stream
-    cam.set_stream(stream)
-    # N > 1: consecutive groups are launched on two alternating streams (one camera object bound to each): the last waves
-    # of a launch -- a few long silhouette rays on an otherwise empty chip -- then overlap the first waves of the next one,
-    # which matters when a rank's share of a group is short.  One GPU keeps everything on one stream by default (worth 1-4 %
-    # there, --two-streams): rocprofv3's per-kernel durations then stay comparable with the hipEvent figure below, while
-    # overlapping launches each look longer than they cost.
-    two = (dist_on or args.two_streams) and not args.one_stream and not rehearsal   # (the rehearsal stages through the host on one stream)
-    cstreams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else None
-    cams = [cam, cam]
-    if two:
-        cams = [rt.Camera(W, H, K, D), rt.Camera(W, H, K, D)]
-        for c_, s_ in zip(cams, cstreams):
-            c_.set_pose(pose)
-            c_.set_stream(s_.cuda_stream)
 
-    # A launch should carry several frames' worth of work for THIS GPU (with N GPUs a rank renders only 1/N of each
-    # frame), so frames go in groups as large as one launch allows (RT_MAX_BATCH = 32): K frames = K // F full groups
-    # plus one last group of K % F frames.
-    f_max = args.frames_per_launch if args.frames_per_launch > 0 else 32
-    F = max(1, min(f_max, 32, args.steps if args.steps > 0 else 1))
-    groups = [F] * (args.steps // F) + ([args.steps % F] if args.steps % F else [])
-    warmup_req = args.warmup
-    warm_groups = [F] * ((args.warmup + F - 1) // F)             # whole groups: at least the requested warm-up
-    args.warmup = len(warm_groups) * F
+    def make_camera(s=None):
+        c = rt.Camera(W, H, K, D)
+        c.set_pose(base_pose)
+        c.set_options(spp, bounces, lighting)
+        c.set_stream(stream if s is None else s.cuda_stream)
+        return c
+    cam = make_camera()
     pitch = W * 3
-    hlib = rt.libs()[0]
-    rotate = dist_on and args.gather == "rotate"
-    # finished frames of one group that THIS rank holds: all F (one GPU, or root0 on rank 0), or its share of a rotating gather
-    my_frames = (lambda c: tiling.rotating_plan(c, world)[3][rank]) if rotate else (lambda c: c if (rank == 0 or not dist_on) else 0)
-    slots = tiling.rotating_plan(F, world)[0] if rotate else F   # frame slots per local buffer (>= world for the rotating exchange)
-    frames = torch.empty((max(my_frames(F), 1), H, pitch), dtype=torch.uint8, device=dev)
-    frames_b = [frames, torch.empty_like(frames)] if not dist_on else None   # one GPU: groups alternate between two frame sets
-    if dist_on:
-        rows = []
-        for r in range(world):
-            n = C.c_int32(0)
-            rt.check(hlib.rt_stripe_rows(H, STRIPE_ROWS, r, world, C.byref(n)))
-            rows.append(n.value)
-        max_rows = max(rows)
-        # per buffer: F frames x this rank's (padded) stripe rows; what comes back is source-rank-major
-        local = [torch.zeros((slots * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
-        if rotate:
-            gathered = [torch.empty((world * tiling.rotating_plan(F, world)[1][rank] * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
-        else:
-            gathered = [torch.empty((world, F * max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
-        if rehearsal:                                            # gloo cannot move device tensors: stage through the host
-            local_dev, gathered_dev = local, gathered
-            local = [torch.zeros_like(t, device="cpu") for t in local_dev]
-            gathered = [torch.empty_like(t, device="cpu") if t is not None else None for t in gathered_dev]
-
     timer = rt.Timer()
 
-    frame_ptrs = [[fb[f].data_ptr() for f in range(F)] for fb in frames_b] if not dist_on else None
-    dev_local = (local_dev if rehearsal else local) if dist_on else None
-    dev_gathered = (gathered_dev if rehearsal else gathered) if dist_on else None
-    local_ptrs = [tiling.batch_local_ptrs(dev_local[b].data_ptr(), F, max_rows, pitch) for b in range(2)] if dist_on else None
-
-    counts = sorted(set(groups + [F]))                           # a full group and, possibly, the shorter last one
-    render_single_calls = {(b, c): cams[b].prepared_batch(scene, [pose] * c, frame_ptrs[b][:c], pitch)
-                           for b in range(2) for c in counts} if not dist_on else None
-    render_local_calls = {(b, c): cams[b].prepared_batch(scene, [pose] * c, local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
-                          for b in range(2) for c in counts} if dist_on else None
-    timing_call = (cam.prepared_batch(scene, [pose] * F, local_ptrs[0][:F], pitch, stripes=(STRIPE_ROWS, rank, world)) if dist_on else
-                   cam.prepared_batch(scene, [pose] * F, frame_ptrs[0][:F], pitch))      # on `stream`, for the hipEvent timing below
-    group_count = [F, F]                                         # frames in the group that currently occupies buffer b
-
-    def render_local(b):
-        render_local_calls[(b, group_count[b])]()
+    # ---- the exchange backend (N > 1): RCCL through the C-ABI, or the gloo rehearsal ----
+    comm = exchange = None
+    if dist_on:
         if rehearsal:
-            local[b].copy_(dev_local[b])
-
-    def unstripe(b):
-        count = my_frames(group_count[b])
-        if count == 0:
-            return
-        if rehearsal:
-            dev_gathered[b].copy_(gathered[b])
-        # rank r's block holds its stripes of my `count` frames (rotate) or of all F frame slots (root0)
-        rank_stride = (tiling.rotating_plan(group_count[b], world)[1][rank] if rotate else F) * max_rows * pitch
-        rt.check(hlib.rt_unstripe_batch(dev_gathered[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames.data_ptr(), pitch, H * pitch,
-                                        count, W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
-
-    def exchange(b):
-        if rotate:
-            return tiling.exchange_rotating(local[b], gathered[b], group_count[b], world, max_rows)
-        return tiling.exchange_to_root(local[b], gathered[b], rank)
-
-    # un-stripe passes run on their own stream: a rank renders group i+1 while group i is exchanged and re-ordered
-    side = torch.cuda.Stream() if dist_on and not rehearsal else None
-    pipe = tiling.StripePipeline(render_local, exchange, unstripe, assembles=rotate or rank == 0, side_stream=side,
-                                 compute_streams=cstreams) if dist_on else None
-
-    def step_group(i, count):
-        if not dist_on:
-            render_single_calls[(i & 1, count)]()
+            exchange = tiling.TorchExchange(rank, world)
         else:
-            pipe.release(i & 1)                                  # buffer i & 1 is about to be reused: its count changes below
-            group_count[i & 1] = count
-            pipe.step(i)
+            box = [rt.Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            comm = rt.Comm(box[0], rank, world)
+            exchange = tiling.RcclExchange(comm)
+        rows = [tiling.stripe_rows(H, STRIPE_ROWS, r, world) for r in range(world)]
+        max_rows = max(rows)
 
     def sync():
         if dist_on:
-            pipe.drain()
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
+    if stream_mode:
+        res = run_stream(args, locals())
+    else:
+        res = run_frames(args, locals())
+    if rank == 0:
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
+    if dist_on:
+        dist.barrier()
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+
+
+def base_line(args, env, value, dt, warmup_done, config, roof, extra):
+    world, rehearsal = env["world"], env["rehearsal"]
+    out = {"metric": METRIC, "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world}
+    if rehearsal:
+        out["REHEARSAL_NOT_A_MEASUREMENT"] = "gloo backend, host-staged exchanges"
+    if args.force_collective and world == 1:
+        out["FORCED_COLLECTIVE_PATH"] = "N > 1 code path run with one rank"
+    out.update({"steps": args.steps, "warmup": args.warmup, "warmup_frames_done": warmup_done,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic", "config": config, "roofline": roof})
+    out.update(extra)
+    return out
+
+
+def run_stream(args, env):
+    """1 primary ray per pixel (render_kernel): K frames in groups of F."""
+    g = env
+    rank, world, dist_on, rehearsal, dev = g["rank"], g["world"], g["dist_on"], g["rehearsal"], g["dev"]
+    W, H, K, D, pitch, scene, cam, stream, hlib, timer = g["W"], g["H"], g["K"], g["D"], g["pitch"], g["scene"], g["cam"], g["stream"], g["hlib"], g["timer"]
+    base_pose, exchange, make_camera = g["base_pose"], g["exchange"], g["make_camera"]
+    rotate = dist_on and args.gather in ("auto", "rotate")
+    two = (dist_on or args.two_streams) and not args.one_stream and not rehearsal
+    cstreams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else None
+    cams = [make_camera(cstreams[0]), make_camera(cstreams[1])] if two else [cam, cam]
+
+    f_max = args.frames_per_launch if args.frames_per_launch > 0 else 32
+    F = max(1, min(f_max, 32, args.steps if args.steps > 0 else 1))
+    groups = [F] * (args.steps // F) + ([args.steps % F] if args.steps % F else [])
+    warm_groups = [F] * ((args.warmup + F - 1) // F)             # whole groups: at least the requested warm-up
+    poses = camera_path(base_pose, F)                            # frame f of every group uses poses[f]
+    counts = sorted(set(groups + [F]))
+
+    if not dist_on:
+        frames_b = [torch.empty((F, H, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]   # groups alternate between two frame sets
+        calls = {(b, c): cams[b].prepared_batch(scene, poses[:c], [frames_b[b][f].data_ptr() for f in range(c)], pitch)
+                 for b in range(2) for c in counts}
+
+        def step_group(i, count):
+            if two:
+                with torch.cuda.stream(cstreams[i & 1]):
+                    calls[(i & 1, count)]()
+            else:
+                calls[(i & 1, count)]()
+        timing_call = cam.prepared_batch(scene, poses, [frames_b[0][f].data_ptr() for f in range(F)], pitch)
+        pipe = None
+        my_frames = lambda c: list(range(c))                     # frame indices (within the group) this rank holds afterwards
+        frames_of = lambda b: frames_b[b]
+    else:
+        max_rows = g["max_rows"]
+        slots = tiling.rotating_plan(F, world)[0] if rotate else F
+        on_dev = exchange.on_device
+        mk = lambda shape, zero=False: (torch.zeros if zero else torch.empty)(shape, dtype=torch.uint8, device=dev)
+        local_dev = [mk((slots * max_rows, pitch), True) for _ in range(2)]
+        if rotate:
+            recv_shape = (world * tiling.rotating_plan(F, world)[1][rank] * max_rows, pitch)
+            gathered_dev = [mk(recv_shape) for _ in range(2)]
+        else:
+            gathered_dev = [mk((world, F * max_rows, pitch)) if rank == 0 else None for _ in range(2)]
+        frames_b = [mk((F, H, pitch)) for _ in range(2)]
+        local = local_dev if on_dev else [torch.zeros_like(t, device="cpu") for t in local_dev]
+        gathered = gathered_dev if on_dev else [torch.empty_like(t, device="cpu") if t is not None else None for t in gathered_dev]
+        local_ptrs = [tiling.batch_local_ptrs(local_dev[b].data_ptr(), F, max_rows, pitch) for b in range(2)]
+        calls = {(b, c): cams[b].prepared_batch(scene, poses[:c], local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
+                 for b in range(2) for c in counts}
+        timing_call = cam.prepared_batch(scene, poses, local_ptrs[0][:F], pitch, stripes=(STRIPE_ROWS, rank, world))
+        group_count = [F, F]                                     # frames in the group that currently occupies buffer set b
+
+        def my_frames(c):                                        # frame indices (within a group of c) this rank assembles
+            if rotate:
+                _, cnt, off, real = tiling.rotating_plan(c, world)
+                return [off[rank] + k for k in range(real[rank])]
+            return list(range(c)) if rank == 0 else []
+
+        def render_fn(b):
+            calls[(b, group_count[b])]()
+            if not on_dev:
+                local[b].copy_(local_dev[b])                    # (synchronous: the rehearsal stages through the host)
+
+        def exchange_fn(b):
+            if rotate:
+                exchange.rotating(local[b], gathered[b], group_count[b], max_rows)
+            else:
+                exchange.to_root(local[b], gathered[b] if rank == 0 else None, 0)
+
+        def unstripe_fn(b):
+            n = len(my_frames(group_count[b]))
+            if n == 0:
+                return
+            if not on_dev:
+                gathered_dev[b].copy_(gathered[b])
+            # rank r's block holds its stripes of my frames (rotate) or of all F frame slots (root0)
+            rank_stride = (tiling.rotating_plan(group_count[b], world)[1][rank] if rotate else F) * max_rows * pitch
+            rt.check(hlib.rt_unstripe_batch(gathered_dev[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames_b[b].data_ptr(), pitch,
+                                            H * pitch, n, W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
+
+        pipe = tiling.StripePipeline(render_fn, exchange_fn, unstripe_fn, assembles=rotate or rank == 0,
+                                     compute_streams=cstreams, comm_stream=torch.cuda.Stream() if on_dev else None)
+
+        def step_group(i, count):
+            group_count[i & 1] = count                           # (read by the callbacks while they issue group i, i.e. inside step())
+            pipe.step(i)
+        frames_of = lambda b: frames_b[b]
+
+    sync = g["sync"]
     for i, c in enumerate(warm_groups):
         step_group(i, c)
     sync()
@@ -286,6 +473,8 @@ def main():
     for i, c in enumerate(groups):
         step_group(i, c)
     t_issue = time.perf_counter() - t0                           # host time to issue all groups (must stay below the GPU's)
+    if pipe is not None:
+        pipe.drain()
     sync()
     dt = time.perf_counter() - t0
     if dist_on:
@@ -293,96 +482,199 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # ---- kernel-only duration with hipEvents on the launch stream (roofline numerator) ----
-    kernel_ms = None
+    # ---- kernel-only duration with hipEvents on the launch stream (roofline denominator); latency figures ----
+    kernel_ms, latency = None, None
     if rank == 0:
         n = max(10, min(len(groups), 100))
-        group_count[0] = F
         torch.cuda.synchronize()
         timer.start(stream)
         for _ in range(n):
             timing_call()
         timer.stop(stream)
         kernel_ms = timer.elapsed_ms() / n                      # one launch = F frames (this rank's stripes of them)
-        single_ms = None
-        if args.latency_probe:                                  # latency of a single-frame launch, for reference
-            one = rt.DeviceBuffer(width_bytes=W * 3, height=H)
-            torch.cuda.synchronize()
-            timer.start(stream)
-            for _ in range(20):
-                cam.render_scene(scene, one.ptr, one.pitch)
-            timer.stop(stream)
-            single_ms = timer.elapsed_ms() / 20
-            one.free()
+        if not dist_on and not args.no_latency:
+            latency = measure_latency(g, poses, kernel_ms / F)
     if dist_on:
         dist.barrier()
 
-    # ---- every rank checks the frames it assembled in the last group against the debug kernel's frame ----
-    dbg = rt.render_debug(scene, cam)
-    mine = my_frames(groups[-1] if groups else F)
-    last_frames = frames if dist_on else frames_b[(len(groups) - 1) & 1]
-    frames_host = last_frames.cpu().numpy().reshape(-1, H, W, 3)
-    frame_ok = bool(all(np.array_equal(frames_host[f], dbg["img"]) for f in range(mine)))
+    # ---- every rank checks frames it assembled in the last group against the debug kernel at the same pose ----
+    last_b, last_c = (len(groups) - 1) & 1, (groups[-1] if groups else F)
+    mine = my_frames(last_c)
+    held = frames_of(last_b).cpu().numpy().reshape(F, H, W, 3)
+    frame_ok, ids_ok, dbg0 = True, True, None
+    for k, f in enumerate(mine):
+        if k not in (0, len(mine) // 2, len(mine) - 1):
+            continue
+        cam.set_pose(poses[f])
+        cam.set_stream(stream)
+        dbg = rt.render_debug(scene, cam)
+        slot = k if (dist_on and rotate) else f                  # rotating exchange: my k-th frame sits in slot k of my frame set
+        frame_ok = frame_ok and bool(np.array_equal(held[slot], dbg["img"]))
+        ids = rt.render_ids(scene, cam)                          # the production kernel's own hit ids
+        ids_ok = ids_ok and bool(np.array_equal(ids["hit_tri"], dbg["hit_tri"]) and np.array_equal(ids["hit_inst"], dbg["hit_inst"]))
     if dist_on:
-        flag = torch.tensor([int(frame_ok)], dtype=torch.int32, device="cpu" if rehearsal else dev)
+        flag = torch.tensor([int(frame_ok), int(ids_ok)], dtype=torch.int32, device="cpu" if rehearsal else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        frame_ok = bool(flag.item())
+        frame_ok, ids_ok = bool(flag[0].item()), bool(flag[1].item())
+    if rank != 0:
+        return None
 
+    cam.set_pose(poses[0])
+    dbg = rt.render_debug(scene, cam)                           # per-frame work counters (same traversal, instrumented)
+    st = {"rays": W * H, "pops": int(dbg["pops"].sum()), "aabb": int(dbg["aabb"].sum()), "tris": int(dbg["tris"].sum()),
+          "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
+    alg = algorithmic_bytes(st)
+    mesh, wl = g["mesh"], g["wl"]
+    name = {"c2": "C2 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ"}.get(args.workload, args.workload)
+    config = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s; every frame of a group has its own pose "
+                          "(a 4 mm loop around that camera)" % (name, mesh.num_triangles, mesh.num_nodes, W, H, g["cam_name"], str(tuple(base_pose[:3]))),
+              "key": g["key"], "width": W, "height": H, "spp": 1, "bounces": 0, "lighting": 0,
+              "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
+                             % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames through rt_all_to_all (the gather's root rotates: each rank assembles 1/N of the frames)" % F if rotate
+                                                  else ", one RCCL gather to rank 0 per %d frames through rt_gather" % F) if dist_on else ""),
+              "frames_per_launch": F, "host_issue_ms_per_launch": round(t_issue / max(len(groups), 1) * 1e3, 3),
+              "single_frame_launch_ms": None if latency is None else latency["f1_kernel_ms"], "latency": latency,
+              "coverage": round(st["hits"] / st["rays"], 4),
+              "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
+              "algorithmic_bytes_per_ray": round(alg / st["rays"], 1)}
+    roof = roofline("render_kernel<false,false>", g["key"], kernel_ms, F, 1.0 / world, alg)
+    extra = {"frame_matches_debug_kernel": frame_ok, "production_hit_ids_match_debug_kernel": ids_ok}
+    value = W * H * args.steps / dt / 1e6
+    out = base_line(args, g, value, dt, len(warm_groups) * F, config, roof, extra)
+    if not dist_on and not args.no_cpu_baseline:
+        cb, ref_img = cpu_baseline_stream(g["obj"], wl, W, H, K, D, poses[0], st)
+        cb["gpu_frame_matches_oracle"] = bool(np.array_equal(ref_img, dbg["img"]))
+        out["cpu_baseline"] = cb
+    return out
+
+
+def measure_latency(g, poses, f32_ms_per_frame):
+    """What batching hides: one frame per launch, two frames per launch, and the reference's own loop
+    (two render calls, then a device synchronise: kernel.cu:277-279).  Every frame has its own pose."""
+    W, H, scene, cam, stream, timer, dev, pitch = g["W"], g["H"], g["scene"], g["cam"], g["stream"], g["timer"], g["dev"], g["pitch"]
+    bufs = torch.empty((2, H, pitch), dtype=torch.uint8, device=dev)
+    n = 40
+    singles = [cam.prepared_batch(scene, [poses[k % len(poses)]], [bufs[k & 1].data_ptr()], pitch) for k in range(n)]
+    pairs = [cam.prepared_batch(scene, [poses[(2 * k) % len(poses)], poses[(2 * k + 1) % len(poses)]], [bufs[0].data_ptr(), bufs[1].data_ptr()], pitch)
+             for k in range(n // 2)]
+    for c in singles[:4]:
+        c()
+    torch.cuda.synchronize()
+    timer.start(stream)
+    for c in singles:
+        c()
+    timer.stop(stream)
+    f1 = timer.elapsed_ms() / n
+    timer.start(stream)
+    for c in pairs:
+        c()
+    timer.stop(stream)
+    f2 = timer.elapsed_ms() / n
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(0, n, 2):
+        singles[k]()
+        singles[k + 1]()
+        torch.cuda.synchronize()
+    ref_loop = (time.perf_counter() - t0) * 1e3 / n
+    t0 = time.perf_counter()
+    for k in range(n):
+        singles[k]()
+        torch.cuda.synchronize()
+    f1_sync = (time.perf_counter() - t0) * 1e3 / n
+    return {"f1_kernel_ms": round(f1, 4), "f1_launch_plus_sync_wall_ms": round(f1_sync, 4), "f2_batch_ms_per_frame": round(f2, 4),
+            "reference_loop_2_renders_per_sync_wall_ms_per_frame": round(ref_loop, 4), "f32_batch_kernel_ms_per_frame": round(f32_ms_per_frame, 4),
+            "note": "kernel ms = hipEvents around back-to-back launches on one stream; wall ms include launch and hipDeviceSynchronize"}
+
+
+def run_frames(args, env):
+    """spp / bounces / lighting workloads (render_ex_kernel + resolve_ex_kernel): one frame per step."""
+    g = env
+    rank, world, dist_on, rehearsal, dev = g["rank"], g["world"], g["dist_on"], g["rehearsal"], g["dev"]
+    W, H, K, D, pitch, scene, cam, stream, hlib, timer = g["W"], g["H"], g["K"], g["D"], g["pitch"], g["scene"], g["cam"], g["stream"], g["hlib"], g["timer"]
+    spp, bounces, lighting, base_pose, exchange, comm = g["spp"], g["bounces"], g["lighting"], g["base_pose"], g["exchange"], g["comm"]
+    poses = camera_path(base_pose, 8)
+    frame = torch.empty((H, pitch), dtype=torch.uint8, device=dev)
+    if dist_on and rehearsal:
+        max_rows = g["max_rows"]
+        local_dev = torch.zeros((max_rows, pitch), dtype=torch.uint8, device=dev)
+        local = torch.zeros_like(local_dev, device="cpu")
+        gathered = torch.empty((world, max_rows, pitch), dtype=torch.uint8) if rank == 0 else None
+        gathered_dev = torch.empty((world, max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None
+
+    def step(i):
+        cam.set_pose(poses[i % len(poses)])
+        if not dist_on:
+            cam.render_scene(scene, frame.data_ptr(), pitch)                            # Camera::render_scene -> rt_render_ex
+        elif not rehearsal:
+            cam.render_scene_tiled(scene, comm, frame.data_ptr(), pitch, stripe_rows=STRIPE_ROWS, root=0)   # stripes + rt_gather + un-stripe
+        else:
+            cam.render_scene_stripes(scene, local_dev.data_ptr(), pitch, STRIPE_ROWS, rank, world, synchronize=True)
+            local.copy_(local_dev)
+            exchange.to_root(local, gathered, 0)
+            if rank == 0:
+                gathered_dev.copy_(gathered)
+                rt.check(hlib.rt_unstripe(gathered_dev.data_ptr(), pitch, max_rows * pitch, frame.data_ptr(), pitch, W, H, STRIPE_ROWS, world, stream))
+
+    sync = g["sync"]
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    last_pose = poses[(args.steps - 1) % len(poses)]
+    got = frame.cpu().numpy().reshape(H, W, 3) if rank == 0 else None            # the last timed frame (before the probe below reuses the buffer)
+
+    # kernel time of this rank's share of one frame (render_ex_kernel launches + resolve passes), hipEvents
+    kernel_ms = None
     if rank == 0:
-        # ---- per-frame work counters from the debug kernel (same traversal, extra stores) ----
-        st = {"rays": W * H, "pops": int(dbg["pops"].sum()), "aabb": int(dbg["aabb"].sum()), "tris": int(dbg["tris"].sum()),
-              "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
-        alg_bytes = algorithmic_bytes(st)                   # per frame
-        share = F / world                                   # one launch = F frames; rank 0's stripes ~ 1/N of each
-        achieved = alg_bytes * share / (kernel_ms * 1e-3) / 1e9
-        # committed rocprofv3 PMC summary of this workload (tools/profile_bench.sh -> profiles/r01_traffic.json), if there is one:
-        # physical HBM bytes per launch, and what actually limits the kernel (VALU issue slots, lanes active per instruction)
-        traffic, pmc = None, {}
-        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tp):
-            try:
-                entry = json.load(open(tp)).get("%s_%dx%d_f%d" % (args.camera if args.workload == "c2" else args.workload, W, H, F), {})
-                traffic = entry.get("hbm_bytes_per_launch")
-                c = {k: v["mean"] for k, v in entry.get("counters", {}).items()}
-                if all(k in c for k in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")):
-                    # 1024 SIMDs, 2 cycles per wave64 VALU instruction; GRBM_GUI_ACTIVE is summed over the 8 XCDs
-                    pmc = {"limiter": "valu_issue", "valu_issue_frac_profiled": round(c["SQ_INSTS_VALU"] * 2 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3),
-                           "lanes_active_per_valu_profiled": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 1),
-                           "profile": entry.get("tag")}
-            except Exception:
-                traffic, pmc = None, {}
-        out = {
-            "metric": "Mrays/sec + ms/frame, 70k-tri OBJ at 1920x1080 1spp; 1/2/4/8 MI355X",
-            "value": round(W * H * args.steps / dt / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": world, **({"REHEARSAL_NOT_A_MEASUREMENT": "gloo backend, host-staged gathers"} if rehearsal else {}),
-            **({"FORCED_COLLECTIVE_PATH": "N > 1 code path run with one rank"} if args.force_collective and world == 1 else {}), "steps": args.steps, "warmup": warmup_req, "warmup_frames_done": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("C4 Sponza-class atrium OBJ (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera inside %s"
-                                    % (mesh.num_triangles, mesh.num_nodes, W, H, str(tuple(pose[:3]))))
-                                   if args.workload == "c4" else
-                                   ("C2 bunny-class blob OBJ (69936 tris, 130227 BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s"
-                                    % (W, H, args.camera, str(tuple(pose[:3])))),
-                       "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
-                                      % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames)" % F if rotate
-                                                           else ", one RCCL gather to rank 0 per %d frames" % F) if dist_on else ""),
-                       "frames_per_launch": F, "host_issue_ms_per_launch": round(t_issue / max(len(groups), 1) * 1e3, 3), "single_frame_launch_ms": None if single_ms is None else round(single_ms, 4),
-                       "coverage": round(st["hits"] / st["rays"], 4),
-                       "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
-                       "algorithmic_bytes_per_ray": round(alg_bytes / st["rays"], 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "render_kernel<false,false>", "kernel_ms": round(kernel_ms, 4),
-                         "frames_per_launch": F, "algorithmic_bytes_per_launch": int(alg_bytes * share), **pmc},
-            "frame_matches_debug_kernel": frame_ok,
-        }
-        if not dist_on and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(obj, W, H, K, D, pose, st, wl["albedo"])
-        sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        n = max(3, min(args.steps, 20))
+        local_probe = torch.empty((g["max_rows"] if dist_on else 1, pitch), dtype=torch.uint8, device=dev) if dist_on else None
+        cam.set_pose(poses[0])
+        torch.cuda.synchronize()
+        timer.start(stream)
+        for _ in range(n):
+            if dist_on:
+                cam.render_scene_stripes(scene, local_probe.data_ptr(), pitch, STRIPE_ROWS, rank, world)
+            else:
+                cam.render_scene(scene, frame.data_ptr(), pitch)
+        timer.stop(stream)
+        kernel_ms = timer.elapsed_ms() / n
     if dist_on:
         dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+
+    # the (tiled) frame must equal the frame one GPU renders alone: rank 0 renders it again, whole
+    cam.set_pose(last_pose)
+    whole = rt.render_ex(scene, cam)
+    frame_ok = bool(np.array_equal(got, whole["img"]))
+    pops = int(whole["total_pops"].astype(np.int64).sum())
+    mesh, wl = g["mesh"], g["wl"]
+    name = {"c3": "C3 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ", "c5": "C5 bunny-class blob OBJ"}.get(args.workload, args.workload)
+    config = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, %d specular bounces, lighting %d (material roughness %.2f metallic %.2f), camera '%s' %s"
+                          % (name, mesh.num_triangles, mesh.num_nodes, W, H, spp, bounces, lighting, wl.get("roughness", 0.0), wl.get("metallic", 0.0),
+                             g["cam_name"], str(tuple(base_pose[:3]))),
+              "key": g["key"], "width": W, "height": H, "spp": spp, "bounces": bounces, "lighting": lighting,
+              "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
+                             % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per frame (Camera::render_scene_tiled -> rt_render_tiled)" if dist_on else ""),
+              "frames_per_launch": 1, "primary_rays_per_frame": W * H * spp,
+              "node_pops_per_pixel": round(pops / (W * H), 1), "G_node_pops_per_s_kernel": round(pops / max(world, 1) / (kernel_ms * 1e-3) / 1e9, 1)}
+    roof = roofline("render_ex_kernel", g["key"], kernel_ms, 1, 1.0 / world)
+    extra = {"frame_matches_single_gpu_render": frame_ok}
+    value = W * H * spp * args.steps / dt / 1e6
+    out = base_line(args, g, value, dt, args.warmup, config, roof, extra)
+    if not dist_on and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_frame(g["obj"], wl, W, H, K, D, last_pose, (spp, bounces, lighting), got)
+    return out
 
 
 if __name__ == "__main__":

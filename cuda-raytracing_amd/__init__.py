@@ -63,7 +63,9 @@ RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
     "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
-    "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
+    "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch",
+    "rt_comm_available", "rt_comm_last_error", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_info", "rt_comm_destroy",
+    "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
     "rth_obj_load", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
@@ -72,7 +74,7 @@ RT_HOST_SYMBOLS = [
     "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance", "rth_scene_update_mesh_instance_async",
     "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
-    "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
+    "rth_camera_render_scene_tiled", "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
     "rth_camera_render_scene_ex", "rth_xorwow", "rth_save_png", "rth_write_png_bgr",
     "rth_read_image_bgr", "rth_zlib_inflate", "rth_overlay_text_bgr", "rth_display_image", "rth_on_mouse", "rth_on_key",
     "rth_camera_params", "rth_q_rsqrt", "rth_atanf", "rth_normalize", "rth_invert_lre", "rth_apply_lre", "rth_euler2quat",
@@ -94,6 +96,14 @@ def libs():
         for p in (HIP_SO, HOST_SO):
             if not os.path.exists(p):
                 raise RtError("%s is missing: run __graft_entry__.build() (no CPU fallback exists)" % p)
+        # When PyTorch is installed it must be loaded FIRST: it ships its own libamdhip64 / librccl under the same sonames,
+        # and a process must not end up with two HIP runtimes or two RCCLs (librt_hip.so dlopens "librccl.so.1" on first use
+        # of rt_comm_*: after torch that resolves to torch's copy, before it to ROCm's -- and torch would then be handed
+        # ROCm's copy in place of the one it was built against; seen as a double free at process exit).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
         _host = C.CDLL(HOST_SO)
         _declare(_hip, _host)
@@ -124,6 +134,19 @@ def _declare(h, s):
     h.rt_unstripe.argtypes = [_vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
     h.rt_unstripe_batch.argtypes = [_vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, _vp]
+    _sz = C.POINTER(C.c_size_t)
+    h.rt_comm_last_error.restype = C.c_char_p
+    h.rt_comm_available.argtypes = [_i]
+    h.rt_comm_unique_id.argtypes = [_vp]
+    h.rt_comm_init_rank.argtypes = [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]
+    h.rt_comm_init_all.argtypes = [_i, C.c_int32, C.POINTER(_vp)]
+    h.rt_comm_info.argtypes = [_vp, _i, _i, _i]
+    h.rt_comm_destroy.argtypes = [_vp]
+    h.rt_gather.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_int32, _vp]
+    h.rt_all_to_all.argtypes = [_vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp]
+    h.rt_render_tiled.argtypes = [_vp, _vp, C.POINTER(RtCameraParams), _vp, _vp, C.c_size_t, C.c_int32, C.c_int32, _vp, C.c_int]
+    h.rt_render_tiled_all.argtypes = [C.POINTER(_vp), C.POINTER(_vp), C.c_int32, C.POINTER(RtCameraParams), _vp, _vp, C.c_size_t,
+                                      C.c_int32, C.c_int32, C.POINTER(_vp), C.c_int]
     h.rt_timer_create.argtypes = [C.POINTER(_vp)]
     h.rt_timer_start.argtypes = [_vp, _vp]
     h.rt_timer_stop.argtypes = [_vp, _vp]
@@ -162,6 +185,7 @@ def _declare(h, s):
     s.rth_camera_set_stream.argtypes = [_vp, _vp]
     s.rth_camera_render_scene.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
     s.rth_camera_render_scene_stripes.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int]
+    s.rth_camera_render_scene_tiled.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int]
     s.rth_camera_render_scene_batch.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int]
     s.rth_camera_render_scene_stripes_batch.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
                                                         C.c_int32, C.c_int]
@@ -199,8 +223,10 @@ def _fp(a):
 def check(rc, what="rt call"):
     if rc != 0:
         h, s = libs()
-        msg = h.rt_error_string(rc).decode() if rc > 0 or rc >= -4 else "?"
+        msg = h.rt_error_string(rc).decode() if rc > 0 or rc >= -5 else "?"
         extra = s.rth_last_error().decode()
+        if rc == -5:
+            extra = h.rt_comm_last_error().decode()
         raise RtError("%s failed: %d (%s) %s" % (what, rc, msg, extra))
 
 
@@ -364,6 +390,11 @@ class Camera:
         check(libs()[1].rth_camera_render_scene_stripes(self.h, scene.h, d_local, local_pitch, stripe_rows, rank, num_ranks,
                                                         1 if synchronize else 0), "Camera::render_scene_stripes")
 
+    def render_scene_tiled(self, scene, comm, d_img, pitch, synchronize=False, stripe_rows=16, root=0):
+        """Camera::render_scene_tiled: every rank of `comm` calls this; the frame arrives in d_img on `root`."""
+        check(libs()[1].rth_camera_render_scene_tiled(self.h, scene.h, comm.h, d_img, pitch, stripe_rows, root, 1 if synchronize else 0),
+              "Camera::render_scene_tiled")
+
     def set_options(self, spp=1, bounces=0, lighting=0):
         libs()[1].rth_camera_set_options(self.h, spp, bounces, 1 if lighting else 0)
 
@@ -416,6 +447,42 @@ class Camera:
         if self.h:
             libs()[1].rth_camera_free(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RtComm: the RCCL communicator behind rt_gather / rt_all_to_all / rt_render_tiled (one process per GPU).
+    Comm.unique_id() on one rank -> the 128 bytes travel to the others by the host's own means -> Comm(id, rank, n)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(libs()[0].rt_comm_unique_id(buf), "rt_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, num_ranks):
+        self.h = _vp()
+        self.rank, self.num_ranks = rank, num_ranks
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(libs()[0].rt_comm_init_rank(buf, rank, num_ranks, C.byref(self.h)), "rt_comm_init_rank")
+
+    def gather(self, d_send, nbytes, d_recv, root=0, stream=None):
+        check(libs()[0].rt_gather(self.h, d_send, nbytes, d_recv, root, stream), "rt_gather")
+
+    def all_to_all(self, d_send, send_bytes, send_offsets, d_recv, recv_bytes, recv_offsets, stream=None):
+        arr = lambda v: (C.c_size_t * self.num_ranks)(*[int(x) for x in v])
+        check(libs()[0].rt_all_to_all(self.h, d_send, arr(send_bytes), arr(send_offsets), d_recv, arr(recv_bytes), arr(recv_offsets), stream),
+              "rt_all_to_all")
+
+    def close(self):
+        if self.h:
+            libs()[0].rt_comm_destroy(self.h)
+            self.h = _vp()
 
     def __del__(self):
         try:

@@ -1,6 +1,6 @@
 """Build the two in-tree shared libraries of the package.
 
-  librt_hip.so   HIP kernels (gfx950) + the C-ABI of include/rt_hip.h   (hipcc)
+  librt_hip.so   HIP kernels (gfx950) + the C-ABI of include/rt_hip.h   (hipcc; RCCL is dlopen'ed at run time, not linked)
   librt_host.so  host C++ API mirror + its C facade include/rt_host.h   (g++, links librt_hip.so)
 
 Both are compiled with -ffp-contract=off: results must be bit-identical to the reference's
@@ -19,7 +19,7 @@ HOST_SO = os.path.join(HERE, "librt_host.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-HIP_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_bvh_build.hip")]
+HIP_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_bvh_build.hip"), os.path.join(CSRC, "rt_comm.hip")]
 HIP_DEPS = HIP_SRCS + [os.path.join(CSRC, n) for n in ("rt_math.h", "rt_device_types.h")] + \
     [os.path.join(ROOT, "include", "rt_hip.h")]
 HOST_SRCS = [os.path.join(CSRC, "host", n) for n in ("rt_host.cpp", "rt_host_capi.cpp", "rt_image_io.cpp")]

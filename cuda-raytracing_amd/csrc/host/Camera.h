@@ -7,6 +7,8 @@
 
 using namespace transforms;
 
+struct RtComm;
+
 // Replacement for display_image()'s `cv::imwrite("out.png", ...)` (kernel.cu:30-43) without OpenCV: copies a pitched BGR
 // device image to the host and writes it as an 8-bit RGB PNG (stored, i.e. uncompressed, deflate blocks).
 // Returns 0 or an rt_hip.h error code (RT_E_INVALID if the file cannot be written).
@@ -40,6 +42,11 @@ public:
     void render_scene_batch(Scene& scene, const lre* poses, int count, uchar3* const* img_ptrs, size_t pitch, bool synchronize = false);
     void render_scene_stripes_batch(Scene& scene, const lre* poses, int count, uchar3* const* local_ptrs, size_t local_pitch,
                                     int stripe_rows, int rank, int num_ranks, bool synchronize = false);
+    // One frame tiled over the GPUs of `comm` (rt_comm_init_rank / rt_comm_init_all, rt_hip.h): every rank calls this with
+    // its own replica of the scene; the frame arrives in img_ptr on rank `root` (img_ptr may be null elsewhere).
+    // Honours spp / bounces / lighting like render_scene.  The multi-GPU form of Camera.cu:18-41.
+    void render_scene_tiled(Scene& scene, RtComm* comm, uchar3* img_ptr, size_t pitch, bool synchronize = false, int stripe_rows = 16,
+                            int root = 0);
     // this rank's stripes of the frame into a tight local buffer (multi-GPU tiling, rt_hip.h)
     void render_scene_stripes(Scene& scene, uchar3* local_ptr, size_t local_pitch, int stripe_rows, int rank, int num_ranks,
                               bool synchronize = false);

@@ -388,6 +388,14 @@ void Camera::render_scene_stripes(Scene& scene, uchar3* local_ptr, size_t local_
                                    synchronize ? 1 : 0);
 }
 
+void Camera::render_scene_tiled(Scene& scene, RtComm* comm, uchar3* img_ptr, size_t pitch, bool synchronize, int stripe_rows, int root)
+{
+    RtCameraParams p = camera_params(*this, pose);
+    RtRenderOptions o;
+    o.spp = spp; o.bounces = bounces; o.lighting = lighting ? 1 : 0;
+    last_error = rt_render_tiled(scene.d_scene, comm, &p, &o, (uint8_t*)img_ptr, pitch, stripe_rows, root, stream, synchronize ? 1 : 0);
+}
+
 void Camera::render_scene_batch(Scene& scene, const lre* poses, int count, uchar3* const* img_ptrs, size_t pitch, bool synchronize)
 {
     if (count < 1 || count > RT_MAX_BATCH || !poses || !img_ptrs) { last_error = RT_E_INVALID; return; }

@@ -172,6 +172,9 @@ int rth_camera_render_scene(RthCamera* c, RthScene* s, void* d_img, size_t pitch
 int rth_camera_render_scene_stripes(RthCamera* c, RthScene* s, void* d_local, size_t local_pitch, int32_t stripe_rows, int32_t rank,
                                     int32_t num_ranks, int synchronize)
 { c->cam.render_scene_stripes(s->scene, (uchar3*)d_local, local_pitch, stripe_rows, rank, num_ranks, synchronize != 0); return c->cam.last_error; }
+int rth_camera_render_scene_tiled(RthCamera* c, RthScene* s, void* comm, void* d_img, size_t pitch, int32_t stripe_rows, int32_t root,
+                                  int synchronize)
+{ c->cam.render_scene_tiled(s->scene, (RtComm*)comm, (uchar3*)d_img, pitch, synchronize != 0, stripe_rows, root); return c->cam.last_error; }
 int rth_camera_render_scene_batch(RthCamera* c, RthScene* s, const float* poses6, void* const* d_imgs, size_t pitch, int32_t count,
                                   int synchronize)
 {

@@ -796,6 +796,7 @@ const char* rt_error_string(int code)
     case RT_E_NOMEM: return "rt: out of host memory";
     case RT_E_DEPTH: return "rt: BVH deeper than the traversal stack";
     case RT_E_NODEVICE: return "rt: no HIP device";
+    case RT_E_COMM: return "rt: RCCL unavailable or failed (rt_comm_last_error)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "rt: unknown error";
     }
 }

@@ -1,5 +1,9 @@
-"""Frame tiling across ranks: stripe bookkeeping and the per-frame gather.  The same code drives
-bench.py on N GPUs (backend nccl = RCCL, device tensors) and the world_size-2 gloo test on CPU."""
+"""Frame tiling across ranks: stripe bookkeeping, the exchange step and the double-buffered frame loop.
+
+The data path of the product is RCCL through the C-ABI (include/rt_hip.h: rt_gather / rt_all_to_all on an RtComm, or the
+one-call rt_render_tiled); `RcclExchange` binds it.  `TorchExchange` moves the same buffers with torch.distributed on
+host tensors (gloo): it exists for the world_size-2 CPU tests and for bench.py's rehearsal mode, never for numbers.
+Both expose the same two calls, so `StripePipeline` and bench.py's loop are the code under test in either case."""
 import numpy as np
 
 
@@ -32,7 +36,7 @@ def unstripe_host(gathered, height, stripe, world):
     return out
 
 
-# ---- buffer layout when F frames travel in one gather --------------------------------------------------
+# ---- buffer layout when F frames travel in one exchange ------------------------------------------------
 # local buffer of a rank:   [F][max_rows][pitch]           (frame f starts f * max_rows rows in)
 # gathered buffer on dst:   [world][F][max_rows][pitch]    (rank r starts r * F * max_rows rows in)
 
@@ -44,16 +48,6 @@ def batch_local_ptrs(local_base, F, max_rows, pitch):
 def batch_unstripe_args(gathered_base, f, F, max_rows, pitch):
     """(d_gathered, rank_stride) to pass to rt_unstripe for frame f of a gathered batch."""
     return gathered_base + f * max_rows * pitch, F * max_rows * pitch
-
-
-def gather_stripes(local, gathered, rank, dst=0):
-    """One frame's exchange step: every rank's padded local stripe buffer to rank `dst`.
-    local: [max_rows, pitch] uint8 tensor; gathered: [world, max_rows, pitch] on dst, None elsewhere."""
-    import torch.distributed as dist
-    if rank == dst:
-        dist.gather(local, list(gathered.unbind(0)), dst=dst)
-    else:
-        dist.gather(local, None, dst=dst)
 
 
 def frames_per_rank(F, world):
@@ -75,94 +69,112 @@ def rotating_plan(count, world):
     return slots, counts, offsets, real
 
 
-def exchange_to_root(local, gathered, rank, dst=0):
-    """Start the gather of a group to one root: local [F * max_rows, pitch] from every rank into
-    gathered [world, F * max_rows, pitch] on `dst` (None elsewhere).  Returns the async work handle."""
-    import torch.distributed as dist
-    if rank == dst:
-        return dist.gather(local, list(gathered.unbind(0)), dst=dst, async_op=True)
-    return dist.gather(local, None, dst=dst, async_op=True)
+# ---- the exchange step ----------------------------------------------------------------------------------
+# to_root(local, gathered, root):   every rank's `local` [rows, pitch] to rank `root`, whose `gathered`
+#                                   [world, rows, pitch] receives rank r's block at index r (None elsewhere)
+# rotating(local, received, count, max_rows): the gathers of a group of `count` frames with a rotating root, fused into
+#                                   ONE all-to-all: local is frame-major [>= slots * max_rows, pitch], so the block for
+#                                   destination d is contiguous; received [>= world * counts[me] * max_rows, pitch] is
+#                                   filled source-major (what rt_unstripe_batch takes as it is)
+
+class RcclExchange:
+    """RCCL over xGMI through the C-ABI.  Tensors are torch CUDA tensors (torch is plumbing: device memory and the
+    current stream); the collectives are enqueued on torch's current stream and are asynchronous."""
+    on_device = True
+
+    def __init__(self, comm):
+        self.comm = comm
+        self.rank, self.world = comm.rank, comm.num_ranks
+
+    @staticmethod
+    def _stream():
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+    def to_root(self, local, gathered, root=0):
+        nbytes = local.numel() * local.element_size()
+        self.comm.gather(local.data_ptr(), nbytes, gathered.data_ptr() if self.rank == root else None, root, self._stream())
+
+    def rotating(self, local, received, count, max_rows):
+        _, counts, offsets, _ = rotating_plan(count, self.world)
+        row = local.shape[1] * local.element_size()
+        me = self.rank
+        self.comm.all_to_all(local.data_ptr(), [c * max_rows * row for c in counts], [o * max_rows * row for o in offsets],
+                             received.data_ptr(), [counts[me] * max_rows * row] * self.world,
+                             [r * counts[me] * max_rows * row for r in range(self.world)], self._stream())
 
 
-def exchange_rotating(local, received, count, world, max_rows):
-    """Start the gather of a group with a rotating root, fused into ONE all-to-all: the stripes of frame f go to the
-    rank that assembles f (rotating_plan), so every rank receives 1/world of the pixels and every xGMI link carries
-    the same load in both directions instead of seven links converging on one root.
-    local: [>= slots * max_rows, pitch] (frame-major, so the block for destination d is contiguous);
-    received: [>= world * counts[me] * max_rows, pitch] (filled source-major).  Returns the async work handle."""
-    import torch.distributed as dist
-    slots, counts, _, _ = rotating_plan(count, world)
-    me = dist.get_rank()
-    return dist.all_to_all_single(received[:world * counts[me] * max_rows], local[:slots * max_rows],
-                                  output_split_sizes=[counts[me] * max_rows] * world,
-                                  input_split_sizes=[c * max_rows for c in counts], async_op=True)
+class TorchExchange:
+    """The same two calls over torch.distributed with host tensors (gloo): CPU tests and bench.py's rehearsal."""
+    on_device = False
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def to_root(self, local, gathered, root=0):
+        import torch.distributed as dist
+        dist.gather(local, list(gathered.unbind(0)) if self.rank == root else None, dst=root)
+
+    def rotating(self, local, received, count, max_rows):
+        import torch.distributed as dist
+        slots, counts, _, _ = rotating_plan(count, self.world)
+        me = self.rank
+        dist.all_to_all_single(received[:self.world * counts[me] * max_rows], local[:slots * max_rows],
+                               output_split_sizes=[counts[me] * max_rows] * self.world,
+                               input_split_sizes=[c * max_rows for c in counts])
 
 
 class StripePipeline:
-    """Double-buffered frame loop for N ranks: while group i's stripes are being exchanged (on the
-    collective's own stream) and un-striped (on `side_stream`), group i+1 is already rendering.
-    render_fn(b) renders this rank's stripes into local buffer b; exchange_fn(b) starts the collective on buffer b
-    and returns its work handle; unstripe_fn(b) (only on ranks for which `assembles` is true) turns received
-    buffer b into frames -- it is called with `side_stream` current, so it must launch on torch's current stream.
-    side_stream = None (CPU backends, tests): waits and un-stripes inline.
-    compute_streams = (s0, s1): buffer b's render launch and collective are issued with s_b current (render_fn(b) must
-    launch on s_b), so consecutive render kernels sit on different streams and the tail of one overlaps the start of
-    the next; None = everything on the caller's current stream.
-    Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests)."""
+    """Double-buffered frame loop for N ranks.  Group i uses buffer set b = i & 1:
 
-    def __init__(self, render_fn, exchange_fn, unstripe_fn, assembles=True, side_stream=None, compute_streams=None):
+        compute stream of b:  [wait: set b free]  render_fn(b)                      -> event rendered[b]
+        comm stream:          [wait: rendered[b]] exchange_fn(b); unstripe_fn(b)    -> event free[b]
+
+    so the exchange and un-stripe pass of group i overlap the render of group i + 1 (which runs on the other compute
+    stream), and nothing touches a buffer of set b again before everything that read it has finished: the render of group
+    i + 2 waits for free[b], and exchanges / un-stripe passes are ordered among themselves by the one comm stream.
+    All three callbacks must enqueue their work on torch's CURRENT stream and return without waiting.
+    unstripe_fn runs only on ranks for which `assembles` is true.
+    comm_stream = None: everything inline and synchronous on the caller's thread (host backends: tests, rehearsal)."""
+
+    def __init__(self, render_fn, exchange_fn, unstripe_fn, assembles=True, compute_streams=None, comm_stream=None):
         self.render_fn, self.exchange_fn, self.unstripe_fn = render_fn, exchange_fn, unstripe_fn
         self.assembles = assembles
-        self.side = side_stream
         self.compute = compute_streams
-        self.pending = [None, None]
-        self.side_busy = [False, False]   # buffer b was handed to the side stream and not yet waited for
+        self.comm = comm_stream
         self.frames_done = 0
+        self.rendered = self.free = None
+        self.used = [False, False]
+        if comm_stream is not None:
+            import torch
+            self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
+            self.free = [torch.cuda.Event(), torch.cuda.Event()]
 
-    def _finish(self, b):
-        """Order 'wait for exchange b, then un-stripe it' -- on the side stream if there is one, so that the stream
-        that renders never waits for a collective or spends time copying rows."""
-        work = self.pending[b]
-        if work is None:
-            return
-        if self.side is None:
-            work.wait()
+    def step(self, i):
+        b = i & 1
+        if self.comm is None:
+            self.render_fn(b)
+            self.exchange_fn(b)
             if self.assembles:
                 self.unstripe_fn(b)
         else:
             import torch
-            with torch.cuda.stream(self.side):
-                work.wait()               # stream-ordered for nccl: only the side stream waits for the collective
+            cs = self.compute[b] if self.compute is not None else torch.cuda.current_stream()
+            if self.used[b]:
+                cs.wait_event(self.free[b])            # group i - 2 has left buffer set b
+            with torch.cuda.stream(cs):
+                self.render_fn(b)
+                self.rendered[b].record(cs)
+            self.comm.wait_event(self.rendered[b])
+            with torch.cuda.stream(self.comm):
+                self.exchange_fn(b)
                 if self.assembles:
                     self.unstripe_fn(b)
-            self.side_busy[b] = True
-        self.pending[b] = None
+                self.free[b].record(self.comm)
+            self.used[b] = True
         self.frames_done += 1
 
-    def release(self, b):
-        """Call before buffers b are written again: everything that still reads them is ordered before what the
-        current stream does next."""
-        self._finish(b)
-        if self.side is not None and self.side_busy[b]:
-            import torch
-            torch.cuda.current_stream().wait_stream(self.side)
-            self.side_busy = [False, False]
-
-    def _issue(self, b):
-        self.release(b)                   # buffers b were last used by group i-2
-        self.render_fn(b)
-        self.pending[b] = self.exchange_fn(b)
-
-    def step(self, i):
-        b = i & 1
-        if self.compute is None:
-            self._issue(b)
-        else:
-            import torch
-            with torch.cuda.stream(self.compute[b]):
-                self._issue(b)
-        self._finish(b ^ 1)               # group i-1: its exchange overlapped this group's render
-
     def drain(self):
-        self.release(0)
-        self.release(1)
+        """Host wait for everything issued so far."""
+        if self.comm is not None:
+            self.comm.synchronize()

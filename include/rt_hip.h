@@ -22,14 +22,15 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 enum {
     RT_OK = 0,
     RT_E_INVALID = -1,      /* bad argument (null pointer, size, index out of range) */
     RT_E_NOMEM = -2,
     RT_E_DEPTH = -3,        /* BVH deeper than 64 levels (the reference's traversal stack holds 32 entries, raycast.cu:54) */
-    RT_E_NODEVICE = -4
+    RT_E_NODEVICE = -4,
+    RT_E_COMM = -5          /* RCCL could not be loaded or returned an error: see rt_comm_last_error() */
 };
 
 /* One mesh as the reference uploads it: MeshPrimitive::to_device (MeshPrimitive.cpp:17-36) sends
@@ -193,6 +194,45 @@ int rt_unstripe(const uint8_t *d_gathered, size_t local_pitch, size_t rank_strid
 int rt_unstripe_batch(const uint8_t *d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
                       uint8_t *d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
                       int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void *stream);
+
+/* ---- the exchange step of frame tiling: an RCCL communicator over the GPUs of one node (no counterpart in the
+ *      reference; BASELINE.json north_star: "the frame is tiled across the 8 GPUs of one node with a final RCCL gather
+ *      over xGMI").  RCCL (librccl.so.1) is loaded on first use; without it these calls return RT_E_COMM.
+ *      One process per GPU: rank 0 calls rt_comm_unique_id, the host application passes the 128 bytes to the other
+ *      ranks by its own means (MPI, a socket, torch.distributed ...), every rank selects its device (rt_set_device)
+ *      and calls rt_comm_init_rank.  One process for all GPUs: rt_comm_init_all fills comms[0..num_devices) (rank i on
+ *      devices[i], or on device i when devices is NULL) and the *_all calls drive them.
+ *      Collectives are asynchronous on `stream` like every other call here. ------------------------------------- */
+typedef struct RtComm RtComm;
+#define RT_COMM_ID_BYTES 128
+int rt_comm_available(int32_t *rccl_version);            /* RT_OK when RCCL could be loaded */
+const char *rt_comm_last_error(void);                    /* text of the calling thread's last RT_E_COMM */
+int rt_comm_unique_id(uint8_t *id /* [RT_COMM_ID_BYTES] */);
+int rt_comm_init_rank(const uint8_t *id, int32_t rank, int32_t num_ranks, RtComm **out);   /* on the current device */
+int rt_comm_init_all(const int32_t *devices, int32_t num_devices, RtComm **comms);
+int rt_comm_info(const RtComm *comm, int32_t *rank, int32_t *num_ranks, int32_t *device);
+int rt_comm_destroy(RtComm *comm);
+int rt_group_start(void);                                /* ncclGroupStart / ncclGroupEnd for single-process callers */
+int rt_group_end(void);
+/* every rank's `bytes` bytes at d_send to rank `root`, which receives rank r's block at d_recv + r * bytes
+ * (d_recv may be NULL elsewhere): the per-frame gather of SURVEY.md 8(e) */
+int rt_gather(RtComm *comm, const void *d_send, size_t bytes, void *d_recv, int32_t root, void *stream);
+/* rank p gets send_bytes[p] bytes from d_send + send_offsets[p]; recv_bytes[p] bytes from rank p land at
+ * d_recv + recv_offsets[p] (zero-byte pairs are skipped; the counts must agree pairwise).  One fused group of
+ * point-to-point transfers: the gathers of a group of frames whose root rotates over the ranks. */
+int rt_all_to_all(RtComm *comm, const void *d_send, const size_t *send_bytes, const size_t *send_offsets,
+                  void *d_recv, const size_t *recv_bytes, const size_t *recv_offsets, void *stream);
+/* One tiled frame, the whole of SURVEY.md 8(e) in one call made by every rank: render this rank's stripes (rt_render_stripes,
+ * or rt_render_ex_stripes when opts is non-NULL and not the default 1 / 0 / 0), gather them to `root`, and on the root
+ * put the rows back into frame order in d_img (may be NULL on other ranks).  Scratch buffers live in the communicator.
+ * With one rank this is rt_render / rt_render_ex. */
+int rt_render_tiled(RtScene *scene, RtComm *comm, const RtCameraParams *cam, const RtRenderOptions *opts, uint8_t *d_img,
+                    size_t pitch, int32_t stripe_rows, int32_t root, void *stream, int synchronize);
+/* the same from ONE process that holds a scene replica and a communicator per device (rt_comm_init_all):
+ * scenes[r] / comms[r] / streams[r] (streams may be NULL) belong to rank r; d_img is on the root's device */
+int rt_render_tiled_all(RtScene *const *scenes, RtComm *const *comms, int32_t num_ranks, const RtCameraParams *cam,
+                        const RtRenderOptions *opts, uint8_t *d_img, size_t pitch, int32_t stripe_rows, int32_t root,
+                        void *const *streams, int synchronize);
 
 /* ---- timing on the stream the kernels run on (hipEvent) ---------------------------------- */
 typedef struct RtTimer RtTimer;

@@ -76,6 +76,9 @@ int rth_camera_render_scene(RthCamera *c, RthScene *s, void *d_img, size_t pitch
 int rth_camera_render_scene_stripes(RthCamera *c, RthScene *s, void *d_local, size_t local_pitch,
                                     int32_t stripe_rows, int32_t rank, int32_t num_ranks, int synchronize);
 /* Camera::render_scene_batch: `count` frames along a camera path (poses6 = count x lre) in one launch (rt_render_batch) */
+/* Camera::render_scene_tiled: one frame over the GPUs of an RtComm (rt_hip.h), frame on rank `root` */
+int rth_camera_render_scene_tiled(RthCamera *c, RthScene *s, void *comm, void *d_img, size_t pitch, int32_t stripe_rows,
+                                  int32_t root, int synchronize);
 int rth_camera_render_scene_batch(RthCamera *c, RthScene *s, const float *poses6, void *const *d_imgs, size_t pitch,
                                   int32_t count, int synchronize);
 int rth_camera_render_scene_stripes_batch(RthCamera *c, RthScene *s, const float *poses6, void *const *d_locals,

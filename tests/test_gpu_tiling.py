@@ -1,0 +1,154 @@
+"""The exchange step on a real GPU: the RCCL communicator of the C-ABI (rt_comm_* / rt_gather / rt_all_to_all /
+rt_render_tiled) with the one rank a one-GPU box offers, and the double-buffered frame loop (tiling.StripePipeline) on its
+real streams and events.  More than one RCCL peer needs more than one GPU: the N-rank bookkeeping is covered by the
+virtual-rank tests (test_gpu_parity.py, test_gpu_full_size.py) and by the gloo tests on CPU (test_tiling_gloo.py)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scene_defs as sd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def comm1(rt):
+    v = C.c_int32(0)
+    rt.check(rt.libs()[0].rt_comm_available(C.byref(v)), "rt_comm_available")
+    assert v.value > 20000                                     # RCCL reports NCCL-style version numbers (2.x.y -> 2xxyy)
+    c = rt.Comm(rt.Comm.unique_id(), 0, 1)
+    yield c
+    c.close()
+
+
+def test_comm_gather_and_all_to_all_single_rank(rt, comm1):
+    h = rt.libs()[0]
+    r, n, d = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+    rt.check(h.rt_comm_info(comm1.h, C.byref(r), C.byref(n), C.byref(d)))
+    assert (r.value, n.value) == (0, 1) and d.value >= 0
+    data = np.random.default_rng(5).integers(0, 256, 1 << 20, dtype=np.uint8)
+    src, dst = rt.DeviceBuffer(nbytes=data.nbytes), rt.DeviceBuffer(nbytes=data.nbytes)
+    rt.check(h.rt_memcpy_h2d(src.ptr, data.ctypes.data, data.nbytes, None))
+    comm1.gather(src.ptr, data.nbytes, dst.ptr, root=0)
+    rt.check(h.rt_device_synchronize())
+    assert np.array_equal(dst.to_host(), data)
+    dst2 = rt.DeviceBuffer(nbytes=data.nbytes)
+    comm1.all_to_all(src.ptr, [4096], [512], dst2.ptr, [4096], [1024])
+    rt.check(h.rt_device_synchronize())
+    assert np.array_equal(dst2.to_host()[1024:1024 + 4096], data[512:512 + 4096])
+    assert h.rt_gather(comm1.h, src.ptr, 16, None, 0, None) == -1          # the root needs a destination
+    assert h.rt_gather(comm1.h, src.ptr, 16, dst.ptr, 1, None) == -1       # no such rank
+    assert h.rt_gather(None, src.ptr, 16, dst.ptr, 0, None) == -1
+
+
+@pytest.mark.parametrize("opts", [(1, 0, 0), (4, 2, 1)])
+def test_render_scene_tiled_single_rank(rt, scenes, blob5k, comm1, opts):
+    """Camera::render_scene_tiled -> rt_render_tiled with one rank renders the frame Camera::render_scene renders."""
+    W, H = 322, 203
+    sp = sd.shiny_scene(scenes, blob5k).build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+    cam.set_pose(sd.SHINY_CAMERA["pose"])
+    cam.set_options(*opts)
+    want = rt.render(sp, cam)
+    img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    cam.render_scene_tiled(sp, comm1, img.ptr, img.pitch, synchronize=True)
+    assert np.array_equal(img.to_host().reshape(H, W, 3), want)
+    # the single-process form (rt_render_tiled_all) with the same one communicator
+    h = rt.libs()[0]
+    p = cam.params()
+    o = (C.c_int32 * 3)(*opts)
+    scn, cm = (C.c_void_p * 1)(sp.device_handle), (C.c_void_p * 1)(comm1.h)
+    img2 = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    rt.check(h.rt_render_tiled_all(scn, cm, 1, C.byref(p), o, img2.ptr, img2.pitch, 16, 0, None, 1), "rt_render_tiled_all")
+    assert np.array_equal(img2.to_host().reshape(H, W, 3), want)
+
+
+def test_stripe_pipeline_on_streams_with_distinct_poses(rt, scenes, blob5k, comm1):
+    """bench.py's N > 1 frame loop on its real streams (two compute streams, one comm stream, events between them) with a
+    different camera for every frame of every group: if a render overwrote a stripe buffer that an exchange still reads,
+    or an exchange a buffer the un-stripe pass still reads, some frame would carry another frame's rows."""
+    import torch
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    W, H, F, ngroups, stripe = 480, 272, 4, 7, 16
+    pitch = W * 3
+    sp = sd.blob_scene(scenes, blob5k).build_product(rt)
+    sp.upload_to_device()
+    dev = torch.device("cuda", 0)
+    cs = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cams = []
+    for s in cs:
+        c = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+        c.set_stream(s.cuda_stream)
+        cams.append(c)
+    poses = [[(0.03 * f - 0.01 * g, -1.5 - 0.1 * g - 0.02 * f, 0.2, 0.01 * g, -0.005 * f, 0.0) for f in range(F)] for g in range(ngroups)]
+    max_rows = tiling.stripe_rows(H, stripe, 0, 1)
+    local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+    gathered = [torch.zeros((1, F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+    frames = [torch.zeros((F, H, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+    results = torch.zeros((ngroups, F, H, pitch), dtype=torch.uint8, device=dev)
+    ex = tiling.RcclExchange(comm1)
+    group_of = [0, 0]
+
+    def render_fn(b):
+        cams[b].render_scene_stripes_batch(sp, poses[group_of[b]], tiling.batch_local_ptrs(local[b].data_ptr(), F, max_rows, pitch), pitch, stripe, 0, 1)
+
+    def exchange_fn(b):
+        ex.to_root(local[b], gathered[b], 0)
+
+    def unstripe_fn(b):
+        rt.check(h.rt_unstripe_batch(gathered[b].data_ptr(), pitch, F * max_rows * pitch, max_rows * pitch, frames[b].data_ptr(), pitch, H * pitch,
+                                     F, W, H, stripe, 1, torch.cuda.current_stream().cuda_stream))
+        results[group_of[b]].copy_(frames[b], non_blocking=True)            # (on the comm stream, behind the un-stripe pass)
+
+    pipe = tiling.StripePipeline(render_fn, exchange_fn, unstripe_fn, compute_streams=cs, comm_stream=torch.cuda.Stream())
+    for g in range(ngroups):
+        group_of[g & 1] = g
+        pipe.step(g)
+    pipe.drain()
+    torch.cuda.synchronize()
+    got = results.cpu().numpy().reshape(ngroups, F, H, W, 3)
+    cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+    for g in range(ngroups):
+        for f in range(F):
+            cam.set_pose(poses[g][f])
+            assert np.array_equal(got[g, f], rt.render(sp, cam)), "group %d frame %d" % (g, f)
+    assert not np.array_equal(got[0, 0], got[1, 0])
+
+
+@pytest.mark.parametrize("extra", [["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8"],
+                                   ["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8", "--gather", "root0"],
+                                   ["--workload", "c3", "--width", "320", "--height", "180", "--spp", "4", "--bounces", "2", "--steps", "3", "--warmup", "1"]])
+def test_bench_forced_collective_path(extra):
+    """bench.py --force-collective: the whole N > 1 code path (stripes, RCCL exchange through the C-ABI, un-stripe, frame
+    check) with the one rank a one-GPU box has."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-collective", "--no-cpu-baseline", "--no-latency"] + extra,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["FORCED_COLLECTIVE_PATH"]
+    assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
+
+
+@pytest.mark.parametrize("workload", [["--workload", "c2", "--width", "480", "--height", "272", "--steps", "24", "--warmup", "4"],
+                                      ["--workload", "c5", "--width", "480", "--height", "272", "--spp", "2", "--bounces", "1", "--steps", "2", "--warmup", "1"]])
+def test_bench_self_launches_two_ranks(workload):
+    """`python bench.py --gpus 2` started bare: it launches its two ranks itself (before touching a GPU) and relays ONE
+    line.  On a one-GPU box the two ranks share the device, so the exchange goes through the gloo rehearsal backend."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-backend", "gloo", "--no-cpu-baseline"] + workload,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "REHEARSAL_NOT_A_MEASUREMENT" in line
+    assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True

@@ -36,7 +36,7 @@ def test_libraries_export_every_declared_symbol(rt):
         assert declared == set(listed), (declared ^ set(listed))
         for name in declared:
             assert getattr(lib, name) is not None
-    assert h.rt_abi_version() == 1
+    assert h.rt_abi_version() == 2
 
 
 def test_struct_layouts_match_header(rt):

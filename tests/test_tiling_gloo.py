@@ -1,6 +1,7 @@
 """N > 1 path on CPU: two gloo ranks render their stripes (with the oracle standing in for the GPU
 kernel -- the stripe bookkeeping and the gather protocol are what is under test), gather to rank 0
-with the same helper bench.py uses over RCCL, un-stripe, and compare with the full frame."""
+with the helper bench.py's rehearsal mode uses (tiling.TorchExchange; the product path makes the same two calls on
+tiling.RcclExchange = rt_gather / rt_all_to_all of the C-ABI), un-stripe, and compare with the full frame."""
 import os
 import socket
 import sys
@@ -37,7 +38,7 @@ def _worker(rank, world, port, blob, H, W, stripe, out_path):
         img = s.render(W, H, K, D, pose, y0=y0, y1=y1, planes=False)["img"]
         local[a:a + (y1 - y0)] = torch.from_numpy(img[y0:y1].reshape(y1 - y0, W * 3))
     gathered = torch.zeros((world, max_rows, W * 3), dtype=torch.uint8) if rank == 0 else None
-    tiling.gather_stripes(local, gathered, rank, dst=0)
+    tiling.TorchExchange(rank, world).to_root(local, gathered, root=0)
     if rank == 0:
         frame = tiling.unstripe_host(gathered.numpy(), H, stripe, world)
         full = s.render(W, H, K, D, pose, planes=False)["img"].reshape(H, W * 3)
@@ -76,8 +77,8 @@ def _pipeline_worker(rank, world, port, blob, H, W, stripe, nframes, out_path):
     def unstripe_fn(b):
         frames.append(tiling.unstripe_host(gathered[b].numpy(), H, stripe, world).copy())
 
-    pipe = tiling.StripePipeline(render_fn, lambda b: tiling.exchange_to_root(local[b], gathered[b], rank), unstripe_fn,
-                                 assembles=rank == 0)
+    ex = tiling.TorchExchange(rank, world)
+    pipe = tiling.StripePipeline(render_fn, lambda b: ex.to_root(local[b], gathered[b], 0), unstripe_fn, assembles=rank == 0)
     for i in range(nframes):
         pipe.step(i)
     pipe.drain()
@@ -122,8 +123,10 @@ def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, ou
             img = s.render(W, H, K, D, poses[g[0] + f], planes=False)["img"].reshape(H, W * 3)
             local[b][f * max_rows:f * max_rows + len(rows)] = torch.from_numpy(img[rows])
 
+    ex = tiling.TorchExchange(rank, world)
+
     def exchange_fn(b):
-        return tiling.exchange_rotating(local[b], received[b], group_of[b][1], world, max_rows)
+        ex.rotating(local[b], received[b], group_of[b][1], max_rows)
 
     def unstripe_fn(b):
         first, count = group_of[b]
@@ -136,7 +139,6 @@ def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, ou
     pipe = tiling.StripePipeline(render_fn, exchange_fn, unstripe_fn)
     first = 0
     for i, c in enumerate(sizes):
-        pipe.release(i & 1)
         group_of[i & 1] = (first, c)
         pipe.step(i)
         first += c

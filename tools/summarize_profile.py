@@ -1,40 +1,65 @@
 #!/usr/bin/env python3
-"""Turns a tools/profile_bench.sh output directory into the committed summaries under profiles/.
-   python tools/summarize_profile.py <profdir> <tag> <workload-key>"""
+"""Turns a tools/profile_bench.sh output directory into the committed summaries under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
+  profiles/<tag>_bench_line.json    the line bench.py printed under the profiler
+  profiles/r02_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME
+A frame = width x height x spp primary rays.  A dispatch of G work-items renders G / (tiles * 256 * spp) frames (one 256-thread
+workgroup per 16x16 tile per frame of the batch, or per sample of the frame), so counters are summed over every dispatch of
+the kernel and divided by the frames those dispatches rendered: the result does not depend on --steps or frames per launch.
+   python tools/summarize_profile.py <profdir> <tag>"""
 import collections, csv, glob, json, os, shutil, sys
-src, tag, key = sys.argv[1], sys.argv[2], sys.argv[3]
+
+src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(ROOT, "profiles")
-summ, meta = {}, {}
-for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    if not os.path.isdir(d):
-        continue
-    fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
-    if not fs:
-        continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
-        if "render_kernel<false, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) > 256 * 1000:
-            acc[r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
-            meta = {k: r[k] for k in ("Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
-    for k, v in acc.items():
-        big = max(g for g, _ in v)                      # the batched launches (largest grid), not the single-frame probes
-        vals = [x for g, x in v if g == big]
-        summ[k] = {"mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals), "dispatches": len(vals), "grid": big}
-ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
-if ks:
-    shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
 bench_line = None
 for line in open(os.path.join(src, "stats.log"), errors="ignore"):
     if line.startswith("{\"metric\""):
         bench_line = json.loads(line)
-tp = os.path.join(dst, "r01_traffic.json")
+assert bench_line, "no bench line in stats.log"
+cfg = bench_line["config"]
+W, H, key = cfg["width"], cfg["height"], cfg["key"]
+kernel = bench_line["roofline"]["kernel"].replace("<false,false>", "<false, false>")
+tiles = ((W + 15) // 16) * ((H + 15) // 16)
+per_frame_items = tiles * 256 * (cfg["spp"] if "render_ex" in kernel else 1)
+tot, meta, frames_by_pass = collections.defaultdict(float), {}, {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) if os.path.isdir(d) else []
+    if not fs:
+        continue
+    seen = {}
+    for r in csv.DictReader(open(fs[0])):
+        if kernel in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+            seen[r["Dispatch_Id"]] = int(r["Grid_Size"])
+            meta = {k: r[k] for k in ("Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size") if k in r}
+    frames = sum(seen.values()) / per_frame_items
+    for r in csv.DictReader(open(fs[0])):
+        if kernel in r["Kernel_Name"]:
+            frames_by_pass[r["Counter_Name"]] = frames
+pf = {k: v / frames_by_pass[k] for k, v in tot.items() if frames_by_pass.get(k)}
+entry = {"tag": tag, "kernel": kernel, "dispatch": meta, "frames_profiled": {k: round(v, 2) for k, v in frames_by_pass.items()},
+         "per_frame": pf, "bench_line_under_rocprof": {k: bench_line[k] for k in ("value", "ms_per_step", "steps")}}
+if "SQ_INSTS_VALU" in pf:
+    entry["valu_insts_per_frame"] = pf["SQ_INSTS_VALU"]
+if "SQ_THREAD_CYCLES_VALU" in pf and "SQ_ACTIVE_INST_VALU" in pf:
+    entry["lanes_active_per_valu"] = round(pf["SQ_THREAD_CYCLES_VALU"] / pf["SQ_ACTIVE_INST_VALU"], 2)
+if "TCP_TOTAL_CACHE_ACCESSES_sum" in pf:
+    entry["tcp_accesses_per_frame"] = pf["TCP_TOTAL_CACHE_ACCESSES_sum"]
+if "FETCH_SIZE" in pf and "WRITE_SIZE" in pf:
+    # KiB units; FETCH_SIZE x 2: the gfx950 correction of MI355X_MICROARCH.md "HBM" (128-B requests tallied at 64 B)
+    entry.update({"hbm_bytes_per_frame": (2 * pf["FETCH_SIZE"] + pf["WRITE_SIZE"]) * 1024, "fetch_bytes_per_frame_corrected": 2 * pf["FETCH_SIZE"] * 1024,
+                  "write_bytes_per_frame": pf["WRITE_SIZE"] * 1024})
+if "GRBM_GUI_ACTIVE" in pf and "SQ_INSTS_VALU" in pf:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction holds a SIMD-32 for 2 cycles
+    entry["valu_issue_frac_under_profiler"] = round(pf["SQ_INSTS_VALU"] * 2 / (1024 * pf["GRBM_GUI_ACTIVE"] / 8), 4)
+ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
+json.dump(bench_line, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
+tp = os.path.join(dst, "r02_counters.json")
 out = json.load(open(tp)) if os.path.exists(tp) else {}
-fetch, write = summ.get("FETCH_SIZE", {}).get("mean"), summ.get("WRITE_SIZE", {}).get("mean")
-entry = {"tag": tag, "dispatch": meta, "counters": summ, "bench_line_under_rocprof": bench_line}
-if fetch is not None and write is not None:
-    entry.update({"hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write})
 out[key] = entry
-json.dump(out, open(tp, "w"), indent=1)
-print(json.dumps({k: (v["mean"] if isinstance(v, dict) else v) for k, v in summ.items()}, indent=0))
-print("hbm_bytes_per_launch", entry.get("hbm_bytes_per_launch"))
+json.dump(out, open(tp, "w"), indent=1, sort_keys=True)
+print(key, json.dumps({k: entry.get(k) for k in ("valu_insts_per_frame", "lanes_active_per_valu", "tcp_accesses_per_frame", "hbm_bytes_per_frame",
+                                                  "valu_issue_frac_under_profiler", "frames_profiled")}, indent=0))
