@@ -6,19 +6,29 @@
 // node numbering -- so a mesh built here is interchangeable with one built by the host builder (csrc/host).
 //
 // The reference recurses node by node on the CPU (1.7 s for 70 k triangles); here the tree grows one LEVEL per step,
-// all nodes of the level in parallel:
-//   bounds   : one thread per triangle, float atomic min/max into its node's box
-//   bins     : one thread per triangle and axis, atomics into 6 bins x 3 axes (box + count) -- a plane's left side is
-//              the union of the bins below it, exactly the partition `centroid <= pos` of BVHTree.hpp:339
-//   decide   : one thread per node evaluates the 15 costs with the host builder's fp32 operations, picks axis/plane,
-//              and creates the two children (their sizes follow from the bin counts)
-//   partition: one device-wide exclusive scan of the "goes left" flags gives every triangle its stable rank
-// and a final pass converts the breadth-first node order into the reference's depth-first numbering.
+// all nodes of the level in parallel, and the level loop runs entirely on the device: the host enqueues the same six
+// launches for every level up to the depth limit without ever reading anything back (where a level starts and ends is
+// device state; past the last level the launches find an empty level and return).  Per level:
+//   bins     : one thread per triangle and axis, atomics into 6 bins x 3 axes (box + count) of its node -- a plane's left
+//              side is the union of the bins below it, exactly the partition `centroid <= pos` of BVHTree.hpp:339
+//   decide   : one thread per node evaluates the 15 costs with the host builder's fp32 operations, picks axis / plane and
+//              creates the two children: sizes from the bin counts, BOXES from the bin boxes (the union of the boxes of
+//              a set of triangles is the same whichever way it is folded, so no per-level bounds pass is needed)
+//   partition: the "goes left" flags, one device-wide exclusive scan of them (2 launches) -- every triangle's stable
+//              rank -- and one scatter
+// and one final pass turns breadth-first order into the reference's depth-first numbering without walking the levels:
+// in pre-order a node is preceded by its ancestors and by every node whose triangle range lies entirely to its left, so
+// pre(Y) = depth(Y) - 1 + #{X : end(X) <= first(Y)} -- a histogram of range ends and one more scan.
 // min/max are exact and order-independent, so the result does not depend on scheduling.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <cfloat>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -27,6 +37,8 @@
 
 namespace {
 
+constexpr int kMaxLevels = 64;                                   // level table size (the depth limit of the reference is 32)
+
 struct BuildNode {
     float mn[3], mx[3];
     int32_t first, count, depth;
@@ -34,8 +46,7 @@ struct BuildNode {
     int32_t axis;                   // split axis (valid while splitting)
     float split_pos;
     int32_t nl;                     // triangles going left
-    int32_t size;                   // subtree size (nodes), for the pre-order numbering
-    int32_t pre;                    // pre-order index
+    int32_t bin;                    // index of this node's Bins in the level's bin array, -1 = the node evaluates no split
 };
 
 struct Bins {                       // per node: 3 axes x 6 bins
@@ -43,26 +54,58 @@ struct Bins {                       // per node: 3 axes x 6 bins
     int32_t cnt[3][6];
 };
 
+// Everything the level loop needs to know lives on the device: level l is nodes [begin[l], begin[l + 1]).
+struct BuildState {
+    int32_t begin[kMaxLevels + 2];
+    int32_t total;                  // nodes created so far (children are appended by decide_kernel)
+    int32_t bins_used[2];           // bin slots handed out for the level being created (parity of that level)
+    int32_t levels;                 // non-empty levels
+    int32_t overflow;               // set when the node array or the level table would overflow (cannot happen for a valid cap)
+};
+
 // Float min/max through integer atomics: non-negative floats order like ints, negative ones like reversed unsigned
 // ints.  -0.0 has the bit pattern of INT_MIN and would break both orders, so zeros are canonicalised to +0.0 first
 // (x + 0.0f); a box may therefore hold +0.0 where a sequential fminf/fmaxf fold would hold -0.0 -- equal by value,
-// and no consumer of the boxes (costs, planes, slab tests) can tell the two apart.
+// and no consumer of the boxes (costs, planes, slab tests) can tell the two apart.  NaN is skipped, as fminf / fmaxf
+// skip it in the host builder's fold (which starts from +-FLT_MAX, so a NaN never enters a box).
 __device__ __forceinline__ void atomic_min_f(float* a, float v)
 {
+    if (!(v == v)) return;
     v = v + 0.0f;
     if (v >= 0.0f) atomicMin((int*)a, __float_as_int(v)); else atomicMax((unsigned int*)a, __float_as_uint(v));
 }
 __device__ __forceinline__ void atomic_max_f(float* a, float v)
 {
+    if (!(v == v)) return;
     v = v + 0.0f;
     if (v >= 0.0f) atomicMax((int*)a, __float_as_int(v)); else atomicMin((unsigned int*)a, __float_as_uint(v));
 }
 
-// per-triangle centroid (TrianglePrimitive::center, TrianglePrimitive.hpp:81-83) and box
-__global__ void prep_kernel(const float* __restrict__ v, int n, float* __restrict__ centroid, float* __restrict__ tbox,
-                            int32_t* __restrict__ order, int32_t* __restrict__ node_of)
+__device__ __forceinline__ void clear_bins(Bins& b)
+{
+    for (int a = 0; a < 3; a++)
+        for (int s = 0; s < 6; s++) {
+            for (int c = 0; c < 3; c++) { b.mn[a][s][c] = FLT_MAX; b.mx[a][s][c] = -FLT_MAX; }
+            b.cnt[a][s] = 0;
+        }
+}
+
+// per-triangle centroid (TrianglePrimitive::center, TrianglePrimitive.hpp:81-83) and box; block 0 also sets up the root
+__global__ void prep_kernel(const float* __restrict__ v, int n, int max_depth, float* __restrict__ centroid, float* __restrict__ tbox,
+                            int32_t* __restrict__ order, int32_t* __restrict__ node_of, BuildNode* nodes, Bins* bins, BuildState* st,
+                            int32_t* __restrict__ end_hist)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        BuildNode& r = nodes[0];                                 // fill(1, max_depth), MeshPrimitive.cpp:54
+        for (int c = 0; c < 3; c++) { r.mn[c] = FLT_MAX; r.mx[c] = -FLT_MAX; }
+        r.first = 0; r.count = n; r.depth = 1; r.child_a = r.child_b = -1; r.axis = 0; r.split_pos = 0.0f; r.nl = 0;
+        r.bin = (1 >= max_depth || n <= 1) ? -1 : 0;             // BVHTree.hpp:211-215
+        if (r.bin == 0) clear_bins(bins[0]);
+        for (int l = 0; l < kMaxLevels + 2; l++) st->begin[l] = l == 0 ? 0 : 1;
+        st->total = 1; st->bins_used[0] = 1; st->bins_used[1] = 0; st->levels = 1; st->overflow = 0;
+    }
+    if (i <= n) end_hist[i] = 0;
     if (i >= n) return;
     const float* t = v + 9 * (size_t)i;
     for (int k = 0; k < 3; k++) {
@@ -74,51 +117,21 @@ __global__ void prep_kernel(const float* __restrict__ v, int n, float* __restric
     node_of[i] = 0;
 }
 
-__global__ void init_level_kernel(BuildNode* nodes, Bins* bins, int level_begin, int level_end)
-{
-    int k = level_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= level_end) return;
-    BuildNode& nd = nodes[k];
-    for (int c = 0; c < 3; c++) { nd.mn[c] = FLT_MAX; nd.mx[c] = -FLT_MAX; }
-    nd.child_a = nd.child_b = -1;
-    Bins& b = bins[k - level_begin];
-    for (int a = 0; a < 3; a++)
-        for (int s = 0; s < 6; s++) {
-            for (int c = 0; c < 3; c++) { b.mn[a][s][c] = FLT_MAX; b.mx[a][s][c] = -FLT_MAX; }
-            b.cnt[a][s] = 0;
-        }
-}
-
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 
-// BVHTree.hpp:206-209: grow the node's box over its triangles.  Near the root every lane of a wave belongs to the same
-// node (ranges are contiguous), so the wave reduces first and issues 6 atomics instead of 384 on one address.
-__global__ void bounds_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
-                              const float* __restrict__ tbox, BuildNode* nodes, int level_begin)
+// BVHTree.hpp:206-209 for the root: grow its box over all triangles (a wave reduces first: 6 atomics per wave)
+__global__ void root_bounds_kernel(int n, const float* __restrict__ tbox, BuildNode* nodes)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int k = p < n ? node_of[p] : -1;
-    const bool valid = k >= level_begin;                         // else: past the end, or its node was finished earlier
-    const unsigned long long vm = __ballot(valid);
-    if (vm == 0) return;
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    if (valid) {
-        const float* tb = tbox + 6 * (size_t)order[p];
+    if (p < n) {
+        const float* tb = tbox + 6 * (size_t)p;
         for (int c = 0; c < 3; c++) { lo[c] = tb[c]; hi[c] = tb[3 + c]; }
     }
-    const int first = __ffsll((long long)vm) - 1;
-    const int k0 = __shfl(k, first);
-    if (__ballot(valid && k != k0) == 0) {                       // one node for the whole wave
-        for (int c = 0; c < 3; c++) { lo[c] = wave_min(lo[c]); hi[c] = wave_max(hi[c]); }
-        if ((int)(threadIdx.x & 63) == first) {
-            BuildNode& nd = nodes[k0];
-            for (int c = 0; c < 3; c++) { atomic_min_f(&nd.mn[c], lo[c]); atomic_max_f(&nd.mx[c], hi[c]); }
-        }
-    } else if (valid) {
-        BuildNode& nd = nodes[k];
-        for (int c = 0; c < 3; c++) { atomic_min_f(&nd.mn[c], lo[c]); atomic_max_f(&nd.mx[c], hi[c]); }
-    }
+    for (int c = 0; c < 3; c++) { lo[c] = wave_min(lo[c]); hi[c] = wave_max(hi[c]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 3; c++) { atomic_min_f(&nodes[0].mn[c], lo[c]); atomic_max_f(&nodes[0].mx[c], hi[c]); }
 }
 
 __device__ __forceinline__ float plane_pos(float mn, float mx, int s)
@@ -128,28 +141,29 @@ __device__ __forceinline__ float plane_pos(float mn, float mx, int s)
 }
 
 // evaluate_split's partition (BVHTree.hpp:324-348), binned: bin = number of planes the centroid lies beyond.
-// Same wave-level pre-reduction as bounds_kernel when the whole wave works on one node.
+// When the whole wave works on one node (always, near the root: ranges are contiguous) it reduces first and issues one
+// set of atomics per bin instead of 64 on the same addresses.
 __global__ void bins_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
                             const float* __restrict__ centroid, const float* __restrict__ tbox,
-                            const BuildNode* __restrict__ nodes, Bins* bins, int level_begin, int max_depth)
+                            const BuildNode* __restrict__ nodes, Bins* bins, const BuildState* __restrict__ st, int level)
 {
+    const int level_begin = st->begin[level];
+    if (level_begin >= st->begin[level + 1]) return;             // past the last level
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     int k = p < n ? node_of[p] : -1;
-    bool valid = k >= level_begin;
-    if (valid) {
-        const BuildNode& nd = nodes[k];
-        valid = !(nd.depth >= max_depth || nd.count <= 1);       // BVHTree.hpp:211-215: no split evaluated
-    }
+    bool valid = k >= level_begin;                               // else: past the end, or its node was finished earlier
+    int bin_index = -1;
+    if (valid) { bin_index = nodes[k].bin; valid = bin_index >= 0; }
     const unsigned long long vm = __ballot(valid);
     if (vm == 0) return;
     const int first = __ffsll((long long)vm) - 1;
-    const int k0 = __shfl(k, first);
+    const int k0 = __shfl(k, first), bin0 = __shfl(bin_index, first);
     const bool uniform = __ballot(valid && k != k0) == 0;
     const int t = valid ? order[p] : 0;
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     if (valid) { const float* tb = tbox + 6 * (size_t)t; for (int q = 0; q < 3; q++) { lo[q] = tb[q]; hi[q] = tb[3 + q]; } }
     const BuildNode& nd = nodes[valid ? k : k0];
-    Bins& b = bins[(valid ? k : k0) - level_begin];
+    Bins& b = bins[valid ? bin_index : bin0];
     for (int a = 0; a < 3; a++) {
         int s = 0;
         if (valid) {
@@ -184,20 +198,23 @@ __device__ __forceinline__ float box_cost(const float* mn, const float* mx, int 
     return half_area * (float)count;
 }
 
-// BVHTree.hpp:218-289 for every node of the level; children are appended to the node array
-__global__ void decide_kernel(BuildNode* nodes, const Bins* bins, int level_begin, int level_end, int max_depth,
-                              int32_t* node_counter)
+// BVHTree.hpp:218-289 for every node of the level; children are appended to the node array with their boxes (the union
+// of the bin boxes on their side of the plane = BVHTree.hpp:206-209 over their triangles) and, if they will evaluate a
+// split themselves, a cleared Bins slot of the other parity
+__global__ void decide_kernel(BuildNode* nodes, Bins* bins, int bins_per_level, BuildState* st, int level, int max_depth, int cap,
+                              const int32_t* __restrict__ order, const float* __restrict__ centroid, const float* __restrict__ tbox)
 {
+    const int level_begin = st->begin[level], level_end = st->begin[level + 1];
     int k = level_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= level_end) return;
     BuildNode& nd = nodes[k];
-    if (nd.depth >= max_depth || nd.count <= 1) return;
-    const Bins& b = bins[k - level_begin];
+    if (nd.bin < 0) return;                                      // depth or count limit: BVHTree.hpp:211-215
+    const Bins& b = bins[nd.bin];
     float eval_cost[3], eval_split[3];
-    int eval_nl[3];
+    int eval_nl[3], eval_s[3];                                   // eval_s = -1: no plane of the axis was accepted
     for (int a = 0; a < 3; a++) {
         float best_cost = FLT_MAX, best_split = 0.0f;
-        int best_nl = 0;
+        int best_nl = 0, best_s = -1;
         for (int s = 0; s < 5; s++) {
             float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
             float rmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -209,48 +226,90 @@ __global__ void decide_kernel(BuildNode* nodes, const Bins* bins, int level_begi
                 if (q <= s) ln += b.cnt[a][q]; else rn += b.cnt[a][q];
             }
             float cost = box_cost(lmn, lmx, ln) + box_cost(rmn, rmx, rn);          // BVHTree.hpp:351
-            if (cost < best_cost) { best_cost = cost; best_split = plane_pos(nd.mn[a], nd.mx[a], s); best_nl = ln; }
+            if (cost < best_cost) { best_cost = cost; best_split = plane_pos(nd.mn[a], nd.mx[a], s); best_nl = ln; best_s = s; }
         }
-        eval_cost[a] = best_cost; eval_split[a] = best_split; eval_nl[a] = best_nl;
+        eval_cost[a] = best_cost; eval_split[a] = best_split; eval_nl[a] = best_nl; eval_s[a] = best_s;
     }
     int axis;                                                    // BVHTree.hpp:229-243
     if (eval_cost[0] < eval_cost[1] && eval_cost[0] < eval_cost[2]) axis = 0;
     else if (eval_cost[1] < eval_cost[0] && eval_cost[1] < eval_cost[2]) axis = 1;
     else axis = 2;
     if (eval_cost[axis] >= box_cost(nd.mn, nd.mx, nd.count)) return;                // BVHTree.hpp:246
-    const int nl = eval_nl[axis], nr = nd.count - nl;
+    int nl = eval_nl[axis];
+    float cmn[2][3], cmx[2][3];                                  // the children's boxes
+    for (int side = 0; side < 2; side++)
+        for (int c = 0; c < 3; c++) { cmn[side][c] = FLT_MAX; cmx[side][c] = -FLT_MAX; }
+    if (eval_s[axis] >= 0) {
+        for (int q = 0; q < 6; q++) {
+            const int side = q <= eval_s[axis] ? 0 : 1;
+            for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], b.mn[axis][q][c]); cmx[side][c] = fmaxf(cmx[side][c], b.mx[axis][q][c]); }
+        }
+    } else {
+        // No plane was cheaper than FLT_MAX, and yet the test above let the node through: its own cost is infinite or NaN
+        // (infinite or NaN coordinates).  The reference then partitions at the initial split position 0 (BVHTree.hpp:253);
+        // the bins say nothing about that plane, so this one thread walks the node's triangles.  Degenerate inputs only.
+        nl = 0;
+        for (int i = 0; i < nd.count; i++) {
+            const int t = order[nd.first + i];
+            const int side = centroid[3 * (size_t)t + axis] <= eval_split[axis] ? 0 : 1;
+            nl += side == 0 ? 1 : 0;
+            for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], tbox[6 * (size_t)t + c]); cmx[side][c] = fmaxf(cmx[side][c], tbox[6 * (size_t)t + 3 + c]); }
+        }
+        for (int side = 0; side < 2; side++)                     // (the atomics of the binned path canonicalise zeros to +0.0)
+            for (int c = 0; c < 3; c++) { cmn[side][c] = cmn[side][c] + 0.0f; cmx[side][c] = cmx[side][c] + 0.0f; }
+    }
+    const int nr = nd.count - nl;
     if (nl == 0 || nr == 0) return;                              // BVHTree.hpp:279
-    const int a = atomicAdd(node_counter, 2);
+    const int a = atomicAdd(&st->total, 2);
+    if (a + 2 > cap || level + 2 > kMaxLevels) { st->overflow = 1; return; }
     nd.axis = axis; nd.split_pos = eval_split[axis]; nd.nl = nl;
     nd.child_a = a; nd.child_b = a + 1;
-    BuildNode& ca = nodes[a];
-    BuildNode& cb = nodes[a + 1];
-    ca.first = nd.first; ca.count = nl; ca.depth = nd.depth + 1;
-    cb.first = nd.first + nl; cb.count = nr; cb.depth = nd.depth + 1;
+    const int other = ((level + 1) & 1) * bins_per_level;        // children use the other half of the bin array
+    for (int side = 0; side < 2; side++) {
+        BuildNode& ch = nodes[a + side];
+        for (int c = 0; c < 3; c++) { ch.mn[c] = cmn[side][c]; ch.mx[c] = cmx[side][c]; }
+        ch.first = side == 0 ? nd.first : nd.first + nl;
+        ch.count = side == 0 ? nl : nr;
+        ch.depth = nd.depth + 1;
+        ch.child_a = ch.child_b = -1; ch.axis = 0; ch.split_pos = 0.0f; ch.nl = 0;
+        ch.bin = -1;
+        if (!(ch.depth >= max_depth || ch.count <= 1)) {
+            ch.bin = other + atomicAdd(&st->bins_used[(level + 1) & 1], 1);           // (<= n / 2 such nodes per level)
+            clear_bins(bins[ch.bin]);
+        }
+    }
 }
 
 // "goes left" flag of every position whose node splits (BVHTree.hpp:253-277)
 __global__ void flags_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
-                             const float* __restrict__ centroid, const BuildNode* __restrict__ nodes, int level_begin,
-                             int32_t* __restrict__ flags)
+                             const float* __restrict__ centroid, const BuildNode* __restrict__ nodes, const BuildState* __restrict__ st,
+                             int level, int32_t* __restrict__ flags)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int f = 0;
     const int k = node_of[p];
-    if (k >= level_begin) {
+    if (k >= st->begin[level]) {
         const BuildNode& nd = nodes[k];
         if (nd.child_a >= 0) f = centroid[3 * (size_t)order[p] + nd.axis] <= nd.split_pos ? 1 : 0;
     }
     flags[p] = f;
 }
 
-// stable partition: left triangles keep their order at the front of the node's range, right ones behind them
+// stable partition: left triangles keep their order at the front of the node's range, right ones behind them.
+// Thread 0 also closes the level: the next level ends where the node array now ends.
 __global__ void scatter_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
-                               const BuildNode* __restrict__ nodes, int level_begin, const int32_t* __restrict__ flags,
+                               const BuildNode* __restrict__ nodes, BuildState* st, int level, const int32_t* __restrict__ flags,
                                const int32_t* __restrict__ scan, int32_t* __restrict__ order_out, int32_t* __restrict__ node_of_out)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int level_begin = st->begin[level];
+    if (p == 0) {
+        const int total = st->total < 0x7fffffff ? st->total : 0x7fffffff;
+        if (level + 2 <= kMaxLevels + 1) st->begin[level + 2] = total;
+        if (total > st->begin[level + 1]) st->levels = level + 2;
+        st->bins_used[level & 1] = 0;                            // free for the level after next
+    }
     if (p >= n) return;
     const int k = node_of[p];
     int q = p, child = k;
@@ -268,40 +327,41 @@ __global__ void scatter_kernel(const int32_t* __restrict__ order, const int32_t*
     node_of_out[q] = child;
 }
 
-__global__ void size_kernel(BuildNode* nodes, int level_begin, int level_end)
-{
-    int k = level_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= level_end) return;
-    BuildNode& nd = nodes[k];
-    nd.size = nd.child_a >= 0 ? 1 + nodes[nd.child_a].size + nodes[nd.child_b].size : 1;
-}
-
-// BVHTree.hpp:283-289: child a is numbered right after its parent, child b after a's whole subtree
-__global__ void preorder_kernel(BuildNode* nodes, int level_begin, int level_end)
-{
-    int k = level_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= level_end) return;
-    BuildNode& nd = nodes[k];
-    if (nd.child_a >= 0) {
-        nodes[nd.child_a].pre = nd.pre + 1;
-        nodes[nd.child_b].pre = nd.pre + 1 + nodes[nd.child_a].size;
-    }
-}
-
-__global__ void emit_kernel(const BuildNode* __restrict__ nodes, int num_nodes, float* __restrict__ bounds,
-                            int32_t* __restrict__ children, int32_t* __restrict__ leaf_first, int32_t* __restrict__ leaf_count)
+// histogram of range ends (for the pre-order numbering)
+__global__ void ends_kernel(const BuildNode* __restrict__ nodes, const BuildState* __restrict__ st, int32_t* __restrict__ end_hist)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= num_nodes) return;
+    if (k >= st->total) return;
+    atomicAdd(&end_hist[nodes[k].first + nodes[k].count], 1);
+}
+
+// BVHTree.hpp:283-289 (child a right after its parent, child b after a's whole subtree) in closed form, and the output arrays
+__device__ __forceinline__ int preorder_of(const BuildNode& nd, const int32_t* ends_before)
+{
+    // ends_before[p] = nodes whose range ends at or before p = exclusive scan of the histogram, taken at p + 1
+    return nd.depth - 1 + ends_before[nd.first + 1];
+}
+__global__ void emit_kernel(const BuildNode* __restrict__ nodes, const BuildState* __restrict__ st, const int32_t* __restrict__ ends_before,
+                            float* __restrict__ bounds, int32_t* __restrict__ children, int32_t* __restrict__ leaf_first, int32_t* __restrict__ leaf_count)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= st->total) return;
     const BuildNode& nd = nodes[k];
-    const size_t o = (size_t)nd.pre;
+    // (a node with an empty range -- only the root of an empty mesh -- has nothing to its left)
+    const size_t o = nd.count > 0 ? (size_t)preorder_of(nd, ends_before) : 0;
     for (int c = 0; c < 3; c++) { bounds[6 * o + c] = nd.mn[c]; bounds[6 * o + 3 + c] = nd.mx[c]; }
     const bool leaf = nd.child_a < 0;
-    children[2 * o] = leaf ? -1 : nodes[nd.child_a].pre;
-    children[2 * o + 1] = leaf ? -1 : nodes[nd.child_b].pre;
+    children[2 * o] = leaf ? -1 : preorder_of(nodes[nd.child_a], ends_before);
+    children[2 * o + 1] = leaf ? -1 : preorder_of(nodes[nd.child_b], ends_before);
     leaf_first[o] = nd.first;
     leaf_count[o] = leaf ? nd.count : 0;
 }
+
+// one cached device arena per process (grow-only): a build of a 70 k-triangle mesh is shorter than a hipMalloc / hipFree pair
+std::mutex g_arena_mutex;
+char* g_arena = nullptr;
+size_t g_arena_bytes = 0;
+int g_arena_device = -1;
 
 }  // namespace
 
@@ -311,101 +371,120 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
 {
     if (n < 0 || max_depth < 1 || (n > 0 && !vertices) || !node_bounds || !node_children || !node_leaf_first ||
         !node_leaf_count || !num_nodes || (n > 0 && !leaf_indices)) return RT_E_INVALID;
+    if (max_depth > kMaxLevels) max_depth = kMaxLevels;          // (levels beyond the table cannot be represented; the reference uses 32)
     int rc = RT_OK;
     const int cap = n > 0 ? 2 * n : 1;                           // <= 2n - 1 nodes
     const int T = 256;
     const int gridN = (n + T - 1) / T;
-    float *d_v = nullptr, *d_centroid = nullptr, *d_tbox = nullptr, *d_bounds = nullptr;
-    int32_t *d_order[2] = {nullptr, nullptr}, *d_nodeof[2] = {nullptr, nullptr}, *d_flags = nullptr, *d_scan = nullptr;
-    int32_t *d_counter = nullptr, *d_children = nullptr, *d_lfirst = nullptr, *d_lcount = nullptr;
-    BuildNode* d_nodes = nullptr;
-    Bins* d_bins = nullptr;
-    void* d_tmp = nullptr;
-    char* arena = nullptr;
-    size_t tmp_bytes = 0;
-    std::vector<int> level_begin;
-    int cur = 0, total = 1, levels = 0;
-    BuildNode root;
+    const int bins_per_level = n / 2 + 1;                        // nodes that evaluate a split hold >= 2 triangles each
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    float *d_v, *d_centroid, *d_tbox, *d_bounds;
+    int32_t *d_order[2], *d_nodeof[2], *d_flags, *d_scan, *d_hist, *d_hscan, *d_children, *d_lfirst, *d_lcount;
+    BuildNode* d_nodes;
+    Bins* d_bins;
+    BuildState* d_state;
+    void* d_tmp;
+    size_t tmp_bytes = 0, tmp2 = 0;
+    int cur = 0, total = 0;
+    BuildState st;
 
-    // one device allocation for everything (a dozen hipMalloc / hipFree pairs cost more than the build kernels of a
-    // 70 k-triangle mesh): sizes are known up front because a tree over n triangles has at most 2n - 1 nodes
     {
-        RT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_flags, d_scan, n > 0 ? n : 1));
+        hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n > 0 ? n : 1);
+        hipError_t e2 = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, (int32_t*)nullptr, (int32_t*)nullptr, n + 2);
+        if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+        tmp_bytes = tmp_bytes > tmp2 ? tmp_bytes : tmp2;
         const size_t n1 = n > 0 ? (size_t)n : 1;
         size_t off = 0;
         auto take = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         const size_t o_v = take(n1 * 9 * 4), o_cen = take(n1 * 3 * 4), o_tbox = take(n1 * 6 * 4), o_ord0 = take(n1 * 4), o_ord1 = take(n1 * 4),
-                     o_nof0 = take(n1 * 4), o_nof1 = take(n1 * 4), o_flags = take(n1 * 4), o_scan = take(n1 * 4), o_counter = take(4),
-                     o_nodes = take(((size_t)cap + 2) * sizeof(BuildNode)), o_bins = take(n1 * sizeof(Bins)), o_tmp = take(tmp_bytes ? tmp_bytes : 1),
+                     o_nof0 = take(n1 * 4), o_nof1 = take(n1 * 4), o_flags = take(n1 * 4), o_scan = take(n1 * 4), o_hist = take((n1 + 2) * 4), o_hscan = take((n1 + 2) * 4),
+                     o_state = take(sizeof(BuildState)), o_nodes = take(((size_t)cap + 2) * sizeof(BuildNode)),
+                     o_bins = take(2 * (size_t)bins_per_level * sizeof(Bins)), o_tmp = take(tmp_bytes ? tmp_bytes : 1),
                      o_bounds = take((size_t)cap * 6 * 4), o_children = take((size_t)cap * 2 * 4), o_lfirst = take((size_t)cap * 4),
                      o_lcount = take((size_t)cap * 4);
-        RT_HIP(hipMalloc((void**)&arena, off));
+        int device = 0;
+        hipError_t he = hipGetDevice(&device);
+        if (he != hipSuccess) return he == hipErrorNoDevice ? RT_E_NODEVICE : (int)he;
+        if (g_arena_bytes < off || g_arena_device != device) {
+            (void)hipFree(g_arena);
+            g_arena = nullptr; g_arena_bytes = 0;
+            he = hipMalloc((void**)&g_arena, off + off / 4);     // some slack: meshes of similar size reuse it
+            if (he != hipSuccess) return (int)he;
+            g_arena_bytes = off + off / 4; g_arena_device = device;
+        }
+        char* arena = g_arena;
         d_v = (float*)(arena + o_v); d_centroid = (float*)(arena + o_cen); d_tbox = (float*)(arena + o_tbox);
         d_order[0] = (int32_t*)(arena + o_ord0); d_order[1] = (int32_t*)(arena + o_ord1);
         d_nodeof[0] = (int32_t*)(arena + o_nof0); d_nodeof[1] = (int32_t*)(arena + o_nof1);
-        d_flags = (int32_t*)(arena + o_flags); d_scan = (int32_t*)(arena + o_scan); d_counter = (int32_t*)(arena + o_counter);
+        d_flags = (int32_t*)(arena + o_flags); d_scan = (int32_t*)(arena + o_scan); d_hist = (int32_t*)(arena + o_hist); d_hscan = (int32_t*)(arena + o_hscan);
+        d_state = (BuildState*)(arena + o_state);
         d_nodes = (BuildNode*)(arena + o_nodes); d_bins = (Bins*)(arena + o_bins); d_tmp = arena + o_tmp;
         d_bounds = (float*)(arena + o_bounds); d_children = (int32_t*)(arena + o_children);
         d_lfirst = (int32_t*)(arena + o_lfirst); d_lcount = (int32_t*)(arena + o_lcount);
     }
 
-    if (n > 0) {
-        RT_HIP(hipMemcpy(d_v, vertices, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(prep_kernel, dim3(gridN), dim3(T), 0, 0, d_v, n, d_centroid, d_tbox, d_order[0], d_nodeof[0]);
-    }
-    memset(&root, 0, sizeof root);
-    root.first = 0; root.count = n; root.depth = 1; root.child_a = root.child_b = -1;      // fill(1, max_depth), MeshPrimitive.cpp:54
-    RT_HIP(hipMemcpy(d_nodes, &root, sizeof root, hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(d_counter, &total, sizeof(int), hipMemcpyHostToDevice));
+    const bool debug = getenv("RT_BVH_DEBUG") != nullptr;           // diagnostics: phase timings (with extra synchronisation) and a state dump
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_start = now(), t_in = 0, t_kernels = 0;
+    if (n > 0) RT_HIP(hipMemcpyAsync(d_v, vertices, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, 0));
+    if (debug) { (void)hipDeviceSynchronize(); t_in = now(); }
+    hipLaunchKernelGGL(prep_kernel, dim3((n + 1 + T - 1) / T), dim3(T), 0, 0, d_v, n, max_depth, d_centroid, d_tbox, d_order[0], d_nodeof[0],
+                       d_nodes, d_bins, d_state, d_hist);
+    if (n > 0) hipLaunchKernelGGL(root_bounds_kernel, dim3(gridN), dim3(T), 0, 0, n, d_tbox, d_nodes);
 
-    // ---- one level per iteration ----
-    {
-        int lb = 0, le = 1;
-        while (lb < le) {
-            level_begin.push_back(lb);
-            levels++;
-            const int gridL = (le - lb + T - 1) / T;
-            hipLaunchKernelGGL(init_level_kernel, dim3(gridL), dim3(T), 0, 0, d_nodes, d_bins, lb, le);
-            if (n > 0) {
-                hipLaunchKernelGGL(bounds_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_tbox, d_nodes, lb);
-                hipLaunchKernelGGL(bins_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_tbox,
-                                   d_nodes, d_bins, lb, max_depth);
-            }
-            hipLaunchKernelGGL(decide_kernel, dim3(gridL), dim3(T), 0, 0, d_nodes, d_bins, lb, le, max_depth, d_counter);
-            int new_total = 0;
-            RT_HIP(hipMemcpy(&new_total, d_counter, sizeof(int), hipMemcpyDeviceToHost));
-            if (new_total > cap) { rc = RT_E_INVALID; goto done; }
-            if (new_total > total && n > 0) {
-                hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, lb, d_flags);
-                RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n));
-                hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, lb, d_flags,
-                                   d_scan, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
-                cur ^= 1;
-            }
-            lb = le; le = new_total; total = new_total;
+    // ---- the level loop: six launches per level, nothing read back.  A tree over n triangles has at most n levels,
+    //      the depth limit caps it at max_depth; levels past the last one find begin[l] == begin[l + 1] and return. ----
+    if (n > 1) {
+        const int levels_to_run = max_depth < n ? max_depth : n;
+        for (int l = 0; l < levels_to_run; l++) {
+            const long long width = l < 30 ? (1ll << l) : (1ll << 30);
+            const int gridL = (int)(((width < n ? width : (long long)n) + T - 1) / T);
+            hipLaunchKernelGGL(bins_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_tbox, d_nodes, d_bins, d_state, l);
+            hipLaunchKernelGGL(decide_kernel, dim3(gridL), dim3(T), 0, 0, d_nodes, d_bins, bins_per_level, d_state, l, max_depth, cap,
+                               d_order[cur], d_centroid, d_tbox);
+            hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l, d_flags);
+            RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n));
+            hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
+                               d_order[cur ^ 1], d_nodeof[cur ^ 1]);
+            cur ^= 1;
         }
     }
-    level_begin.push_back(total);
     // ---- breadth-first -> the reference's depth-first numbering ----
-    for (int l = levels - 1; l >= 0; l--) {
-        const int lb = level_begin[l], le = level_begin[l + 1];
-        hipLaunchKernelGGL(size_kernel, dim3((le - lb + T - 1) / T), dim3(T), 0, 0, d_nodes, lb, le);
-    }
-    for (int l = 0; l < levels; l++) {                            // root.pre = 0 from the memset
-        const int lb = level_begin[l], le = level_begin[l + 1];
-        hipLaunchKernelGGL(preorder_kernel, dim3((le - lb + T - 1) / T), dim3(T), 0, 0, d_nodes, lb, le);
-    }
-    hipLaunchKernelGGL(emit_kernel, dim3((total + T - 1) / T), dim3(T), 0, 0, d_nodes, total, d_bounds, d_children, d_lfirst, d_lcount);
+    hipLaunchKernelGGL(ends_kernel, dim3((cap + T - 1) / T), dim3(T), 0, 0, d_nodes, d_state, d_hist);
+    RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_hist, d_hscan, n + 2));
+    hipLaunchKernelGGL(emit_kernel, dim3((cap + T - 1) / T), dim3(T), 0, 0, d_nodes, d_state, d_hscan, d_bounds, d_children, d_lfirst, d_lcount);
     RT_HIP(hipGetLastError());
+    if (debug) { (void)hipDeviceSynchronize(); t_kernels = now(); }
+    RT_HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
+    total = st.total;
+    if (debug) {
+        fprintf(stderr, "bvh: n %d total %d levels %d overflow %d bins_used %d %d begin", n, st.total, st.levels, st.overflow, st.bins_used[0], st.bins_used[1]);
+        for (int l = 0; l < 8; l++) fprintf(stderr, " %d", st.begin[l]);
+        fprintf(stderr, "\n");
+        std::vector<BuildNode> hn((size_t)(total < 7 ? total : 7));
+        (void)hipMemcpy(hn.data(), d_nodes, hn.size() * sizeof(BuildNode), hipMemcpyDeviceToHost);
+        for (size_t k = 0; k < hn.size(); k++)
+            fprintf(stderr, "  node %zu: [%g %g %g]-[%g %g %g] first %d count %d depth %d children %d %d axis %d split %g nl %d bin %d\n", k, hn[k].mn[0], hn[k].mn[1], hn[k].mn[2],
+                    hn[k].mx[0], hn[k].mx[1], hn[k].mx[2], hn[k].first, hn[k].count, hn[k].depth, hn[k].child_a, hn[k].child_b, hn[k].axis, hn[k].split_pos, hn[k].nl, hn[k].bin);
+        for (int k = 0; k < 3 && k < total; k++) {
+            if (hn[k].bin < 0) continue;
+            Bins hb;
+            (void)hipMemcpy(&hb, d_bins + hn[k].bin, sizeof hb, hipMemcpyDeviceToHost);
+            fprintf(stderr, "  bins of node %d:", k);
+            for (int a = 0; a < 3; a++) { fprintf(stderr, " |"); for (int q = 0; q < 6; q++) fprintf(stderr, " %d", hb.cnt[a][q]); }
+            fprintf(stderr, "\n");
+        }
+    }
+    if (st.overflow || total < 1 || total > cap) { rc = RT_E_INVALID; goto done; }
     RT_HIP(hipMemcpy(node_bounds, d_bounds, (size_t)total * 6 * sizeof(float), hipMemcpyDeviceToHost));
     RT_HIP(hipMemcpy(node_children, d_children, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
     RT_HIP(hipMemcpy(node_leaf_first, d_lfirst, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
     RT_HIP(hipMemcpy(node_leaf_count, d_lcount, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (n > 0) RT_HIP(hipMemcpy(leaf_indices, d_order[cur], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     *num_nodes = total;
-    if (num_levels) *num_levels = levels;
+    if (num_levels) *num_levels = st.levels;
+    if (debug) fprintf(stderr, "bvh timing: copy in %.3f ms, kernels %.3f ms, copy out (+ dump) %.3f ms\n", t_in - t_start, t_kernels - t_in, now() - t_kernels);
 
 done:
-    (void)hipFree(arena);
     return rc;
 }

@@ -83,6 +83,9 @@ struct RenderParams {
     int32_t local_rows, stripe_rows, rank, num_ranks;
     int32_t tiles_x, tiles_y;   // 16x16-pixel workgroup tiles over width x local_rows
     unsigned long long* trace;  // diagnostics: per-wave {start, end, hw id, tile} stamps, or null
+    // single-frame launches (render_kernel<.., ORDERED>): heavy-tiles-first dispatch from the previous frame's costs
+    const int32_t* tile_order;  // workgroup b renders tile tile_order[b] (null = b)
+    int32_t* tile_cost;         // [tile] loop iterations of the tile's longest lane (null = not recorded)
     // extension kernel (rt_render_ex): samples per pixel, specular bounces, sun + shadow pass, optional pops plane
     int32_t spp, bounces, lighting;
     int32_t sample_base;        // this launch renders sample indices sample_base + blockIdx.y

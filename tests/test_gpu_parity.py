@@ -307,6 +307,38 @@ def test_batched_frames_equal_single_frames(rt, orc, scenes, blob5k):
         b.free()
 
 
+def test_heavy_first_tile_order_keeps_frames_identical(rt, scenes, blob70k):
+    """Single-frame launches dispatch their tiles heaviest-first, in an order sorted from an earlier frame's per-tile costs
+    on a side stream (rt_kernels.hip, launch_ordered).  Whatever order a launch happens to read -- none yet, one frame
+    old, several frames old, sorted for another camera -- every frame must equal the frame the natural-order kernel
+    renders (rt_render_ids does not use the order)."""
+    W, H = 1920, 1080
+    sp = sd.blob_scene(scenes, blob70k).build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+    img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    poses = [scenes.C2_CAMERAS["far"]] * 3 + [scenes.C2_CAMERAS["near"], scenes.C2_CAMERAS["mid"]] + \
+            [(0.1 * k, -1.5 - 0.1 * k, 0.2, 0.05 * k, 0.0, 0.02 * k) for k in range(6)]
+    want = {}
+    for k, pose in enumerate(poses):
+        cam.set_pose(pose)
+        if pose not in want:
+            want[pose] = rt.render_ids(sp, cam)["img"]
+        # odd frames are issued back to back with the previous one (no host wait in between: the sort of the previous
+        # frame is then usually still pending), even ones after a synchronise
+        cam.render_scene(sp, img.ptr, img.pitch, synchronize=(k % 2 == 0))
+        rt.check(rt.libs()[0].rt_device_synchronize())
+        assert np.array_equal(img.to_host().reshape(H, W, 3), want[pose]), "frame %d" % k
+    # another frame size on the same scene: the order state starts over
+    cam2 = rt.Camera(1280, 720, scenes.scaled_K(1280), scenes.D_REF)
+    cam2.set_pose(scenes.C2_CAMERAS["mid"])
+    ref2 = rt.render_ids(sp, cam2)["img"]
+    for _ in range(3):
+        assert np.array_equal(rt.render(sp, cam2), ref2)
+    cam.set_pose(scenes.C2_CAMERAS["mid"])
+    assert np.array_equal(rt.render(sp, cam), want[scenes.C2_CAMERAS["mid"]])
+
+
 def test_batched_stripes_layout(rt, scenes, blob5k):
     """The buffer layout bench.py uses for N ranks x F frames per gather: every virtual rank renders its F stripe
     buffers straight into its slice of the gathered buffer, then each frame is un-striped and compared."""
@@ -545,6 +577,20 @@ def test_gpu_bvh_build_matches_host_builder(rt, scenes, blob5k, blob70k, atrium)
     base = sd.random_triangles(6, seed=3, spread=0.5, size=0.6)
     dup = np.concatenate([np.repeat(base[:1], 40, axis=0), np.repeat(base[1:2], 33, axis=0), base[2:]])
     _same_tree(rt.Mesh.from_triangles(dup, gpu_build=True).dump(), rt.Mesh.from_triangles(dup).dump())
+    # NaN and infinite coordinates: fminf / fmaxf skip NaN in the host builder's folds, the float atomics must too
+    weird = sd.random_triangles(700, seed=12, spread=1.0, size=0.3)
+    weird[5, 0] = np.nan; weird[17, 4] = np.inf; weird[40, 8] = -np.inf; weird[41, :9] = np.nan; weird[100, 2] = np.nan
+    weird[300:310, 1] = np.inf; weird[400, 3:6] = -np.inf
+    nans = sd.random_triangles(900, seed=13, spread=1.0, size=0.3)
+    nans[::37, 0] = np.nan; nans[5::53, 4] = np.nan; nans[11::71, 6:9] = np.nan; nans[200, :9] = np.nan
+    with np.errstate(all="ignore"):
+        _same_tree(rt.Mesh.from_triangles(weird, gpu_build=True).dump(), rt.Mesh.from_triangles(weird).dump())
+        host_nan = rt.Mesh.from_triangles(nans)
+        assert host_nan.num_nodes > 100                        # NaN vertices alone do not stop the splitting
+        a, b = rt.Mesh.from_triangles(nans, gpu_build=True).dump(), host_nan.dump()
+        for k in ("child", "leaf_count", "leaf_idx"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a["boxes"], b["boxes"], equal_nan=True)
     chain = sd.deep_stack_scene(28).meshes[0][1]
     d = rt.Mesh.from_triangles(chain, gpu_build=True)
     assert d.max_level == 28

@@ -152,3 +152,27 @@ def test_bench_self_launches_two_ranks(workload):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and "REHEARSAL_NOT_A_MEASUREMENT" in line
     assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
+
+
+def test_cpp_tiled_application(rt, orc, scenes, blob5k, tmp_path):
+    """examples/tiled_main.cpp: ONE C++ process, a scene replica and an RCCL communicator per visible GPU
+    (rt_comm_init_all), the frame through rt_render_tiled_all -- no Python, no torch in the process.  Its PNG must equal
+    the oracle's frame, for a plain frame and for a 4-spp frame with bounces and shadow rays."""
+    root = ROOT
+    exe = str(tmp_path / "tiled")
+    pkg = os.path.join(root, "cuda-raytracing_amd")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "csrc", "host"),
+                    os.path.join(root, "examples", "tiled_main.cpp"), "-L" + pkg, "-lrt_host", "-lrt_hip", "-Wl,-rpath," + pkg,
+                    "-o", exe], check=True)
+    W, H = 640, 360
+    desc = sd.SceneDesc([((0.9, 0.5, 0.2), None, dict(roughness=0.05, metallic=0.4))], [("obj", blob5k)], [(0, 0, (0,) * 6, (1, 1, 1))])
+    so = desc.build_oracle(orc)
+    for opts in ((1, 0, 0), (4, 2, 1)):
+        png = str(tmp_path / ("tiled_%d.png" % opts[0]))
+        r = subprocess.run([exe, blob5k, png, str(W), str(H)] + [str(v) for v in opts], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "GPU(s)" in r.stdout and "wrote" in r.stdout
+        ref = so.render_ex(W, H, scenes.scaled_K(W), scenes.D_REF, (0.0, -1.6, 0.2, 0, 0, 0), *opts, threads=16)["img"]
+        assert np.array_equal(rt.read_image(png), ref), opts
+    so.close()

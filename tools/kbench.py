@@ -73,8 +73,9 @@ def main():
                     cam.render_scene(scene, img.ptr, img.pitch)
                 else:
                     cam.render_scene_batch(scene, [pose] * a.batch, ptrs, img.pitch)
-        for _ in range(5):
+        for _ in range(5):                                 # warm-up; single-frame launches also settle their dispatch order
             go()
+            rt.check(rt.libs()[0].rt_device_synchronize())
         if a.streams > 1:                                  # events on one stream cannot bracket several: wall clock
             import time
             torch.cuda.synchronize()
