@@ -6,22 +6,24 @@
 // node numbering -- so a mesh built here is interchangeable with one built by the host builder (csrc/host).
 //
 // The reference recurses node by node on the CPU (1.7 s for 70 k triangles); here the tree grows one LEVEL per step,
-// all nodes of the level in parallel, and the level loop runs entirely on the device: the host enqueues the same six
+// all nodes of the level in parallel, and the level loop runs entirely on the device: the host enqueues the same
 // launches for every level up to the depth limit without ever reading anything back (where a level starts and ends is
-// device state; past the last level the launches find an empty level and return).  Per level:
+// device state; past the last level the launches find an empty level and return).  Per level (four launches up to 1 M
+// triangles):
 //   bins     : one thread per triangle and axis, atomics into 6 bins x 3 axes (box + count) of its node -- a plane's left
 //              side is the union of the bins below it, exactly the partition `centroid <= pos` of BVHTree.hpp:339
 //   decide   : one thread per node evaluates the 15 costs with the host builder's fp32 operations, picks axis / plane and
 //              creates the two children: sizes from the bin counts, BOXES from the bin boxes (the union of the boxes of
 //              a set of triangles is the same whichever way it is folded, so no per-level bounds pass is needed)
-//   partition: the "goes left" flags, one device-wide exclusive scan of them (2 launches) -- every triangle's stable
-//              rank -- and one scatter
+//   partition: the "goes left" flags with their exclusive scan per 256-position block and the block totals in one launch,
+//              then the scatter (each workgroup turns the totals into block offsets itself): every triangle's stable rank
 // and one final pass turns breadth-first order into the reference's depth-first numbering without walking the levels:
 // in pre-order a node is preceded by its ancestors and by every node whose triangle range lies entirely to its left, so
 // pre(Y) = depth(Y) - 1 + #{X : end(X) <= first(Y)} -- a histogram of range ends and one more scan.
 // min/max are exact and order-independent, so the result does not depend on scheduling.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 #include <cfloat>
 #include <chrono>
 #include <cstdint>
@@ -120,18 +122,25 @@ __global__ void prep_kernel(const float* __restrict__ v, int n, int max_depth, f
 __device__ __forceinline__ float wave_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 
-// BVHTree.hpp:206-209 for the root: grow its box over all triangles (a wave reduces first: 6 atomics per wave)
-__global__ void root_bounds_kernel(int n, const float* __restrict__ tbox, BuildNode* nodes)
+// BVHTree.hpp:206-209 for the root: grow its box over all triangles.  Few blocks with a grid-stride loop, a reduction
+// per block, six atomics per block (one atomic per wave put a thousand waves in line for the same six words).
+__global__ __launch_bounds__(1024) void root_bounds_kernel(int n, const float* __restrict__ tbox, BuildNode* nodes)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[16][6];
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    if (p < n) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const float* tb = tbox + 6 * (size_t)p;
-        for (int c = 0; c < 3; c++) { lo[c] = tb[c]; hi[c] = tb[3 + c]; }
+        for (int c = 0; c < 3; c++) { lo[c] = fminf(lo[c], tb[c]); hi[c] = fmaxf(hi[c], tb[3 + c]); }
     }
     for (int c = 0; c < 3; c++) { lo[c] = wave_min(lo[c]); hi[c] = wave_max(hi[c]); }
-    if ((threadIdx.x & 63) == 0)
-        for (int c = 0; c < 3; c++) { atomic_min_f(&nodes[0].mn[c], lo[c]); atomic_max_f(&nodes[0].mx[c], hi[c]); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; c++) { red[wave][c] = lo[c]; red[wave][3 + c] = hi[c]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[0][threadIdx.x];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomic_min_f(&nodes[0].mn[threadIdx.x], v); else atomic_max_f(&nodes[0].mx[threadIdx.x - 3], v);
+    }
 }
 
 __device__ __forceinline__ float plane_pos(float mn, float mx, int s)
@@ -154,6 +163,45 @@ __global__ void bins_kernel(const int32_t* __restrict__ order, const int32_t* __
     bool valid = k >= level_begin;                               // else: past the end, or its node was finished earlier
     int bin_index = -1;
     if (valid) { bin_index = nodes[k].bin; valid = bin_index >= 0; }
+    // Block-uniform case (every position of the block belongs to one splitting node: the upper levels, where a few nodes
+    // take all the triangles): the block bins into LDS and adds its 126 words to the node's bins once, instead of every
+    // wave queueing for the same words.  node_of is constant over a node's contiguous range, so comparing the block's
+    // first and last position decides it.
+    __shared__ int sbin[3][6][7];                                // per axis and bin: min xyz, max xyz (ordered-int encoded), count
+    const int p_first = blockIdx.x * blockDim.x, p_last = min(p_first + (int)blockDim.x, n) - 1;
+    const int k_first = node_of[p_first], k_last = node_of[p_last];
+    if (k_first == k_last && k_first >= level_begin && nodes[k_first].bin >= 0) {
+        const BuildNode& nd = nodes[k_first];
+        for (int i = threadIdx.x; i < 126; i += blockDim.x) { const int w = i % 7; (&sbin[0][0][0])[i] = w < 3 ? 0x7f7fffff : (w < 6 ? (int)0x80800000 : 0); }
+        __syncthreads();
+        if (p < n) {
+            const int t = order[p];
+            const float* tb = tbox + 6 * (size_t)t;
+            for (int a = 0; a < 3; a++) {
+                const float c = centroid[3 * (size_t)t + a];
+                int s = 0;
+                while (s < 5 && !(c <= plane_pos(nd.mn[a], nd.mx[a], s))) s++;
+                for (int q = 0; q < 3; q++) {
+                    // order-preserving integer image of a float (NaN skipped, zeros canonicalised, as atomic_min_f / atomic_max_f)
+                    const float lo_v = tb[q] + 0.0f, hi_v = tb[3 + q] + 0.0f;
+                    if (lo_v == lo_v) { const int b = __float_as_int(lo_v); atomicMin(&sbin[a][s][q], b >= 0 ? b : b ^ 0x7fffffff); }
+                    if (hi_v == hi_v) { const int b = __float_as_int(hi_v); atomicMax(&sbin[a][s][3 + q], b >= 0 ? b : b ^ 0x7fffffff); }
+                }
+                atomicAdd(&sbin[a][s][6], 1);
+            }
+        }
+        __syncthreads();
+        Bins& b = bins[nd.bin];
+        for (int i = threadIdx.x; i < 126; i += blockDim.x) {
+            const int a = i / 42, s = (i / 7) % 6, w = i % 7;
+            const int v = sbin[a][s][w];
+            if (w == 6) { if (v) atomicAdd(&b.cnt[a][s], v); continue; }
+            if (sbin[a][s][6] == 0) continue;                    // empty bin: nothing to add
+            const float f = __int_as_float(v >= 0 ? v : v ^ 0x7fffffff);
+            if (w < 3) atomic_min_f(&b.mn[a][s][w], f); else atomic_max_f(&b.mx[a][s][w - 3], f);
+        }
+        return;
+    }
     const unsigned long long vm = __ballot(valid);
     if (vm == 0) return;
     const int first = __ffsll((long long)vm) - 1;
@@ -296,12 +344,54 @@ __global__ void flags_kernel(const int32_t* __restrict__ order, const int32_t* _
     flags[p] = f;
 }
 
+// The usual case (up to kScanBlocks x 256 = 1 M triangles): flags, their exclusive scan inside each 256-position block and
+// the block totals in ONE launch; the scatter kernel turns the block totals into block offsets itself (every workgroup
+// scans the short totals array into LDS).  Two launches per level instead of flags + a library scan (two more) + scatter.
+constexpr int kScanBlocks = 4096;
+__global__ __launch_bounds__(256) void flags_scan_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
+                                                         const float* __restrict__ centroid, const BuildNode* __restrict__ nodes,
+                                                         const BuildState* __restrict__ st, int level, int32_t* __restrict__ flags,
+                                                         int32_t* __restrict__ local, int32_t* __restrict__ block_total)
+{
+    typedef hipcub::BlockScan<int, 256> BlockScan;
+    __shared__ typename BlockScan::TempStorage tmp;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int f = 0;
+    if (p < n) {
+        const int k = node_of[p];
+        if (k >= st->begin[level]) {
+            const BuildNode& nd = nodes[k];
+            if (nd.child_a >= 0) f = centroid[3 * (size_t)order[p] + nd.axis] <= nd.split_pos ? 1 : 0;
+        }
+    }
+    int before = 0, total = 0;
+    BlockScan(tmp).ExclusiveSum(f, before, total);
+    if (p < n) { flags[p] = f; local[p] = before; }
+    if (threadIdx.x == 0) block_total[blockIdx.x] = total;
+}
+
 // stable partition: left triangles keep their order at the front of the node's range, right ones behind them.
 // Thread 0 also closes the level: the next level ends where the node array now ends.
 __global__ void scatter_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
                                const BuildNode* __restrict__ nodes, BuildState* st, int level, const int32_t* __restrict__ flags,
-                               const int32_t* __restrict__ scan, int32_t* __restrict__ order_out, int32_t* __restrict__ node_of_out)
+                               const int32_t* __restrict__ scan, const int32_t* __restrict__ block_total, int num_blocks,
+                               int32_t* __restrict__ order_out, int32_t* __restrict__ node_of_out)
 {
+    // scan[] holds device-wide exclusive sums (block_total == nullptr: the hipcub path) or sums inside each 256-position
+    // block; in the second case the offset of block j is the sum of the totals of the blocks before it
+    __shared__ int block_offset[kScanBlocks];
+    if (block_total) {
+        typedef hipcub::BlockScan<int, 256> BlockScan;
+        __shared__ typename BlockScan::TempStorage tmp;
+        const int per_thread = (num_blocks + 255) / 256, j0 = threadIdx.x * per_thread;
+        int sum = 0;
+        for (int j = j0; j < j0 + per_thread && j < num_blocks; j++) sum += block_total[j];
+        int before = 0;
+        BlockScan(tmp).ExclusiveSum(sum, before);
+        for (int j = j0; j < j0 + per_thread && j < num_blocks; j++) { block_offset[j] = before; before += block_total[j]; }
+        __syncthreads();
+    }
+    auto scan_at = [&](int q) { return block_total ? block_offset[q >> 8] + scan[q] : scan[q]; };
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int level_begin = st->begin[level];
     if (p == 0) {
@@ -316,7 +406,7 @@ __global__ void scatter_kernel(const int32_t* __restrict__ order, const int32_t*
     if (k >= level_begin) {
         const BuildNode& nd = nodes[k];
         if (nd.child_a >= 0) {
-            const int lrank = scan[p] - scan[nd.first];          // left-going triangles before p inside the node
+            const int lrank = scan_at(p) - scan_at(nd.first);    // left-going triangles before p inside the node
             if (flags[p]) { q = nd.first + lrank; child = nd.child_a; }
             else { q = nd.first + nd.nl + (p - nd.first - lrank); child = nd.child_b; }
         } else {
@@ -379,7 +469,7 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     const int bins_per_level = n / 2 + 1;                        // nodes that evaluate a split hold >= 2 triangles each
     std::lock_guard<std::mutex> lock(g_arena_mutex);
     float *d_v, *d_centroid, *d_tbox, *d_bounds;
-    int32_t *d_order[2], *d_nodeof[2], *d_flags, *d_scan, *d_hist, *d_hscan, *d_children, *d_lfirst, *d_lcount;
+    int32_t *d_order[2], *d_nodeof[2], *d_flags, *d_scan, *d_btot, *d_hist, *d_hscan, *d_children, *d_lfirst, *d_lcount;
     BuildNode* d_nodes;
     Bins* d_bins;
     BuildState* d_state;
@@ -397,7 +487,7 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
         size_t off = 0;
         auto take = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         const size_t o_v = take(n1 * 9 * 4), o_cen = take(n1 * 3 * 4), o_tbox = take(n1 * 6 * 4), o_ord0 = take(n1 * 4), o_ord1 = take(n1 * 4),
-                     o_nof0 = take(n1 * 4), o_nof1 = take(n1 * 4), o_flags = take(n1 * 4), o_scan = take(n1 * 4), o_hist = take((n1 + 2) * 4), o_hscan = take((n1 + 2) * 4),
+                     o_nof0 = take(n1 * 4), o_nof1 = take(n1 * 4), o_flags = take(n1 * 4), o_scan = take(n1 * 4), o_btot = take(((n1 + 255) / 256 + 1) * 4), o_hist = take((n1 + 2) * 4), o_hscan = take((n1 + 2) * 4),
                      o_state = take(sizeof(BuildState)), o_nodes = take(((size_t)cap + 2) * sizeof(BuildNode)),
                      o_bins = take(2 * (size_t)bins_per_level * sizeof(Bins)), o_tmp = take(tmp_bytes ? tmp_bytes : 1),
                      o_bounds = take((size_t)cap * 6 * 4), o_children = take((size_t)cap * 2 * 4), o_lfirst = take((size_t)cap * 4),
@@ -416,7 +506,7 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
         d_v = (float*)(arena + o_v); d_centroid = (float*)(arena + o_cen); d_tbox = (float*)(arena + o_tbox);
         d_order[0] = (int32_t*)(arena + o_ord0); d_order[1] = (int32_t*)(arena + o_ord1);
         d_nodeof[0] = (int32_t*)(arena + o_nof0); d_nodeof[1] = (int32_t*)(arena + o_nof1);
-        d_flags = (int32_t*)(arena + o_flags); d_scan = (int32_t*)(arena + o_scan); d_hist = (int32_t*)(arena + o_hist); d_hscan = (int32_t*)(arena + o_hscan);
+        d_flags = (int32_t*)(arena + o_flags); d_scan = (int32_t*)(arena + o_scan); d_btot = (int32_t*)(arena + o_btot); d_hist = (int32_t*)(arena + o_hist); d_hscan = (int32_t*)(arena + o_hscan);
         d_state = (BuildState*)(arena + o_state);
         d_nodes = (BuildNode*)(arena + o_nodes); d_bins = (Bins*)(arena + o_bins); d_tmp = arena + o_tmp;
         d_bounds = (float*)(arena + o_bounds); d_children = (int32_t*)(arena + o_children);
@@ -430,11 +520,12 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     if (debug) { (void)hipDeviceSynchronize(); t_in = now(); }
     hipLaunchKernelGGL(prep_kernel, dim3((n + 1 + T - 1) / T), dim3(T), 0, 0, d_v, n, max_depth, d_centroid, d_tbox, d_order[0], d_nodeof[0],
                        d_nodes, d_bins, d_state, d_hist);
-    if (n > 0) hipLaunchKernelGGL(root_bounds_kernel, dim3(gridN), dim3(T), 0, 0, n, d_tbox, d_nodes);
+    if (n > 0) hipLaunchKernelGGL(root_bounds_kernel, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, 0, n, d_tbox, d_nodes);
 
-    // ---- the level loop: six launches per level, nothing read back.  A tree over n triangles has at most n levels,
+    // ---- the level loop: four launches per level, nothing read back.  A tree over n triangles has at most n levels,
     //      the depth limit caps it at max_depth; levels past the last one find begin[l] == begin[l + 1] and return. ----
     if (n > 1) {
+        const bool library_scan = getenv("RT_BVH_LIBRARY_SCAN") != nullptr;     // tests: force the path meshes above 1 M triangles take
         const int levels_to_run = max_depth < n ? max_depth : n;
         for (int l = 0; l < levels_to_run; l++) {
             const long long width = l < 30 ? (1ll << l) : (1ll << 30);
@@ -442,10 +533,17 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
             hipLaunchKernelGGL(bins_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_tbox, d_nodes, d_bins, d_state, l);
             hipLaunchKernelGGL(decide_kernel, dim3(gridL), dim3(T), 0, 0, d_nodes, d_bins, bins_per_level, d_state, l, max_depth, cap,
                                d_order[cur], d_centroid, d_tbox);
-            hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l, d_flags);
-            RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n));
-            hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
-                               d_order[cur ^ 1], d_nodeof[cur ^ 1]);
+            if (gridN <= kScanBlocks && !library_scan) {
+                hipLaunchKernelGGL(flags_scan_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l,
+                                   d_flags, d_scan, d_btot);
+                hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
+                                   d_btot, gridN, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
+            } else {                                             // very large meshes: library scan over the whole array
+                hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l, d_flags);
+                RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n));
+                hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
+                                   (const int32_t*)nullptr, 0, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
+            }
             cur ^= 1;
         }
     }

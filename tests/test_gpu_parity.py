@@ -577,6 +577,12 @@ def test_gpu_bvh_build_matches_host_builder(rt, scenes, blob5k, blob70k, atrium)
     base = sd.random_triangles(6, seed=3, spread=0.5, size=0.6)
     dup = np.concatenate([np.repeat(base[:1], 40, axis=0), np.repeat(base[1:2], 33, axis=0), base[2:]])
     _same_tree(rt.Mesh.from_triangles(dup, gpu_build=True).dump(), rt.Mesh.from_triangles(dup).dump())
+    # the partition path of meshes above 1 M triangles (device-wide library scan instead of the fused block scan)
+    os.environ["RT_BVH_LIBRARY_SCAN"] = "1"
+    try:
+        _same_tree(rt.Mesh.load_obj(blob70k, gpu_build=True).dump(), rt.Mesh.load_obj(blob70k).dump())
+    finally:
+        del os.environ["RT_BVH_LIBRARY_SCAN"]
     # NaN and infinite coordinates: fminf / fmaxf skip NaN in the host builder's folds, the float atomics must too
     weird = sd.random_triangles(700, seed=12, spread=1.0, size=0.3)
     weird[5, 0] = np.nan; weird[17, 4] = np.inf; weird[40, 8] = -np.inf; weird[41, :9] = np.nan; weird[100, 2] = np.nan
