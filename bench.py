@@ -537,7 +537,7 @@ def run_stream(args, env):
               "coverage": round(st["hits"] / st["rays"], 4),
               "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
               "algorithmic_bytes_per_ray": round(alg / st["rays"], 1)}
-    roof = roofline("render_kernel<false,false>", g["key"], kernel_ms, F, 1.0 / world, alg)
+    roof = roofline("render_kernel<false,false,false>", g["key"], kernel_ms, F, 1.0 / world, alg)
     extra = {"frame_matches_debug_kernel": frame_ok, "production_hit_ids_match_debug_kernel": ids_ok}
     value = W * H * args.steps / dt / 1e6
     out = base_line(args, g, value, dt, len(warm_groups) * F, config, roof, extra)

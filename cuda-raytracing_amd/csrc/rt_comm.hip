@@ -241,10 +241,17 @@ int rt_all_to_all(RtComm* c, const void* d_send, const size_t* send_bytes, const
     Rccl* r = rccl();
     if (!r) return RT_E_COMM;
     if (!c || !d_send || !d_recv || !send_bytes || !send_offsets || !recv_bytes || !recv_offsets) return RT_E_INVALID;
+    if (send_bytes[c->rank] != recv_bytes[c->rank]) return RT_E_INVALID;
+    // this rank's own block never leaves the device: a plain copy on the same stream
+    if (send_bytes[c->rank])
+        RT_HIP(hipMemcpyAsync((uint8_t*)d_recv + recv_offsets[c->rank], (const uint8_t*)d_send + send_offsets[c->rank], send_bytes[c->rank],
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (c->num_ranks == 1) return RT_OK;
     // one fused group of point-to-point transfers: every pair of ranks exchanges over its own xGMI link
     RT_NCCL(r, r->GroupStart(), "ncclGroupStart");
     ncclResult_t e = ncclSuccess;
     for (int p = 0; p < c->num_ranks && e == ncclSuccess; p++) {
+        if (p == c->rank) continue;
         if (send_bytes[p]) e = r->Send((const uint8_t*)d_send + send_offsets[p], send_bytes[p], ncclUint8, p, c->comm, (hipStream_t)stream);
         if (e == ncclSuccess && recv_bytes[p]) e = r->Recv((uint8_t*)d_recv + recv_offsets[p], recv_bytes[p], ncclUint8, p, c->comm, (hipStream_t)stream);
     }

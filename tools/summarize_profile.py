@@ -19,7 +19,9 @@ for line in open(os.path.join(src, "stats.log"), errors="ignore"):
 assert bench_line, "no bench line in stats.log"
 cfg = bench_line["config"]
 W, H, key = cfg["width"], cfg["height"], cfg["key"]
-kernel = bench_line["roofline"]["kernel"].replace("<false,false>", "<false, false>")
+kernel = bench_line["roofline"]["kernel"].replace(",", ", ")
+if kernel == "render_kernel<false, false>":                 # (lines printed before the ORDERED template parameter existed)
+    kernel = "render_kernel<false, false, false>"
 tiles = ((W + 15) // 16) * ((H + 15) // 16)
 per_frame_items = tiles * 256 * (cfg["spp"] if "render_ex" in kernel else 1)
 tot, meta, frames_by_pass = collections.defaultdict(float), {}, {}
