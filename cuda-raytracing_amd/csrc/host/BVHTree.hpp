@@ -25,6 +25,9 @@ public:
     void build(const TrianglePrimitive* triangles, int num_triangles, int max_depth = 32);   // fill(1, 32)
     // the same tree built on the GPU (rt_bvh_build); returns an rt_hip.h status, the tree is unchanged on failure
     int build_on_device(const TrianglePrimitive* triangles, int num_triangles, int max_depth = 32);
+    // same tree over moved triangles: every node's bounds recomputed (what fill()'s bounds pass gives that node), topology,
+    // leaf lists and numbering unchanged.  The reference has no refit; the device form is rt_scene_refit_mesh.
+    void refit(const TrianglePrimitive* triangles, int num_triangles);
     int max_level() const { return levels_; }
     void print_stats() const;                      // same report as BVHTree.hpp:117-172
 

@@ -14,6 +14,8 @@ public:
     int num_triangles;
     BVHTree bvh_top;
     const std::vector<TrianglePrimitive>& triangle_array() const { return triangles; }
+    // deformation with fixed connectivity: replaces the triangles (same count) and refits the BVH bounds; false if the count differs
+    bool refit(std::vector<TrianglePrimitive> moved);
 
 private:
     std::vector<TrianglePrimitive> triangles;

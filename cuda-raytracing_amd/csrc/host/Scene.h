@@ -32,6 +32,9 @@ public:
     void update_mesh_instance(int index, MeshInstance mesh_instance);   // rt_scene_update_instance (Scene.cpp:67-74)
     // the same, ordered on a stream instead of synchronising (rt_scene_update_instance_async): for per-frame animation
     void update_mesh_instance(int index, MeshInstance mesh_instance, void* stream);
+    // A mesh deforms (same triangle count and order): host copy and device copy get the moved triangles and refitted
+    // bounds; no rebuild, no re-upload of anything else.  Ordered on `stream` like update_mesh_instance(.., stream).
+    void refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream = nullptr);
     RtScene* d_scene = nullptr;
     int num_mesh_instances = 0;
     int last_error = 0;                             // rt_hip.h status of the last device call (the reference ignores errors)

@@ -144,6 +144,29 @@ void BVHTree::fill(int self, int depth, int max_depth)
     fill(b, depth + 1, max_depth);
 }
 
+void BVHTree::refit(const TrianglePrimitive* triangles, int n)
+{
+    tris_ = triangles;
+    for (int k = (int)nodes.size() - 1; k >= 0; k--) {          // children follow their parents in the array
+        BVHNode& nd = nodes[(size_t)k];
+        Box b;
+        if (nd.child_index_a < 0) {
+            for (int i = 0; i < nd.count && nd.first + i < n; i++) {
+                const TrianglePrimitive& t = triangles[order[(size_t)(nd.first + i)]];
+                for (int j = 0; j < 3; j++) { const float v[3] = {t.vertices[j].x, t.vertices[j].y, t.vertices[j].z}; b.grow(v, v); }
+            }
+        } else {
+            const BVHNode& ca = nodes[(size_t)nd.child_index_a];
+            const BVHNode& cb = nodes[(size_t)nd.child_index_b];
+            const float amn[3] = {ca.min.x, ca.min.y, ca.min.z}, amx[3] = {ca.max.x, ca.max.y, ca.max.z};
+            const float bmn[3] = {cb.min.x, cb.min.y, cb.min.z}, bmx[3] = {cb.max.x, cb.max.y, cb.max.z};
+            b.grow(amn, amx); b.grow(bmn, bmx);
+        }
+        nd.min = make_float3(b.mn[0], b.mn[1], b.mn[2]);
+        nd.max = make_float3(b.mx[0], b.mx[1], b.mx[2]);
+    }
+}
+
 int BVHTree::build_on_device(const TrianglePrimitive* triangles, int n, int max_depth)
 {
     std::vector<float> v((size_t)n * 9);
@@ -318,6 +341,29 @@ void Scene::upload_to_device()
     last_error = rt_scene_upload(&sd, &d_scene);
     num_mesh_instances = (int)mesh_instances.size();
     if (last_error) std::cerr << "Scene::upload_to_device: " << rt_error_string(last_error) << std::endl;
+}
+
+bool MeshPrimitive::refit(std::vector<TrianglePrimitive> moved)
+{
+    if ((int)moved.size() != num_triangles) return false;
+    triangles = std::move(moved);
+    bvh_top.refit(triangles.data(), num_triangles);
+    return true;
+}
+
+void Scene::refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream)
+{
+    if (mesh_index < 0 || mesh_index >= (int)meshes.size() || !meshes[(size_t)mesh_index].refit(std::move(moved))) { last_error = RT_E_INVALID; return; }
+    if (!d_scene) { last_error = RT_OK; return; }               // not uploaded yet: upload_to_device() will send the moved mesh
+    const MeshPrimitive& m = meshes[(size_t)mesh_index];
+    std::vector<float> v((size_t)m.num_triangles * 9), n((size_t)m.num_triangles * 3);
+    for (int t = 0; t < m.num_triangles; t++) {
+        const TrianglePrimitive& tr = m.triangle_array()[(size_t)t];
+        for (int k = 0; k < 3; k++) { v[9 * (size_t)t + 3 * k] = tr.vertices[k].x; v[9 * (size_t)t + 3 * k + 1] = tr.vertices[k].y; v[9 * (size_t)t + 3 * k + 2] = tr.vertices[k].z; }
+        n[3 * (size_t)t] = tr.normal.x; n[3 * (size_t)t + 1] = tr.normal.y; n[3 * (size_t)t + 2] = tr.normal.z;
+    }
+    last_error = rt_scene_refit_mesh(d_scene, mesh_index, v.data(), n.data(), m.num_triangles, stream);
+    if (last_error == RT_OK) last_error = rt_stream_synchronize(stream);   // v and n die with this call
 }
 
 void Scene::update_mesh_instance(int index, MeshInstance mesh_instance)

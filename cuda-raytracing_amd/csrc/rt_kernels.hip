@@ -240,8 +240,8 @@ __device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevIn
 // interior and leaf entries its lanes hold.  Each lane still visits exactly the reference's sequence of nodes.
 // PROF = diagnostic copy with s_memtime stamps per phase (RT_TRACE_FILE); its frames are never timed.
 // COUNT: *iters counts this lane's loop iterations (the cost measure behind the heavy-first dispatch order).
-// EX without DEBUG (the extension kernel): *pops counts the lane's node pops, the one visit count that kernel reports.
-template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack>
+// POPS (the extension kernel): *pops counts the lane's node pops, the one visit count that kernel reports.
+template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
                                                int* pops = nullptr)
@@ -264,7 +264,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         if constexpr (COUNT) (*iters)++;
         const bool interior = cur >= 0;
         if constexpr (DEBUG) cnt.pops += (interior || rem < 0) ? 1 : 0;
-        if constexpr (EX && !DEBUG) *pops += (interior || rem < 0) ? 1 : 0;
+        if constexpr (POPS) *pops += (interior || rem < 0) ? 1 : 0;
         // About half of all wave iterations (three quarters for close-up views) find every active lane holding
         // the SAME entry -- coherent rays walk the top of the tree in lockstep.  Those iterations fetch the record
         // once per wave through the scalar cache (s_load_dwordx16) instead of 64 x 64 B through the vector memory
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 // semantics are defined in DESIGN.md section 7 (and restated by the test oracle); with spp = 1, bounces = 0, lighting = 0 the
 // result equals render_kernel's bit for bit.
 // ---------------------------------------------------------------------------------------------------------
+template <bool LOC = true>                                  // LOC: keep the accepted hit's world location (secondary rays start there)
 __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, Stack& stack, int& pops)
 {
     Hit hit;
@@ -501,7 +502,7 @@ __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir
     hit.loc = v3(0.0f, 0.0f, 0.0f);
     Counters<false> none;
     for (int i = 0; i < p.num_instances; i++)
-        trace_instance<false, false, true, false>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
+        trace_instance<false, false, LOC, false, Stack, true>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
     return hit;
 }
 
@@ -521,6 +522,9 @@ __device__ __forceinline__ V3 hit_normal(const RenderParams& p, const Hit& hit)
 // of spp frames.  (A pixel's samples used to run as a loop inside its lane: the waves on the silhouette then lived
 // 64 x as long as their neighbours and the kernel spent most of its time waiting for a handful of them.)
 // The sample's radiance and node pops go to ex_samples[sample][local pixel]; resolve_ex_kernel sums them in order.
+// SIMPLE = no bounces and no lighting (samples per pixel only, BASELINE configs[3]): the path is one primary ray, so
+// nothing but the hit has to survive the cast -- no path state spilled around the traversal loop, no hit location.
+template <bool SIMPLE>
 __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];
@@ -550,6 +554,18 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     V3 dir = camera_direction(f, px, py);
     V3 weight = v3(1.0f, 1.0f, 1.0f), sample = v3(0.0f, 0.0f, 0.0f);
+    if constexpr (SIMPLE) {                                     // the loop below for bounces = 0, lighting = 0, written out
+        const Hit hit = cast_ray_ex<false>(p, org, dir, stack, pops);
+        if (hit.min == FLT_MAX) sample = sample + weight * v3(1.0f, 0.8f, 0.6f);
+        else {
+            const V3 base = base_colour(p, hit);
+            float illum = 1.0f;
+            illum = fminf(1.0f, illum);
+            illum = fmaxf(0.4f, illum);
+            const V3 local = v3(illum * base.x, illum * base.y, illum * base.z);
+            sample = sample + weight * (local * (1.0f - 0.0f));
+        }
+    } else
     for (int depth = 0; depth <= p.bounces; depth++) {
         const Hit hit = cast_ray_ex(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); break; }
@@ -672,6 +688,69 @@ __global__ __launch_bounds__(1024) void tile_sort_kernel(const int32_t* __restri
     for (int i = t; i < ntiles; i += 1024) order[atomicAdd(&start[keys[i]], 1)] = i;
 }
 
+// ---- refit of a deforming mesh (rt_scene_refit_mesh): same topology, new vertex positions ----------------------------
+// The reference has no refit (it can only re-pose instances, Scene.cpp:67-74); SURVEY.md 8(f) item 2 lists it next to the
+// build.  Result = the tree BVHTree::fill's bounds pass (BVHTree.hpp:206-209) would give every node of the SAME tree over
+// the moved triangles: a node's box is the exact min / max over its triangles' vertices, so folding children's boxes
+// bottom-up gives the same values as folding the triangles.
+__global__ void refit_triangles_kernel(float4* __restrict__ records, const int32_t* __restrict__ tri_id, int slot_base, int num_slots,
+                                       const float* __restrict__ vertices, const float* __restrict__ normals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_slots) return;
+    const int slot = slot_base + i;
+    const int t = tri_id[slot];
+    const float* v = vertices + 9 * (size_t)t;
+    const float* nn = normals + 3 * (size_t)t;
+    const V3 v0 = v3(v[0], v[1], v[2]), v1 = v3(v[3], v[4], v[5]), v2 = v3(v[6], v[7], v[8]);
+    const V3 e0 = v2 - v0, e1 = v1 - v0;                        // TrianglePrimitive.hpp:154-155 (as rt_scene_upload)
+    const float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1);
+    const float inv = 1.0f / (d00 * d11 - d01 * d01);          // TrianglePrimitive.hpp:164
+    float4* q = records + (size_t)slot * 4;
+    q[0] = make_float4(v0.x, v0.y, v0.z, nn[0]);
+    q[1] = make_float4(nn[1], nn[2], e0.x, e0.y);
+    q[2] = make_float4(e0.z, e1.x, e1.y, e1.z);
+    q[3] = make_float4(d00, d01, d11, inv);
+}
+
+// box of the subtree behind `ref`: a leaf's triangles' vertices, or the union of the two boxes an interior record holds
+__device__ __forceinline__ void refit_child_box(const float4* records, const int32_t* tri_id, const int32_t* leaf_count, const float* vertices,
+                                                int32_t ref, float* mn, float* mx)
+{
+    for (int c = 0; c < 3; c++) { mn[c] = FLT_MAX; mx[c] = -FLT_MAX; }
+    if (ref >= 0) {
+        const float4* q = records + (size_t)ref * 4;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        const float a[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y}, b[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        for (int c = 0; c < 3; c++) { mn[c] = fminf(fminf(mn[c], a[c]), b[c]); mx[c] = fmaxf(fmaxf(mx[c], a[3 + c]), b[3 + c]); }
+    } else {
+        const int slot = ref & kSlotMask;
+        int count = (ref >> kSlotBits) & 31;
+        if (count == 31) count = leaf_count[slot];
+        for (int k = 0; k < count; k++) {
+            const float* v = vertices + 9 * (size_t)tri_id[slot + k];
+            for (int j = 0; j < 3; j++)
+                for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], v[3 * j + c]); mx[c] = fmaxf(mx[c], v[3 * j + c]); }
+        }
+    }
+}
+
+// one level of interior nodes, deepest level first: sched[begin .. end) are the record indices of the level
+__global__ void refit_level_kernel(float4* records, const int32_t* __restrict__ tri_id, const int32_t* __restrict__ leaf_count,
+                                   const float* __restrict__ vertices, const int32_t* __restrict__ sched, int begin, int end)
+{
+    const int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end) return;
+    float4* q = records + (size_t)sched[i] * 4;
+    const float4 q3 = q[3];
+    float amn[3], amx[3], bmn[3], bmx[3];
+    refit_child_box(records, tri_id, leaf_count, vertices, __float_as_int(q3.x), amn, amx);
+    refit_child_box(records, tri_id, leaf_count, vertices, __float_as_int(q3.y), bmn, bmx);
+    q[0] = make_float4(amn[0], amn[1], amn[2], amx[0]);
+    q[1] = make_float4(amx[1], amx[2], bmn[0], bmn[1]);
+    q[2] = make_float4(bmn[2], bmx[0], bmx[1], bmx[2]);
+}
+
 // rt_scene_update_instance_async: the new record travels as a kernel argument, so the update is ordered on the stream
 // like any launch and needs no host buffer that outlives the call
 __global__ void set_instance_kernel(DevInstance* dst, const DevInstance value) { *dst = value; }
@@ -694,6 +773,16 @@ struct RtScene {
     std::vector<DevInstance> instances;          // host mirror (for update_instance)
     std::vector<int32_t> mesh_root_ref;          // per mesh
     std::vector<int32_t> mesh_exact_uv;
+    // per mesh, for rt_scene_refit_mesh: its slot range, triangle count, and its interior records grouped by tree level
+    struct MeshRefit {
+        int32_t slot_base = 0, num_slots = 0, num_triangles = 0;
+        std::vector<int32_t> sched;              // interior record indices, deepest level first
+        std::vector<int32_t> level_end;          // sched[level_end[k-1] .. level_end[k]) is one level
+        int32_t* d_sched = nullptr;
+    };
+    std::vector<MeshRefit> mesh_refit;
+    float* d_refit_scratch = nullptr;            // vertices + normals of the mesh being refitted (grow-only)
+    size_t refit_scratch_bytes = 0;
     int32_t num_materials = 0;
     int32_t max_stack = 1;
     size_t device_bytes = 0;
@@ -1027,6 +1116,19 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             }
             s->mesh_root_ref.push_back(entry[0]);
             s->mesh_exact_uv.push_back(exact_uv ? 1 : 0);
+            {
+                RtScene::MeshRefit rf;
+                rf.slot_base = (int32_t)slot_base; rf.num_slots = (int32_t)n_slot; rf.num_triangles = m.num_triangles;
+                std::vector<std::vector<int32_t>> by_level((size_t)max_level + 1);
+                for (int i = 0; i < m.num_nodes; i++)
+                    if (m.node_children[2 * i] > 0) by_level[(size_t)level[i]].push_back(entry[i]);
+                for (int l = max_level; l >= 1; l--) {
+                    if (by_level[(size_t)l].empty()) continue;
+                    rf.sched.insert(rf.sched.end(), by_level[(size_t)l].begin(), by_level[(size_t)l].end());
+                    rf.level_end.push_back((int32_t)rf.sched.size());
+                }
+                s->mesh_refit.push_back(std::move(rf));
+            }
         }
         if (rc == RT_OK) {
             s->num_materials = desc->num_materials;
@@ -1051,6 +1153,8 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     if ((rc = upload(&s->d_tri_uv, tri_uv, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_tri_id, tri_id, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_leaf_count, leaf_count, s->device_bytes))) return fail(rc);
+    for (auto& rf : s->mesh_refit)
+        if ((rc = upload(&rf.d_sched, rf.sched, s->device_bytes))) return fail(rc);
     std::vector<DevMaterial> mats((size_t)desc->num_materials);
     for (int i = 0; i < desc->num_materials; i++) {
         const RtMaterialDesc& m = desc->materials[i];
@@ -1095,6 +1199,37 @@ int rt_scene_update_instance_async(RtScene* s, int32_t index, const RtInstanceDe
     return RT_OK;
 }
 
+int rt_scene_refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, const float* normals, int32_t num_triangles, void* stream)
+{
+    if (!s || !vertices || !normals || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size()) return RT_E_INVALID;
+    const RtScene::MeshRefit& rf = s->mesh_refit[(size_t)mesh_index];
+    if (num_triangles != rf.num_triangles) return RT_E_INVALID;
+    if (rf.num_triangles == 0) return RT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nv = (size_t)rf.num_triangles * 9, nn = (size_t)rf.num_triangles * 3, need = (nv + nn) * sizeof(float);
+    if (s->refit_scratch_bytes < need) {
+        (void)hipFree(s->d_refit_scratch);                      // (synchronises with a refit still in flight)
+        s->d_refit_scratch = nullptr; s->refit_scratch_bytes = 0;
+        RT_HIP(hipMalloc((void**)&s->d_refit_scratch, need));
+        s->refit_scratch_bytes = need;
+    }
+    float* d_v = s->d_refit_scratch;
+    float* d_n = d_v + nv;
+    // (the host arrays may be pageable: the copies return once the bytes are staged, and stay ordered on the stream)
+    RT_HIP(hipMemcpyAsync(d_v, vertices, nv * sizeof(float), hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_n, normals, nn * sizeof(float), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(refit_triangles_kernel, dim3((unsigned)((rf.num_slots + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
+                       rf.slot_base, rf.num_slots, d_v, d_n);
+    int begin = 0;
+    for (int32_t end : rf.level_end) {                           // deepest level first: children before parents
+        hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)((end - begin + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
+                           s->d_leaf_count, d_v, rf.d_sched, begin, end);
+        begin = end;
+    }
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
 int rt_scene_destroy(RtScene* s)
 {
     if (!s) return RT_OK;
@@ -1104,6 +1239,8 @@ int rt_scene_destroy(RtScene* s)
         (void)hipStreamDestroy(s->order.sort_stream);
     }
     (void)hipFree(s->order.d_cost);
+    for (auto& rf : s->mesh_refit) (void)hipFree(rf.d_sched);
+    (void)hipFree(s->d_refit_scratch);
     (void)hipFree(s->d_ex_scratch);
     (void)hipFree(s->d_records); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
     (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
@@ -1189,7 +1326,8 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
         const bool tracing = trace_file && base == 0;
         p.sample_base = base;
         if (tracing) RT_HIP(trace_begin(p, trace_n));
-        hipLaunchKernelGGL(render_ex_kernel, grid, dim3(kBlock), lds, stream, p);
+        if (p.bounces == 0 && !p.lighting) hipLaunchKernelGGL(render_ex_kernel<true>, grid, dim3(kBlock), lds, stream, p);
+        else hipLaunchKernelGGL(render_ex_kernel<false>, grid, dim3(kBlock), lds, stream, p);
         RT_HIP(hipGetLastError());
         if (tracing) RT_HIP(trace_end(p, trace_n, trace_file, stream));
         hipLaunchKernelGGL(resolve_ex_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, p, n, base == 0 ? 1 : 0,

@@ -126,6 +126,13 @@ int rt_scene_update_instance(RtScene *scene, int32_t index, const RtInstanceDesc
  * call see the old instance, renders issued after it the new one -- an animated instance (the teapot of kernel.cu:272-273)
  * then costs no host wait per frame.  Renders in flight on OTHER streams are not ordered against it. */
 int rt_scene_update_instance_async(RtScene *scene, int32_t index, const RtInstanceDesc *instance, void *stream);
+/* Refit of a deforming mesh: the same triangles (same count, same order as at upload) at new positions.  vertices
+ * [n][3][3] and normals [n][3] are HOST arrays in the RtMeshDesc layout; uvs and the tree's topology stay.  Every node
+ * gets the exact bounds of its triangles (what BVHTree::fill's bounds pass, BVHTree.hpp:206-209, would compute for that
+ * node), triangle records are recomputed as at upload.  Ordered on `stream`: renders issued on it before the call see the
+ * old mesh, renders after it the new one.  No counterpart in the reference (SURVEY.md 8(f) item 2 "build / refit"). */
+int rt_scene_refit_mesh(RtScene *scene, int32_t mesh_index, const float *vertices, const float *normals,
+                        int32_t num_triangles, void *stream);
 int rt_scene_destroy(RtScene *scene);
 /* bytes of device memory the scene holds, and the traversal-stack depth it needs */
 int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);

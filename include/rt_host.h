@@ -56,6 +56,9 @@ int rth_scene_update_mesh_instance(RthScene *s, int32_t index, int32_t mesh, int
 /* ordered on `stream` instead of synchronising (rt_scene_update_instance_async) */
 int rth_scene_update_mesh_instance_async(RthScene *s, int32_t index, int32_t mesh, int32_t material, const float *pose6,
                                          const float *scale3, void *stream);
+/* Scene::refit_mesh: the mesh's triangles moved (tris18 = n TrianglePrimitives of 18 floats, same count and order as when
+ * the mesh was built): new triangle records and refitted BVH bounds on host and device, no rebuild (rt_scene_refit_mesh) */
+int rth_scene_refit_mesh(RthScene *s, int32_t mesh_index, const float *tris18, int32_t n, void *stream);
 int32_t rth_scene_num_mesh_instances(const RthScene *s);
 /* the RtScene* behind the Scene (for rt_render_debug etc.), NULL before upload */
 void *rth_scene_device_handle(RthScene *s);

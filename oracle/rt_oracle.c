@@ -394,6 +394,22 @@ OrcMesh *orc_mesh_from_triangles(const float *tris18, int n)
     return m;
 }
 
+/* Refit (no counterpart in the reference, which can only re-pose instances: Scene.cpp:67-74): the same tree over moved
+ * triangles.  Every node keeps its triangle list (like the reference's nodes) and gets the bounds BVHTree::fill's bounds
+ * pass (BVHTree.hpp:206-209) would compute over that list; topology and lists are untouched. */
+int orc_mesh_refit(OrcMesh *m, const float *tris18, int n)
+{
+    int k, i;
+    if (!m || n != m->ntris) return -1;
+    memcpy(m->tris, tris18, sizeof(tri_t) * (size_t)n);
+    for (k = 0; k < m->nnodes; k++) {
+        node_t *nd = &m->nodes[k];
+        box_init(&nd->bmin, &nd->bmax);
+        for (i = 0; i < nd->count; i++) box_grow_t(&nd->bmin, &nd->bmax, &m->tris[nd->idx[i]]);
+    }
+    return 0;
+}
+
 /* one triangle from 3 vertices via the 3-vertex constructor (config C1) */
 OrcMesh *orc_mesh_single_triangle(const float *abc9)
 {

@@ -87,6 +87,12 @@ class _Lib:
         t = np.ascontiguousarray(tris18, np.float32).reshape(-1, 18)
         return getattr(self.lib, self.prefix + "mesh_from_triangles")(_fp(t), t.shape[0])
 
+    def mesh_refit(self, h, tris18):
+        t = np.ascontiguousarray(tris18, np.float32).reshape(-1, 18)
+        fn = getattr(self.lib, self.prefix + "mesh_refit")
+        fn.argtypes = [C.c_void_p, _f, C.c_int]
+        assert fn(h, _fp(t), t.shape[0]) == 0
+
     def obj_load(self, path):
         h = getattr(self.lib, self.prefix + "obj_load")(path.encode())
         return h

@@ -220,6 +220,61 @@ def test_update_mesh_instance(rt, orc, scenes, blob5k):
         assert np.array_equal(dbg[n], ref[n]), n
 
 
+def test_refit_of_a_deforming_mesh(rt, orc, scenes, blob5k):
+    """Scene::refit_mesh / rt_scene_refit_mesh: the triangles of a mesh move (same count, same order), the tree keeps its
+    topology and every node gets the exact bounds of its triangles.  All planes must equal the oracle's, which refits the
+    same tree on its side (orc_mesh_refit); the deformed frame differs from the rest pose; a second refit back to the rest
+    pose restores the original frame; a host-built and a GPU-built mesh behave alike."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    W, H = 320, 180
+    K, pose = scenes.scaled_K(W), scenes.C2_CAMERAS["mid"]
+    tex = sd.checker_texture(32, 32, seed=5)
+    for gpu_build in (False, True):
+        mesh = rt.Mesh.load_obj(blob5k, gpu_build=gpu_build)
+        rest = mesh.dump()["tris"].copy()
+        sp = rt.Scene()
+        sp.add_material((1.0, 1.0, 1.0), texture_bgr=tex)
+        sp.add_mesh(mesh)
+        sp.add_mesh_instance(0, 0, (0.1, 0.0, 0.0, 0.2, 0.0, 0.0), (1.0, 0.9, 1.1))
+        sp.upload_to_device()
+        cam = rt.Camera(W, H, K, scenes.D_REF)
+        cam.set_pose(pose)
+        so = orc_mod.OracleScene(o)
+        so.add_material((1.0, 1.0, 1.0), tex)
+        om = o.mesh_from_triangles(rest)
+        so.add_mesh(om)
+        so.add_instance(0, 0, (0.1, 0.0, 0.0, 0.2, 0.0, 0.0), (1.0, 0.9, 1.1))
+        frames = []
+        for step in (1, 2, 0):                                  # two deformations, then back to the rest pose
+            moved = rest.copy()
+            v = moved[:, :9].reshape(-1, 3, 3)
+            v[..., 2] += np.float32(0.15 * step) * np.sin(3.0 * v[..., 0] + step)           # a travelling bulge
+            v[..., 1] *= np.float32(1.0 + 0.1 * step)
+            for i in range(len(moved)):                         # normals as the 3-vertex constructor computes them
+                moved[i, :12] = o.tri_from_vertices(moved[i, :9])[:12]
+            sp.refit_mesh(0, moved)
+            o.mesh_refit(om, moved)
+            ref = so.render(W, H, K, scenes.D_REF, pose, threads=8)
+            dbg = rt.render_debug(sp, cam)
+            ids = rt.render_ids(sp, cam)
+            assert np.array_equal(dbg["img"], ref["img"]) and np.array_equal(ids["img"], ref["img"]), step
+            for n in PLANES:
+                assert np.array_equal(dbg[n], ref[n]), (n, step)
+            assert np.array_equal(ids["hit_tri"], ref["hit_tri"])
+            frames.append(ref["img"])
+            if step == 2:                                       # a re-upload sends the host copy, which was refitted too
+                sp.upload_to_device()
+                again = rt.render_debug(sp, cam)
+                assert np.array_equal(again["img"], ref["img"]) and np.array_equal(again["pops"], ref["pops"])
+        assert not np.array_equal(frames[0], frames[2]) and not np.array_equal(frames[0], frames[1])
+        so.close()
+    h = rt.libs()[0]
+    import ctypes as C
+    assert h.rt_scene_refit_mesh(sp.device_handle, 3, rest.ctypes.data_as(C.POINTER(C.c_float)), rest.ctypes.data_as(C.POINTER(C.c_float)), len(rest), None) == -1
+    assert h.rt_scene_refit_mesh(sp.device_handle, 0, rest.ctypes.data_as(C.POINTER(C.c_float)), rest.ctypes.data_as(C.POINTER(C.c_float)), len(rest) - 1, None) == -1
+
+
 def test_animated_instance_without_host_waits(rt, orc, scenes, blob5k):
     """The animation loop of kernel.cu:272-277 (re-pose an instance, render, repeat) issued on one stream with no
     synchronisation in between: update k must be seen by render k and by no earlier one (rt_scene_update_instance_async)."""
