@@ -432,8 +432,8 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     }
 }
 
-// ORDERED (single-frame launches, see launch()): workgroup b renders tile tile_order[b] -- the tiles that took longest in
-// the previous frame first -- and the last wave of every workgroup to finish records the workgroup's cost for the
+// ORDERED (single-frame launches, see launch()): workgroup b renders tile tile_order[b] --
+// the tiles that took longest in the previous frame first -- and the last wave of every workgroup to finish records the workgroup's cost for the
 // next frame's order (cost = loop iterations of its longest lane).  A frame rendered alone ends in a tail of a few long waves (rays grazing the silhouette) on an
 // otherwise idle chip; started first, those waves run beside the bulk of the frame instead of after it
 // (measured: -22 % / -12 % / 0 % frame time for the far / mid / near camera).  Which tile a workgroup renders does not
@@ -446,10 +446,14 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
     // Workgroup b renders tile b (row-major).  Consecutive workgroups are dealt round-robin to the 8 XCDs, so every
     // XCD sees tiles from the whole frame: measured faster than giving each XCD one contiguous band (better load
     // balance; the working set is L1/L2 resident either way).
-    int tile = (int)blockIdx.x;
+    int tile = (int)blockIdx.x, frame = (int)blockIdx.y;
     lds_int* group = nullptr;                                   // ORDERED: {waves finished, longest lane so far}
     int iters = 0;
     if constexpr (ORDERED) {
+        // a one-dimensional grid: workgroup b renders frame b % F of the tile with rank b / F, so the costly tiles of ALL
+        // frames of a batch come first and the launch ends with cheap ones
+        frame = tile % p.num_frames;
+        tile = tile / p.num_frames;
         if (p.tile_order) tile = p.tile_order[tile];
         group = (lds_int*)lds_stack + (p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack) * kBlock;
         if (threadIdx.x == 0) { group[0] = 0; group[1] = 0; }
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
     if (x < p.width && ly < p.local_rows) {
         // stripes: local row -> frame row (identity when num_ranks == 1)
         const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
-        render_pixel<DEBUG, PROF, ORDERED>(p, p.frames[blockIdx.y], x, ly, y, (lds_int*)lds_stack + tid, &iters);   // blockIdx.y = frame of the batch
+        render_pixel<DEBUG, PROF, ORDERED>(p, p.frames[frame], x, ly, y, (lds_int*)lds_stack + tid, &iters);
     }
     if constexpr (ORDERED) {
         // cost of the tile = loop iterations of its longest lane: deterministic, unlike a lifetime, which also measures
@@ -522,6 +526,7 @@ __device__ __forceinline__ V3 hit_normal(const RenderParams& p, const Hit& hit)
 // of spp frames.  (A pixel's samples used to run as a loop inside its lane: the waves on the silhouette then lived
 // 64 x as long as their neighbours and the kernel spent most of its time waiting for a handful of them.)
 // The sample's radiance and node pops go to ex_samples[sample][local pixel]; resolve_ex_kernel sums them in order.
+// (8 waves per SIMD at 32 spilled registers beats 7 / 6 / 5 waves with 18 / 4 / 0 spills: +2 % / +8 % / +21 % time.)
 // SIMPLE = no bounces and no lighting (samples per pixel only, BASELINE configs[3]): the path is one primary ray, so
 // nothing but the hit has to survive the cast -- no path state spilled around the traversal loop, no hit location.
 template <bool SIMPLE>
@@ -796,8 +801,10 @@ struct RtScene {
         int cur = -1;                            // order buffer renders read (-1: none sorted yet -> natural order)
         bool pending = false;                    // a sort into d_order[target] is in flight on sort_stream
         int target = 0;
-        hipEvent_t render_done = nullptr, sort_done = nullptr;
+        hipEvent_t sort_done = nullptr;
         hipStream_t sort_stream = nullptr;
+        // the last ordered launch on each stream that uses this scene (a sort waits for all of them)
+        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; } seen[4];
     } order;
 };
 
@@ -894,12 +901,13 @@ hipError_t trace_end(RenderParams& p, size_t n, const char* path, hipStream_t st
     return e;
 }
 
-// Single-frame launch with heavy-first tile order.  The order a launch reads was sorted from the costs of an earlier
+// Launch with heavy-first tile order.  The order a launch reads was sorted from the costs of an earlier
 // frame by tile_sort_kernel on the scene's own side stream, so sorting never sits between two frames on the caller's
 // stream; the host switches to a new order when it finds its sort finished (an event query, no wait) and keeps at most one
 // sort in flight: a sort writes the buffer no queued or running launch reads (every launch issued before the sort used the
-// other buffer or has finished -- the sort waits for the latest of them -- and every launch issued while the sort is
-// pending still reads the other buffer).
+// other buffer or has finished -- the sort waits for the last ordered launch of every stream that renders this scene, up to
+// four; a fifth stream renders in natural order -- and every launch issued while the sort is pending still reads the
+// other buffer).
 int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchronize)
 {
     RtScene::TileOrder& o = s->order;
@@ -912,24 +920,28 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
         o.tiles_x = o.tiles_y = o.ntiles = 0; o.cur = -1;
         if (!o.sort_stream) {
             RT_HIP(hipStreamCreateWithFlags(&o.sort_stream, hipStreamNonBlocking));
-            RT_HIP(hipEventCreateWithFlags(&o.render_done, hipEventDisableTiming));
             RT_HIP(hipEventCreateWithFlags(&o.sort_done, hipEventDisableTiming));
+            for (auto& e : o.seen) RT_HIP(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
         }
+        for (auto& e : o.seen) e.used = false;                   // (hipFree above waited for every launch in flight)
         RT_HIP(hipMalloc((void**)&o.d_cost, (size_t)ntiles * 4 * sizeof(int32_t)));
         RT_HIP(hipMemsetAsync(o.d_cost, 0, (size_t)ntiles * sizeof(int32_t), stream));
         o.d_keys = o.d_cost + ntiles; o.d_order[0] = o.d_keys + ntiles; o.d_order[1] = o.d_order[0] + ntiles;
         o.tiles_x = p.tiles_x; o.tiles_y = p.tiles_y; o.ntiles = ntiles;
     }
     if (o.pending && hipEventQuery(o.sort_done) == hipSuccess) { o.cur = o.target; o.pending = false; }
-    p.tile_order = o.cur >= 0 ? o.d_order[o.cur] : nullptr;
-    p.tile_cost = o.d_cost;
+    RtScene::TileOrder::Seen* mine = nullptr;
+    for (auto& e : o.seen) if (e.used && e.stream == stream) mine = &e;
+    if (!mine) for (auto& e : o.seen) if (!e.used) { mine = &e; e.used = true; e.stream = stream; break; }
+    p.tile_order = (mine && o.cur >= 0) ? o.d_order[o.cur] : nullptr;
+    p.tile_cost = mine ? o.d_cost : nullptr;
     const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int) + 2 * sizeof(int);
-    hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles, 1), dim3(kBlock), lds, stream, p);
+    hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     RT_HIP(hipGetLastError());
-    if (!o.pending) {
+    if (mine) RT_HIP(hipEventRecord(mine->done, stream));
+    if (mine && !o.pending) {
         o.target = o.cur < 0 ? 0 : o.cur ^ 1;
-        RT_HIP(hipEventRecord(o.render_done, stream));
-        RT_HIP(hipStreamWaitEvent(o.sort_stream, o.render_done, 0));
+        for (auto& e : o.seen) if (e.used) RT_HIP(hipStreamWaitEvent(o.sort_stream, e.done, 0));
         hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(1024), 0, o.sort_stream, o.d_cost, ntiles, o.d_keys, o.d_order[o.target]);
         RT_HIP(hipGetLastError());
         RT_HIP(hipEventRecord(o.sort_done, o.sort_stream));
@@ -948,10 +960,13 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kBlock);
     const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
-    // one frame per launch, enough tiles to have a tail worth hiding: heavy-first order (RT_TILE_ORDER=0 turns it off)
-    if (scene && !debug && !trace_file && p.num_frames == 1 && grid.x >= 2048 && grid.x <= (1u << 22)) {
+    // Heavy-first dispatch (RT_TILE_ORDER=0 turns it off): for one frame per launch with enough tiles to have a tail worth
+    // hiding.  Batches do not use it: the tail of one frame already overlaps the bulk of the next, and measured with the
+    // order applied across all frames of a batch (workgroup b -> frame b % F of the tile with rank b / F) whole-frame batches ran -2 % (far) to +4 %
+    // (near), a rank's stripes of 32 frames -6 % on one stream but no better than the two alternating streams bench.py uses.
+    if (scene && !debug && !trace_file && !p.hit_instance && !p.hit_triangle && grid.x >= 256 && (size_t)grid.x * grid.y <= ((size_t)1 << 30)) {
         static const bool enabled = [] { const char* e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
-        if (enabled) return launch_ordered(scene, p, stream, synchronize);
+        if (enabled && p.num_frames == 1 && grid.x >= 2048) return launch_ordered(scene, p, stream, synchronize);
     }
     const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
     if (trace_file) RT_HIP(trace_begin(p, trace_n));
@@ -1235,7 +1250,8 @@ int rt_scene_destroy(RtScene* s)
     if (!s) return RT_OK;
     if (s->order.sort_stream) {
         (void)hipStreamSynchronize(s->order.sort_stream);
-        (void)hipEventDestroy(s->order.render_done); (void)hipEventDestroy(s->order.sort_done);
+        (void)hipEventDestroy(s->order.sort_done);
+        for (auto& e : s->order.seen) (void)hipEventDestroy(e.done);
         (void)hipStreamDestroy(s->order.sort_stream);
     }
     (void)hipFree(s->order.d_cost);

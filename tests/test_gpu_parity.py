@@ -384,6 +384,34 @@ def test_heavy_first_tile_order_keeps_frames_identical(rt, scenes, blob70k):
         cam.render_scene(sp, img.ptr, img.pitch, synchronize=(k % 2 == 0))
         rt.check(rt.libs()[0].rt_device_synchronize())
         assert np.array_equal(img.to_host().reshape(H, W, 3), want[pose]), "frame %d" % k
+    # a rank's stripes of a batch of frames take the same path (all frames' costly tiles first), here on two streams
+    import importlib
+    import torch
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    F, world, stripe, pitch = 4, 8, 16, W * 3
+    bposes = poses[-F:]
+    max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+    gathered = rt.DeviceBuffer(nbytes=world * F * max_rows * pitch)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cams = []
+    for st in streams:
+        c = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+        c.set_stream(st.cuda_stream)
+        cams.append(c)
+    for rep in range(3):
+        for r in range(world):
+            base = gathered.ptr.value + r * F * max_rows * pitch
+            cams[r & 1].render_scene_stripes_batch(sp, bposes, tiling.batch_local_ptrs(base, F, max_rows, pitch), pitch, stripe, r, world)
+        torch.cuda.synchronize()
+        outs = rt.DeviceBuffer(nbytes=F * H * pitch)
+        rt.check(h.rt_unstripe_batch(gathered.ptr, pitch, F * max_rows * pitch, max_rows * pitch, outs.ptr, pitch, H * pitch, F, W, H, stripe, world, None))
+        rt.check(h.rt_device_synchronize())
+        got = outs.to_host().reshape(F, H, W, 3)
+        for f in range(F):
+            assert np.array_equal(got[f], want[bposes[f]]), "stripes batch rep %d frame %d" % (rep, f)
+        outs.free()
+    gathered.free()
     # another frame size on the same scene: the order state starts over
     cam2 = rt.Camera(1280, 720, scenes.scaled_K(1280), scenes.D_REF)
     cam2.set_pose(scenes.C2_CAMERAS["mid"])
