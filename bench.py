@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--gather", default="auto", choices=["auto", "rotate", "root0"],
                     help="N > 1 stream workloads: rotate = the gather's root rotates over the frames of a group (one fused all-to-all), "
                          "root0 = every frame to rank 0; auto = rotate for streams, root0 for single frames")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1 data path: rccl = RtComm of the C-ABI (rt_gather / rt_all_to_all / rt_render_tiled), torch = the same buffers "
+                         "through torch.distributed's nccl backend (what a failed RtComm creation falls back to, announced in the line)")
     ap.add_argument("--one-stream", action="store_true", help="N > 1: launch every group on the same compute stream")
     ap.add_argument("--two-streams", action="store_true", help="one GPU: alternate consecutive groups between two streams")
     ap.add_argument("--force-collective", action="store_true",
@@ -331,15 +334,36 @@ def main():
 
     # ---- the exchange backend (N > 1): RCCL through the C-ABI, or the gloo rehearsal ----
     comm = exchange = None
+    exchange_note = None
     if dist_on:
         if rehearsal:
             exchange = tiling.TorchExchange(rank, world)
         else:
-            box = [rt.Comm.unique_id() if rank == 0 else None]
+            # the product path: RtComm (RCCL through the C-ABI).  If it cannot be created on every rank the run goes on with
+            # torch.distributed's own RCCL communicator moving the same buffers, and SAYS SO in the result line.
+            err = ""
+            try:
+                box = [rt.Comm.unique_id() if rank == 0 else None]
+            except rt.RtError as e:
+                box, err = [None], str(e)
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
-            comm = rt.Comm(box[0], rank, world)
-            exchange = tiling.RcclExchange(comm)
+            if box[0] is not None and args.exchange == "rccl":
+                try:
+                    comm = rt.Comm(box[0], rank, world)
+                except rt.RtError as e:
+                    err = str(e)
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                exchange = tiling.RcclExchange(comm)
+            else:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                exchange = tiling.TorchExchange(rank, world, on_device=True)
+                exchange_note = "torch.distributed (nccl backend) instead of rt_comm: " + (err or ("--exchange torch" if args.exchange != "rccl" else "another rank failed to create its RtComm"))
+                log("bench.py rank %d: %s" % (rank, exchange_note))
         rows = [tiling.stripe_rows(H, STRIPE_ROWS, r, world) for r in range(world)]
         max_rows = max(rows)
 
@@ -369,6 +393,8 @@ def base_line(args, env, value, dt, warmup_done, config, roof, extra):
         out["REHEARSAL_NOT_A_MEASUREMENT"] = "gloo backend, host-staged exchanges"
     if args.force_collective and world == 1:
         out["FORCED_COLLECTIVE_PATH"] = "N > 1 code path run with one rank"
+    if env.get("exchange_note"):
+        out["EXCHANGE_FALLBACK"] = env["exchange_note"]
     out.update({"steps": args.steps, "warmup": args.warmup, "warmup_frames_done": warmup_done,
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic", "config": config, "roofline": roof})
@@ -530,8 +556,8 @@ def run_stream(args, env):
                           "(a 4 mm loop around that camera)" % (name, mesh.num_triangles, mesh.num_nodes, W, H, g["cam_name"], str(tuple(base_pose[:3]))),
               "key": g["key"], "width": W, "height": H, "spp": 1, "bounces": 0, "lighting": 0,
               "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
-                             % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames through rt_all_to_all (the gather's root rotates: each rank assembles 1/N of the frames)" % F if rotate
-                                                  else ", one RCCL gather to rank 0 per %d frames through rt_gather" % F) if dist_on else ""),
+                             % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames) through %s" % (F, "rt_all_to_all" if g["comm"] is not None else "torch.distributed") if rotate
+                                                  else ", one RCCL gather to rank 0 per %d frames through %s" % (F, "rt_gather" if g["comm"] is not None else "torch.distributed")) if dist_on else ""),
               "frames_per_launch": F, "host_issue_ms_per_launch": round(t_issue / max(len(groups), 1) * 1e3, 3),
               "single_frame_launch_ms": None if latency is None else latency["f1_kernel_ms"], "latency": latency,
               "coverage": round(st["hits"] / st["rays"], 4),
@@ -595,25 +621,28 @@ def run_frames(args, env):
     spp, bounces, lighting, base_pose, exchange, comm = g["spp"], g["bounces"], g["lighting"], g["base_pose"], g["exchange"], g["comm"]
     poses = camera_path(base_pose, 8)
     frame = torch.empty((H, pitch), dtype=torch.uint8, device=dev)
-    if dist_on and rehearsal:
+    python_path = dist_on and comm is None                      # rehearsal (host-staged) or the torch.distributed fallback (device tensors)
+    if python_path:
         max_rows = g["max_rows"]
         local_dev = torch.zeros((max_rows, pitch), dtype=torch.uint8, device=dev)
-        local = torch.zeros_like(local_dev, device="cpu")
-        gathered = torch.empty((world, max_rows, pitch), dtype=torch.uint8) if rank == 0 else None
         gathered_dev = torch.empty((world, max_rows, pitch), dtype=torch.uint8, device=dev) if rank == 0 else None
+        local = local_dev if exchange.on_device else torch.zeros_like(local_dev, device="cpu")
+        gathered = gathered_dev if exchange.on_device else (torch.empty((world, max_rows, pitch), dtype=torch.uint8) if rank == 0 else None)
 
     def step(i):
         cam.set_pose(poses[i % len(poses)])
         if not dist_on:
             cam.render_scene(scene, frame.data_ptr(), pitch)                            # Camera::render_scene -> rt_render_ex
-        elif not rehearsal:
+        elif not python_path:
             cam.render_scene_tiled(scene, comm, frame.data_ptr(), pitch, stripe_rows=STRIPE_ROWS, root=0)   # stripes + rt_gather + un-stripe
         else:
-            cam.render_scene_stripes(scene, local_dev.data_ptr(), pitch, STRIPE_ROWS, rank, world, synchronize=True)
-            local.copy_(local_dev)
+            cam.render_scene_stripes(scene, local_dev.data_ptr(), pitch, STRIPE_ROWS, rank, world, synchronize=not exchange.on_device)
+            if not exchange.on_device:
+                local.copy_(local_dev)
             exchange.to_root(local, gathered, 0)
             if rank == 0:
-                gathered_dev.copy_(gathered)
+                if not exchange.on_device:
+                    gathered_dev.copy_(gathered)
                 rt.check(hlib.rt_unstripe(gathered_dev.data_ptr(), pitch, max_rows * pitch, frame.data_ptr(), pitch, W, H, STRIPE_ROWS, world, stream))
 
     sync = g["sync"]
@@ -665,7 +694,7 @@ def run_frames(args, env):
                              g["cam_name"], str(tuple(base_pose[:3]))),
               "key": g["key"], "width": W, "height": H, "spp": spp, "bounces": bounces, "lighting": lighting,
               "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
-                             % (STRIPE_ROWS, world, ", one RCCL gather to rank 0 per frame (Camera::render_scene_tiled -> rt_render_tiled)" if dist_on else ""),
+                             % (STRIPE_ROWS, world, (", one RCCL gather to rank 0 per frame (Camera::render_scene_tiled -> rt_render_tiled)" if comm is not None else ", one gather to rank 0 per frame through torch.distributed") if dist_on else ""),
               "frames_per_launch": 1, "primary_rays_per_frame": W * H * spp,
               "node_pops_per_pixel": round(pops / (W * H), 1), "G_node_pops_per_s_kernel": round(pops / max(world, 1) / (kernel_ms * 1e-3) / 1e9, 1)}
     roof = roofline("render_ex_kernel", g["key"], kernel_ms, 1, 1.0 / world)

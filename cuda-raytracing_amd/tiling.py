@@ -105,11 +105,12 @@ class RcclExchange:
 
 
 class TorchExchange:
-    """The same two calls over torch.distributed with host tensors (gloo): CPU tests and bench.py's rehearsal."""
-    on_device = False
+    """The same two calls over torch.distributed: with host tensors (gloo) in the CPU tests and bench.py's rehearsal, with
+    device tensors (backend nccl = RCCL driven by PyTorch) as bench.py's announced fallback when the C-ABI communicator
+    cannot be created.  The collectives are ordered against torch's current stream."""
 
-    def __init__(self, rank, world):
-        self.rank, self.world = rank, world
+    def __init__(self, rank, world, on_device=False):
+        self.rank, self.world, self.on_device = rank, world, on_device
 
     def to_root(self, local, gathered, root=0):
         import torch.distributed as dist

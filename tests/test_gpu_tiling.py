@@ -125,10 +125,13 @@ def test_stripe_pipeline_on_streams_with_distinct_poses(rt, scenes, blob5k, comm
 
 @pytest.mark.parametrize("extra", [["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8"],
                                    ["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8", "--gather", "root0"],
-                                   ["--workload", "c3", "--width", "320", "--height", "180", "--spp", "4", "--bounces", "2", "--steps", "3", "--warmup", "1"]])
+                                   ["--workload", "c3", "--width", "320", "--height", "180", "--spp", "4", "--bounces", "2", "--steps", "3", "--warmup", "1"],
+                                   ["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8", "--exchange", "torch"],
+                                   ["--workload", "c3", "--width", "320", "--height", "180", "--spp", "4", "--bounces", "2", "--steps", "3", "--warmup", "1",
+                                    "--exchange", "torch"]])
 def test_bench_forced_collective_path(extra):
     """bench.py --force-collective: the whole N > 1 code path (stripes, RCCL exchange through the C-ABI, un-stripe, frame
-    check) with the one rank a one-GPU box has."""
+    check) with the one rank a one-GPU box has; --exchange torch = the announced fallback transport."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-collective", "--no-cpu-baseline", "--no-latency"] + extra,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -136,6 +139,7 @@ def test_bench_forced_collective_path(extra):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["FORCED_COLLECTIVE_PATH"]
     assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
+    assert ("EXCHANGE_FALLBACK" in line) == ("torch" in extra)
 
 
 @pytest.mark.parametrize("workload", [["--workload", "c2", "--width", "480", "--height", "272", "--steps", "24", "--warmup", "4"],
