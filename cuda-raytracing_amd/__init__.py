@@ -481,10 +481,18 @@ class Comm:
     def gather(self, d_send, nbytes, d_recv, root=0, stream=None):
         check(libs()[0].rt_gather(self.h, d_send, nbytes, d_recv, root, stream), "rt_gather")
 
-    def all_to_all(self, d_send, send_bytes, send_offsets, d_recv, recv_bytes, recv_offsets, stream=None):
+    def all_to_all_plan(self, send_bytes, send_offsets, recv_bytes, recv_offsets):
+        """The four size arrays of rt_all_to_all as ctypes arrays, for calls repeated with the same layout."""
         arr = lambda v: (C.c_size_t * self.num_ranks)(*[int(x) for x in v])
-        check(libs()[0].rt_all_to_all(self.h, d_send, arr(send_bytes), arr(send_offsets), d_recv, arr(recv_bytes), arr(recv_offsets), stream),
-              "rt_all_to_all")
+        return arr(send_bytes), arr(send_offsets), arr(recv_bytes), arr(recv_offsets)
+
+    def all_to_all_planned(self, d_send, d_recv, plan, stream=None):
+        rc = libs()[0].rt_all_to_all(self.h, d_send, plan[0], plan[1], d_recv, plan[2], plan[3], stream)
+        if rc:
+            check(rc, "rt_all_to_all")
+
+    def all_to_all(self, d_send, send_bytes, send_offsets, d_recv, recv_bytes, recv_offsets, stream=None):
+        self.all_to_all_planned(d_send, d_recv, self.all_to_all_plan(send_bytes, send_offsets, recv_bytes, recv_offsets), stream)
 
     def close(self):
         if self.h:

@@ -85,6 +85,7 @@ class RcclExchange:
     def __init__(self, comm):
         self.comm = comm
         self.rank, self.world = comm.rank, comm.num_ranks
+        self._plans = {}
 
     @staticmethod
     def _stream():
@@ -96,12 +97,17 @@ class RcclExchange:
         self.comm.gather(local.data_ptr(), nbytes, gathered.data_ptr() if self.rank == root else None, root, self._stream())
 
     def rotating(self, local, received, count, max_rows):
-        _, counts, offsets, _ = rotating_plan(count, self.world)
         row = local.shape[1] * local.element_size()
-        me = self.rank
-        self.comm.all_to_all(local.data_ptr(), [c * max_rows * row for c in counts], [o * max_rows * row for o in offsets],
-                             received.data_ptr(), [counts[me] * max_rows * row] * self.world,
-                             [r * counts[me] * max_rows * row for r in range(self.world)], self._stream())
+        key = (count, max_rows, row)
+        plan = self._plans.get(key)
+        if plan is None:                                        # (built once per group size: this runs once per group of frames)
+            _, counts, offsets, _ = rotating_plan(count, self.world)
+            me = self.rank
+            plan = self.comm.all_to_all_plan([c * max_rows * row for c in counts], [o * max_rows * row for o in offsets],
+                                             [counts[me] * max_rows * row] * self.world,
+                                             [r * counts[me] * max_rows * row for r in range(self.world)])
+            self._plans[key] = plan
+        self.comm.all_to_all_planned(local.data_ptr(), received.data_ptr(), plan, self._stream())
 
 
 class TorchExchange:
