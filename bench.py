@@ -9,7 +9,9 @@ Workloads (BASELINE.json configs[1..4]; scenes are synthetic, see cuda-raytracin
   c4  260k-triangle atrium, 3840x2160, 16 spp                           (--spp 1: the primary kernel at 4K)
   c5  the c3 workload at 7680x4320, meant for --gpus 8 (frame tiled over the ranks, RCCL gather to rank 0)
 One "step" = one frame.  `value` = primary rays (width x height x spp) per second of wall clock over K steps, scene and
-frame buffers resident in HBM, timed between two barrier + synchronise pairs, max over ranks.
+frame buffers resident in HBM, timed between two barrier + synchronise pairs, max over ranks.  The untimed warm-up is at
+least W steps and, for the 1-spp stream, at least 320 frames (a frame is 0.13 ms; the GPU's clock needs tens of
+milliseconds of load to settle): the line reports the requested and the executed warm-up.
 
 c2 (and any 1-spp run) is a frame STREAM: frames are issued in groups of F = min(32, K) through
 Camera::render_scene_batch / rt_render_batch (one launch renders F frames along a short camera path: every frame of a
@@ -57,6 +59,7 @@ N_SIMD = 256 * 4
 VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 2 / 1e9     # wave64 VALU instructions per second: 2 cycles each on a SIMD-32 (MICROARCH "Wave scheduling")
 L1_PEAK_GBS = 256 * 64 * CLOCK_HZ / 1e9           # vector L1: one 64-B access per CU per clock
 STRIPE_ROWS = 16
+MIN_WARM_FRAMES = 320            # 1-spp stream workloads: untimed frames before the timed region, whatever --warmup asks (see run_stream)
 COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
@@ -416,7 +419,12 @@ def run_stream(args, env):
     f_max = args.frames_per_launch if args.frames_per_launch > 0 else 32
     F = max(1, min(f_max, 32, args.steps if args.steps > 0 else 1))
     groups = [F] * (args.steps // F) + ([args.steps % F] if args.steps % F else [])
-    warm_groups = [F] * ((args.warmup + F - 1) // F)             # whole groups: at least the requested warm-up
+    # Warm-up: whole groups, at least the requested W steps -- and at least MIN_WARM_FRAMES frames (about 45 ms of GPU work):
+    # a step here is 0.13 ms, and a GPU that has just been idle needs tens of milliseconds of load to reach its steady
+    # clock (measured: the same 20 timed steps take 0.153 ms each after 20 warm-up frames, 0.143 after 80, 0.135 after 320
+    # or 1280).  Both numbers are in the line ("warmup" = requested, "warmup_frames_done").
+    warm_frames = args.warmup if rehearsal else max(args.warmup, MIN_WARM_FRAMES)
+    warm_groups = [F] * ((warm_frames + F - 1) // F)
     poses = camera_path(base_pose, F)                            # frame f of every group uses poses[f]
     counts = sorted(set(groups + [F]))
 
