@@ -423,7 +423,7 @@ def run_stream(args, env):
     # a step here is 0.13 ms, and a GPU that has just been idle needs tens of milliseconds of load to reach its steady
     # clock (measured: the same 20 timed steps take 0.153 ms each after 20 warm-up frames, 0.143 after 80, 0.135 after 320
     # or 1280).  Both numbers are in the line ("warmup" = requested, "warmup_frames_done").
-    warm_frames = args.warmup if rehearsal else max(args.warmup, MIN_WARM_FRAMES)
+    warm_frames = args.warmup if rehearsal else max(args.warmup, MIN_WARM_FRAMES * world)    # (a rank of N renders 1/N of every frame)
     warm_groups = [F] * ((warm_frames + F - 1) // F)
     poses = camera_path(base_pose, F)                            # frame f of every group uses poses[f]
     counts = sorted(set(groups + [F]))
