@@ -130,7 +130,8 @@ int rt_scene_update_instance_async(RtScene *scene, int32_t index, const RtInstan
  * [n][3][3] and normals [n][3] are HOST arrays in the RtMeshDesc layout; uvs and the tree's topology stay.  Every node
  * gets the exact bounds of its triangles (what BVHTree::fill's bounds pass, BVHTree.hpp:206-209, would compute for that
  * node), triangle records are recomputed as at upload.  Ordered on `stream`: renders issued on it before the call see the
- * old mesh, renders after it the new one.  No counterpart in the reference (SURVEY.md 8(f) item 2 "build / refit"). */
+ * old mesh, renders after it the new one; the host arrays must stay valid until the stream has passed the call
+ * (rt_stream_synchronize, or any later synchronising call).  No counterpart in the reference. */
 int rt_scene_refit_mesh(RtScene *scene, int32_t mesh_index, const float *vertices, const float *normals,
                         int32_t num_triangles, void *stream);
 int rt_scene_destroy(RtScene *scene);

@@ -57,6 +57,27 @@ def test_argument_validation_without_gpu(rt):
     assert h.rt_scene_destroy(None) == 0
 
 
+def test_comm_argument_validation_without_gpu(rt):
+    """The exchange entry points reject bad arguments before they touch RCCL or a device (no GPU here)."""
+    h, _ = rt.libs()
+    v = C.c_int32(0)
+    rc = h.rt_comm_available(C.byref(v))
+    assert rc in (0, -5)                                        # RCCL present in this image; -5 = RT_E_COMM if it were not
+    if rc == 0:
+        assert v.value > 20000
+        out = C.c_void_p()
+        assert h.rt_comm_init_rank(None, 0, 1, C.byref(out)) == -1
+        buf = (C.c_uint8 * 128)()
+        assert h.rt_comm_init_rank(buf, 2, 2, C.byref(out)) == -1      # rank out of range
+        assert h.rt_comm_init_all(None, 0, C.byref(out)) == -1
+        assert h.rt_gather(None, None, 0, None, 0, None) == -1
+        assert h.rt_render_tiled(None, None, None, None, None, 0, 16, 0, None, 0) == -1
+    assert h.rt_comm_destroy(None) == 0
+    assert h.rt_comm_info(None, None, None, None) == -1
+    assert h.rt_error_string(-5).decode().startswith("rt:")
+    assert h.rt_scene_refit_mesh(None, 0, None, None, 0, None) == -1
+
+
 def test_stripe_rows_python_mirror(rt):
     tiling = __import__("importlib").import_module("cuda-raytracing_amd.tiling")
     h, _ = rt.libs()
