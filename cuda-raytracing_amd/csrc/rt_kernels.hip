@@ -660,17 +660,17 @@ __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pi
 }
 
 // Heavy-first dispatch order of the next single-frame launch: a counting sort of the tiles by the lifetime their workgroup
-// had in the last frame (its longest lane's iteration count, longest first), by one 1024-thread workgroup.  Each cost is read ONCE (a render
+// had in the last frame (its longest lane's iteration count, longest first), by one 256-thread workgroup.  Each cost is read ONCE (a render
 // on another stream may be rewriting the array): whatever the values, the result is a permutation of the tiles.
-constexpr int kSortKeys = 1024;
-__global__ __launch_bounds__(1024) void tile_sort_kernel(const int32_t* __restrict__ cost, int ntiles, int32_t* __restrict__ keys,
-                                                         int32_t* __restrict__ order)
+constexpr int kSortKeys = 1024, kSortThreads = 256;           // (four waves: finds room on a CU while a render kernel fills the chip)
+__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int32_t* __restrict__ cost, int ntiles, int32_t* __restrict__ keys,
+                                                                 int32_t* __restrict__ order)
 {
-    __shared__ int count[kSortKeys], start[kSortKeys];
+    __shared__ int count[kSortKeys], start[kSortKeys], partial[kSortThreads];
     const int t = threadIdx.x;
-    count[t] = 0;
+    for (int k = t; k < kSortKeys; k += kSortThreads) count[k] = 0;
     __syncthreads();
-    for (int i = t; i < ntiles; i += 1024) {
+    for (int i = t; i < ntiles; i += kSortThreads) {
         int k = cost[i];                                        // iterations of the tile's longest lane (a few hundred at most)
         k = k < 0 ? 0 : (k > kSortKeys - 1 ? kSortKeys - 1 : k);
         k = kSortKeys - 1 - k;                                  // longest first
@@ -678,19 +678,22 @@ __global__ __launch_bounds__(1024) void tile_sort_kernel(const int32_t* __restri
         atomicAdd(&count[k], 1);
     }
     __syncthreads();
-    start[t] = count[t];
+    // exclusive prefix over the classes: each thread owns kSortKeys / kSortThreads consecutive classes
+    constexpr int kPer = kSortKeys / kSortThreads;
+    int sum = 0;
+    for (int j = 0; j < kPer; j++) sum += count[t * kPer + j];
+    partial[t] = sum;
     __syncthreads();
-    for (int o = 1; o < kSortKeys; o <<= 1) {                   // inclusive scan (Hillis-Steele)
-        const int v = t >= o ? start[t - o] : 0;
+    for (int o = 1; o < kSortThreads; o <<= 1) {                // inclusive scan (Hillis-Steele)
+        const int v = t >= o ? partial[t - o] : 0;
         __syncthreads();
-        start[t] += v;
+        partial[t] += v;
         __syncthreads();
     }
-    const int first = start[t] - count[t];
+    int base = partial[t] - sum;
+    for (int j = 0; j < kPer; j++) { start[t * kPer + j] = base; base += count[t * kPer + j]; }     // running cursor of each class
     __syncthreads();
-    start[t] = first;                                           // running cursor of class t
-    __syncthreads();
-    for (int i = t; i < ntiles; i += 1024) order[atomicAdd(&start[keys[i]], 1)] = i;
+    for (int i = t; i < ntiles; i += kSortThreads) order[atomicAdd(&start[keys[i]], 1)] = i;
 }
 
 // ---- refit of a deforming mesh (rt_scene_refit_mesh): same topology, new vertex positions ----------------------------
@@ -942,7 +945,7 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     if (mine && !o.pending) {
         o.target = o.cur < 0 ? 0 : o.cur ^ 1;
         for (auto& e : o.seen) if (e.used) RT_HIP(hipStreamWaitEvent(o.sort_stream, e.done, 0));
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(1024), 0, o.sort_stream, o.d_cost, ntiles, o.d_keys, o.d_order[o.target]);
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, o.sort_stream, o.d_cost, ntiles, o.d_keys, o.d_order[o.target]);
         RT_HIP(hipGetLastError());
         RT_HIP(hipEventRecord(o.sort_done, o.sort_stream));
         o.pending = true;

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 echo "== stats: bench.py $*" | tee -a $out/progress.log
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline "$@" > $out/stats.log 2>$out/stats.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --no-latency "$@" > $out/stats.log 2>$out/stats.err
 echo "rc=$?" | tee -a $out/progress.log
 BENCH_ARGS="$*"
 pmc() { name=$1; shift; echo "== $name" | tee -a $out/progress.log; timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -- python3 bench.py $BENCH_ARGS --steps $psteps --warmup $pwarm --no-cpu-baseline --no-latency > $out/$name.log 2>$out/$name.err; rc=$?; echo "rc=$rc" | tee -a $out/progress.log; return $rc; }

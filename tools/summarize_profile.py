@@ -55,6 +55,18 @@ if "FETCH_SIZE" in pf and "WRITE_SIZE" in pf:
 if "GRBM_GUI_ACTIVE" in pf and "SQ_INSTS_VALU" in pf:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction holds a SIMD-32 for 2 cycles
     entry["valu_issue_frac_under_profiler"] = round(pf["SQ_INSTS_VALU"] * 2 / (1024 * pf["GRBM_GUI_ACTIVE"] / 8), 4)
+# kernel-trace pass: durations of the dominant kernel per launch shape (a run also contains a few single-frame launches of
+# the same kernel -- the frame checks -- which the plain --stats average mixes in)
+kt = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+if kt:
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt[0])):
+        if kernel in r["Kernel_Name"]:
+            grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            groups[grid].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    entry["kernel_trace"] = [{"grid_work_items": g, "frames_per_launch": round(g / per_frame_items, 3), "launches": len(v),
+                              "avg_ms": round(sum(v) / len(v), 4), "min_ms": round(min(v), 4), "max_ms": round(max(v), 4)}
+                             for g, v in sorted(groups.items(), key=lambda kv: -len(kv[1]))]
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
