@@ -249,70 +249,104 @@ __device__ __forceinline__ float box_cost(const float* mn, const float* mx, int 
 // BVHTree.hpp:218-289 for every node of the level; children are appended to the node array with their boxes (the union
 // of the bin boxes on their side of the plane = BVHTree.hpp:206-209 over their triangles) and, if they will evaluate a
 // split themselves, a cleared Bins slot of the other parity
+//
+// Node pairs and bin slots are handed out per WAVE (one atomic on the shared counter per wave, the lanes take consecutive
+// pieces): with one atomic per node the deep levels -- tens of thousands of nodes -- queued on a single word.
 __global__ void decide_kernel(BuildNode* nodes, Bins* bins, int bins_per_level, BuildState* st, int level, int max_depth, int cap,
                               const int32_t* __restrict__ order, const float* __restrict__ centroid, const float* __restrict__ tbox)
 {
     const int level_begin = st->begin[level], level_end = st->begin[level + 1];
-    int k = level_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= level_end) return;
-    BuildNode& nd = nodes[k];
-    if (nd.bin < 0) return;                                      // depth or count limit: BVHTree.hpp:211-215
-    const Bins& b = bins[nd.bin];
-    float eval_cost[3], eval_split[3];
-    int eval_nl[3], eval_s[3];                                   // eval_s = -1: no plane of the axis was accepted
-    for (int a = 0; a < 3; a++) {
-        float best_cost = FLT_MAX, best_split = 0.0f;
-        int best_nl = 0, best_s = -1;
-        for (int s = 0; s < 5; s++) {
-            float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-            float rmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-            int ln = 0, rn = 0;
-            for (int q = 0; q < 6; q++) {
-                float* mn = q <= s ? lmn : rmn;
-                float* mx = q <= s ? lmx : rmx;
-                for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], b.mn[a][q][c]); mx[c] = fmaxf(mx[c], b.mx[a][q][c]); }
-                if (q <= s) ln += b.cnt[a][q]; else rn += b.cnt[a][q];
-            }
-            float cost = box_cost(lmn, lmx, ln) + box_cost(rmn, rmx, rn);          // BVHTree.hpp:351
-            if (cost < best_cost) { best_cost = cost; best_split = plane_pos(nd.mn[a], nd.mx[a], s); best_nl = ln; best_s = s; }
-        }
-        eval_cost[a] = best_cost; eval_split[a] = best_split; eval_nl[a] = best_nl; eval_s[a] = best_s;
-    }
-    int axis;                                                    // BVHTree.hpp:229-243
-    if (eval_cost[0] < eval_cost[1] && eval_cost[0] < eval_cost[2]) axis = 0;
-    else if (eval_cost[1] < eval_cost[0] && eval_cost[1] < eval_cost[2]) axis = 1;
-    else axis = 2;
-    if (eval_cost[axis] >= box_cost(nd.mn, nd.mx, nd.count)) return;                // BVHTree.hpp:246
-    int nl = eval_nl[axis];
+    const int k = level_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
+    bool split = k < level_end && nodes[k < level_end ? k : level_begin].bin >= 0;      // depth or count limit: BVHTree.hpp:211-215
+    BuildNode& nd = nodes[k < level_end ? k : level_begin];
+    int axis = 2, nl = 0;
+    float split_pos = 0.0f;
     float cmn[2][3], cmx[2][3];                                  // the children's boxes
     for (int side = 0; side < 2; side++)
         for (int c = 0; c < 3; c++) { cmn[side][c] = FLT_MAX; cmx[side][c] = -FLT_MAX; }
-    if (eval_s[axis] >= 0) {
-        for (int q = 0; q < 6; q++) {
-            const int side = q <= eval_s[axis] ? 0 : 1;
-            for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], b.mn[axis][q][c]); cmx[side][c] = fmaxf(cmx[side][c], b.mx[axis][q][c]); }
+    if (split) {
+        const Bins& b = bins[nd.bin];
+        float eval_cost[3], eval_split[3];
+        int eval_nl[3], eval_s[3];                               // eval_s = -1: no plane of the axis was accepted
+        for (int a = 0; a < 3; a++) {
+            float best_cost = FLT_MAX, best_split = 0.0f;
+            int best_nl = 0, best_s = -1;
+            // right side of plane s = bins s+1..5, accumulated from the far end; the left side grows with s (each bin is read
+            // twice instead of five times; unions of boxes are exact, so the order of the folds does not matter)
+            float rmn[5][3], rmx[5][3];
+            int rcount[5];
+            {
+                float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                int n = 0;
+                for (int q = 5; q >= 1; q--) {
+                    for (int c = 0; c < 3; c++) { amn[c] = fminf(amn[c], b.mn[a][q][c]); amx[c] = fmaxf(amx[c], b.mx[a][q][c]); }
+                    n += b.cnt[a][q];
+                    for (int c = 0; c < 3; c++) { rmn[q - 1][c] = amn[c]; rmx[q - 1][c] = amx[c]; }
+                    rcount[q - 1] = n;
+                }
+            }
+            float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            int ln = 0;
+            for (int s5 = 0; s5 < 5; s5++) {
+                for (int c = 0; c < 3; c++) { lmn[c] = fminf(lmn[c], b.mn[a][s5][c]); lmx[c] = fmaxf(lmx[c], b.mx[a][s5][c]); }
+                ln += b.cnt[a][s5];
+                const float cost = box_cost(lmn, lmx, ln) + box_cost(rmn[s5], rmx[s5], rcount[s5]);     // BVHTree.hpp:351
+                if (cost < best_cost) { best_cost = cost; best_split = plane_pos(nd.mn[a], nd.mx[a], s5); best_nl = ln; best_s = s5; }
+            }
+            eval_cost[a] = best_cost; eval_split[a] = best_split; eval_nl[a] = best_nl; eval_s[a] = best_s;
         }
-    } else {
-        // No plane was cheaper than FLT_MAX, and yet the test above let the node through: its own cost is infinite or NaN
-        // (infinite or NaN coordinates).  The reference then partitions at the initial split position 0 (BVHTree.hpp:253);
-        // the bins say nothing about that plane, so this one thread walks the node's triangles.  Degenerate inputs only.
-        nl = 0;
-        for (int i = 0; i < nd.count; i++) {
-            const int t = order[nd.first + i];
-            const int side = centroid[3 * (size_t)t + axis] <= eval_split[axis] ? 0 : 1;
-            nl += side == 0 ? 1 : 0;
-            for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], tbox[6 * (size_t)t + c]); cmx[side][c] = fmaxf(cmx[side][c], tbox[6 * (size_t)t + 3 + c]); }
+        if (eval_cost[0] < eval_cost[1] && eval_cost[0] < eval_cost[2]) axis = 0;   // BVHTree.hpp:229-243
+        else if (eval_cost[1] < eval_cost[0] && eval_cost[1] < eval_cost[2]) axis = 1;
+        else axis = 2;
+        split_pos = eval_split[axis];
+        if (eval_cost[axis] >= box_cost(nd.mn, nd.mx, nd.count)) split = false;     // BVHTree.hpp:246
+        if (split) {
+            nl = eval_nl[axis];
+            if (eval_s[axis] >= 0) {
+                for (int q = 0; q < 6; q++) {
+                    const int side = q <= eval_s[axis] ? 0 : 1;
+                    for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], b.mn[axis][q][c]); cmx[side][c] = fmaxf(cmx[side][c], b.mx[axis][q][c]); }
+                }
+            } else {
+                // No plane was cheaper than FLT_MAX, and yet the test above let the node through: its own cost is infinite or
+                // NaN (infinite or NaN coordinates).  The reference then partitions at the initial split position 0
+                // (BVHTree.hpp:253); the bins say nothing about that plane, so this one thread walks the node's triangles.
+                // Degenerate inputs only.
+                nl = 0;
+                for (int i = 0; i < nd.count; i++) {
+                    const int t = order[nd.first + i];
+                    const int side = centroid[3 * (size_t)t + axis] <= split_pos ? 0 : 1;
+                    nl += side == 0 ? 1 : 0;
+                    for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], tbox[6 * (size_t)t + c]); cmx[side][c] = fmaxf(cmx[side][c], tbox[6 * (size_t)t + 3 + c]); }
+                }
+                for (int side = 0; side < 2; side++)             // (the atomics of the binned path canonicalise zeros to +0.0)
+                    for (int c = 0; c < 3; c++) { cmn[side][c] = cmn[side][c] + 0.0f; cmx[side][c] = cmx[side][c] + 0.0f; }
+            }
+            if (nl == 0 || nd.count - nl == 0) split = false;    // BVHTree.hpp:279
         }
-        for (int side = 0; side < 2; side++)                     // (the atomics of the binned path canonicalise zeros to +0.0)
-            for (int c = 0; c < 3; c++) { cmn[side][c] = cmn[side][c] + 0.0f; cmx[side][c] = cmx[side][c] + 0.0f; }
     }
+    // ---- one allocation per wave: 2 nodes per splitting lane, one bin slot per child that will evaluate a split itself
     const int nr = nd.count - nl;
-    if (nl == 0 || nr == 0) return;                              // BVHTree.hpp:279
-    const int a = atomicAdd(&st->total, 2);
+    const bool bin_a = split && !(nd.depth + 1 >= max_depth || nl <= 1), bin_b = split && !(nd.depth + 1 >= max_depth || nr <= 1);
+    const unsigned long long m_split = __ballot(split), m_a = __ballot(bin_a), m_b = __ballot(bin_b);
+    if (m_split == 0ull) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int leader = __ffsll((long long)m_split) - 1;
+    int node_base = 0, bin_base = 0;
+    if (lane == leader) {
+        node_base = atomicAdd(&st->total, 2 * __popcll(m_split));
+        if ((m_a | m_b) != 0ull) bin_base = atomicAdd(&st->bins_used[(level + 1) & 1], __popcll(m_a) + __popcll(m_b));
+    }
+    node_base = __shfl(node_base, leader);
+    bin_base = __shfl(bin_base, leader);
+    if (!split) return;
+    const int a = node_base + 2 * __popcll(m_split & below);
     if (a + 2 > cap || level + 2 > kMaxLevels) { st->overflow = 1; return; }
-    nd.axis = axis; nd.split_pos = eval_split[axis]; nd.nl = nl;
+    nd.axis = axis; nd.split_pos = split_pos; nd.nl = nl;
     nd.child_a = a; nd.child_b = a + 1;
     const int other = ((level + 1) & 1) * bins_per_level;        // children use the other half of the bin array
+    const int slot_a = bin_base + __popcll(m_a & below) + __popcll(m_b & below);       // (<= n / 2 such nodes per level)
     for (int side = 0; side < 2; side++) {
         BuildNode& ch = nodes[a + side];
         for (int c = 0; c < 3; c++) { ch.mn[c] = cmn[side][c]; ch.mx[c] = cmx[side][c]; }
@@ -321,8 +355,8 @@ __global__ void decide_kernel(BuildNode* nodes, Bins* bins, int bins_per_level, 
         ch.depth = nd.depth + 1;
         ch.child_a = ch.child_b = -1; ch.axis = 0; ch.split_pos = 0.0f; ch.nl = 0;
         ch.bin = -1;
-        if (!(ch.depth >= max_depth || ch.count <= 1)) {
-            ch.bin = other + atomicAdd(&st->bins_used[(level + 1) & 1], 1);           // (<= n / 2 such nodes per level)
+        if (side == 0 ? bin_a : bin_b) {
+            ch.bin = other + slot_a + (side == 1 && bin_a ? 1 : 0);
             clear_bins(bins[ch.bin]);
         }
     }
