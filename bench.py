@@ -562,7 +562,7 @@ def run_stream(args, env):
     name = {"c2": "C2 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ"}.get(args.workload, args.workload)
     config = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s; every frame of a group has its own pose "
                           "(a 4 mm loop around that camera)" % (name, mesh.num_triangles, mesh.num_nodes, W, H, g["cam_name"], str(tuple(base_pose[:3]))),
-              "key": g["key"], "width": W, "height": H, "spp": 1, "bounces": 0, "lighting": 0,
+              "key": g["key"] + ("_f1" if F == 1 and not dist_on else ""), "width": W, "height": H, "spp": 1, "bounces": 0, "lighting": 0,
               "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
                              % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames) through %s" % (F, "rt_all_to_all" if g["comm"] is not None else "torch.distributed") if rotate
                                                   else ", one RCCL gather to rank 0 per %d frames through %s" % (F, "rt_gather" if g["comm"] is not None else "torch.distributed")) if dist_on else ""),
@@ -571,7 +571,10 @@ def run_stream(args, env):
               "coverage": round(st["hits"] / st["rays"], 4),
               "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
               "algorithmic_bytes_per_ray": round(alg / st["rays"], 1)}
-    roof = roofline("render_kernel<false,false,false>", g["key"], kernel_ms, F, 1.0 / world, alg)
+    # one frame per launch goes through the heavy-first variant of the kernel: its own profile entry
+    single = F == 1 and not dist_on
+    roof = roofline("render_kernel<false,false,true>" if single else "render_kernel<false,false,false>", g["key"] + ("_f1" if single else ""),
+                    kernel_ms, F, 1.0 / world, alg)
     extra = {"frame_matches_debug_kernel": frame_ok, "production_hit_ids_match_debug_kernel": ids_ok}
     value = W * H * args.steps / dt / 1e6
     out = base_line(args, g, value, dt, len(warm_groups) * F, config, roof, extra)
