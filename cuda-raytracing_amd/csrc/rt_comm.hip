@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -50,10 +51,12 @@ Rccl* rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // RT_RCCL_LIBRARY=<path>: load that library instead (the tests' in-process mock, tests/mock_rccl; an RCCL build elsewhere)
+        if (const char* e = getenv("RT_RCCL_LIBRARY")) r.lib = dlopen(e, RTLD_NOW | RTLD_LOCAL);
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) return;
         bool ok = true;

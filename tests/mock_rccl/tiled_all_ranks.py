@@ -1,0 +1,114 @@
+"""Child process of test_gpu_tiling.py::test_tiled_all_with_several_ranks_over_mock_rccl.  RT_RCCL_LIBRARY points rt_comm at
+the in-process mock (mock_rccl.cpp), so rt_comm_init_all can create N > 1 ranks on the one GPU of the box, and
+rt_render_tiled_all runs its real N-rank code: per-rank stripes, scratch sizing, the grouped gathers, the un-stripe on the
+root.  Every frame must equal the plain single-GPU render of the same pose."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import scene_defs as sd                                          # noqa: E402
+
+rt = importlib.import_module("cuda-raytracing_amd")
+scenes = importlib.import_module("cuda-raytracing_amd.scenes")
+
+
+def main(blob):
+    h = rt.libs()[0]
+    v = C.c_int32(0)
+    rt.check(h.rt_comm_available(C.byref(v)), "rt_comm_available")
+    assert v.value == 99999, "the mock was not loaded"
+    W, H = 322, 203
+    cases = 0
+    for n in (2, 3, 8):
+        replicas = []
+        for _ in range(n):
+            sp = sd.shiny_scene(scenes, blob).build_product(rt)
+            sp.upload_to_device()
+            replicas.append(sp)
+        comms = (C.c_void_p * n)()
+        rt.check(h.rt_comm_init_all((C.c_int32 * n)(*([0] * n)), n, comms), "rt_comm_init_all")
+        scn = (C.c_void_p * n)(*[sp.device_handle for sp in replicas])
+        for r in range(n):
+            rk, nr = C.c_int32(-1), C.c_int32(-1)
+            rt.check(h.rt_comm_info(comms[r], C.byref(rk), C.byref(nr), None))
+            assert (rk.value, nr.value) == (r, n)
+        cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+        for k, (opts, stripe, root) in enumerate([((1, 0, 0), 16, 0), ((1, 0, 0), 7, n - 1), ((4, 2, 1), 16, n // 2), ((1, 0, 0), 64, 0)]):
+            pose = list(sd.SHINY_CAMERA["pose"])
+            pose[0] += 0.05 * k                                   # another frame every time: stale scratch cannot pass
+            cam.set_pose(pose)
+            cam.set_options(*opts)
+            want = rt.render(replicas[0], cam)
+            img = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+            p = cam.params()
+            o = (C.c_int32 * 3)(*opts)
+            rt.check(h.rt_render_tiled_all(scn, comms, n, C.byref(p), o, img.ptr, img.pitch, stripe, root, None, 1), "rt_render_tiled_all")
+            got = img.to_host().reshape(H, W, 3)
+            assert np.array_equal(got, want), (n, opts, stripe, root, int((got != want).any(axis=2).sum()))
+            cases += 1
+        # argument checks of the N-rank form
+        assert h.rt_render_tiled_all(scn, comms, n, C.byref(p), None, img.ptr, img.pitch, 16, n, None, 1) == -1       # no such root
+        assert h.rt_render_tiled_all(scn, comms, n - 1, C.byref(p), None, img.ptr, img.pitch, 16, 0, None, 1) == -1   # not the whole communicator
+        for r in range(n):
+            rt.check(h.rt_comm_destroy(comms[r]))
+    cases += rotating_groups(h, blob)
+    print("OK", cases)
+
+
+def rotating_groups(h, blob):
+    """The rotating-root exchange of a group of frames (bench.py's stream mode with N ranks): every rank renders its stripes of
+    all frames of the group, ONE rt_all_to_all per rank moves frame slot s to its assembling rank, every rank un-stripes the
+    frames it owns.  Plan and buffer layout are tiling.rotating_plan's, as tiling.RcclExchange passes them."""
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    W, H, stripe = 322, 203, 16
+    row = W * 3
+    sz = C.c_size_t
+    cases = 0
+    for n, count in ((2, 4), (3, 5), (8, 3), (4, 1)):
+        comms = (C.c_void_p * n)()
+        rt.check(h.rt_comm_init_all((C.c_int32 * n)(*([0] * n)), n, comms), "rt_comm_init_all")
+        sp = sd.shiny_scene(scenes, blob).build_product(rt)
+        sp.upload_to_device()
+        cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+        max_rows = tiling.stripe_rows(H, stripe, 0, n)
+        slots, counts, offsets, real = tiling.rotating_plan(count, n)
+        poses = []
+        for f in range(count):
+            pose = list(sd.SHINY_CAMERA["pose"])
+            pose[0] += 0.04 * f + 0.01 * n
+            poses.append(pose)
+        local = [rt.DeviceBuffer(nbytes=slots * max_rows * row) for _ in range(n)]
+        received = [rt.DeviceBuffer(nbytes=n * counts[r] * max_rows * row) for r in range(n)]
+        for r in range(n):
+            cam.render_scene_stripes_batch(sp, poses, tiling.batch_local_ptrs(local[r].ptr.value, count, max_rows, row), row, stripe, r, n)
+        rt.check(h.rt_group_start(), "rt_group_start")
+        for r in range(n):
+            rt.check(h.rt_all_to_all(comms[r], local[r].ptr, (sz * n)(*[c * max_rows * row for c in counts]),
+                                     (sz * n)(*[o * max_rows * row for o in offsets]), received[r].ptr,
+                                     (sz * n)(*([counts[r] * max_rows * row] * n)), (sz * n)(*[q * counts[r] * max_rows * row for q in range(n)]), None),
+                     "rt_all_to_all")
+        rt.check(h.rt_group_end(), "rt_group_end")
+        assert sum(real) == count
+        for d in range(n):
+            for j in range(real[d]):
+                src, rank_stride = tiling.batch_unstripe_args(received[d].ptr.value, j, counts[d], max_rows, row)
+                img = rt.DeviceBuffer(width_bytes=row, height=H)
+                rt.check(h.rt_unstripe(src, row, rank_stride, img.ptr, img.pitch, W, H, stripe, n, None), "rt_unstripe")
+                rt.check(h.rt_device_synchronize())
+                cam.set_pose(poses[offsets[d] + j])
+                want = rt.render(sp, cam)
+                got = img.to_host().reshape(H, W, 3)
+                assert np.array_equal(got, want), (n, count, d, j, int((got != want).any(axis=2).sum()))
+        for r in range(n):
+            rt.check(h.rt_comm_destroy(comms[r]))
+        cases += 1
+    return cases
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,7 +1,8 @@
 """The exchange step on a real GPU: the RCCL communicator of the C-ABI (rt_comm_* / rt_gather / rt_all_to_all /
 rt_render_tiled) with the one rank a one-GPU box offers, and the double-buffered frame loop (tiling.StripePipeline) on its
 real streams and events.  More than one RCCL peer needs more than one GPU: the N-rank bookkeeping is covered by the
-virtual-rank tests (test_gpu_parity.py, test_gpu_full_size.py) and by the gloo tests on CPU (test_tiling_gloo.py)."""
+virtual-rank tests (test_gpu_parity.py, test_gpu_full_size.py), by the gloo tests on CPU (test_tiling_gloo.py) and, for
+the single-process form of the C-ABI (rt_render_tiled_all), by N ranks on the one GPU over an in-process mock of RCCL."""
 import ctypes as C
 import importlib
 import os
@@ -180,3 +181,18 @@ def test_cpp_tiled_application(rt, orc, scenes, blob5k, tmp_path):
         ref = so.render_ex(W, H, scenes.scaled_K(W), scenes.D_REF, (0.0, -1.6, 0.2, 0, 0, 0), *opts, threads=16)["img"]
         assert np.array_equal(rt.read_image(png), ref), opts
     so.close()
+
+
+def test_tiled_all_with_several_ranks_over_mock_rccl(blob5k, tmp_path):
+    """rt_comm_init_all + rt_render_tiled_all with 2, 3 and 8 ranks.  Real RCCL refuses two ranks on one device, so the ranks
+    of this test share the box's one GPU and the collective is tests/mock_rccl (device-to-device copies when the group
+    closes), loaded through RT_RCCL_LIBRARY in a child process.  What runs for real is the product's N-rank code: stripes of
+    every rank, scratch sizing, offsets of the gathered blocks, roots other than 0, ragged last stripes, the un-stripe."""
+    mock = str(tmp_path / "librccl_mock.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", mock, os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")],
+                   check=True, timeout=600)
+    env = dict(os.environ, RT_RCCL_LIBRARY=mock)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "tiled_all_ranks.py"), blob5k], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.strip().splitlines()[-1] == "OK 16"
