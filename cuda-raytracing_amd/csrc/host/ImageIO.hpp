@@ -3,9 +3,10 @@
 // The reference decodes textures with cv::imread (Material.hpp:29-43) and ends every frame with
 // display_image() (kernel.cu:30-43): download, "FPS: ..." overlay with cv::putText, cv::imwrite("out.png").
 // This image has no OpenCV, so the decoders and the overlay are written here:
-//   * PNG reader: zlib inflate (stored / fixed / dynamic Huffman blocks), 8-bit grey, grey+alpha, RGB, RGBA and
-//     palette images, non-interlaced; lossless, so its pixels are pinned by any other PNG decoder (tests: Pillow).
-//   * baseline JPEG reader: see read_jpeg_bgr.
+//   * PNG reader: zlib inflate (stored / fixed / dynamic Huffman blocks); grey, grey+alpha, RGB, RGBA and palette images
+//     of every legal depth, plain or Adam7-interlaced; lossless, so its pixels are pinned by any other PNG decoder
+//     (tests: Pillow).
+//   * JPEG reader (sequential and progressive): see read_jpeg_bgr.
 //   * text overlay with a built-in 5x7 font (cv::putText draws Hershey strokes; glyph shapes are NOT reproduced,
 //     only position, colour and content of the overlay).
 // All pixel buffers are B,G,R like cv::Mat.

@@ -1,4 +1,4 @@
-// rt_image_io.cpp -- PNG / PPM / baseline-JPEG readers, text overlay, display_image and the interaction handlers
+// rt_image_io.cpp -- PNG (plain and interlaced) / PPM / JPEG (sequential and progressive) readers, text overlay, display_image and the interaction handlers
 // (ImageIO.hpp).  Host-only; nothing here is on the raycast path.
 #include "ImageIO.hpp"
 
@@ -256,7 +256,7 @@ bool read_png_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& width
         pos += 12 + (size_t)len;
     }
     if (ctype < 0 || !seen_end || w == 0 || h == 0 || w > 32768 || h > 32768) return fail(error, "incomplete PNG");
-    if (interlace != 0) return fail(error, "interlaced PNG is not supported");
+    if (interlace != 0 && interlace != 1) return fail(error, "unknown PNG interlace method");
     int channels;
     switch (ctype) {
         case 0: channels = 1; break;
@@ -271,57 +271,83 @@ bool read_png_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& width
                           ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
     if (!depth_ok) return fail(error, "invalid PNG bit depth");
     if (ctype == 3 && (palette.empty() || palette.size() % 3)) return fail(error, "palette PNG without PLTE");
-    std::vector<uint8_t> raw;
-    const size_t row_bytes = ((size_t)w * channels * depth + 7) / 8;
-    if (!zlib_inflate(idat.data(), idat.size(), raw, error, (size_t)h * (row_bytes + 1))) return false;   // no more than IHDR announces
-    if (raw.size() < (size_t)h * (row_bytes + 1)) return fail(error, "PNG image data too short");
-    const int bpp = std::max(1, channels * depth / 8);          // filter distance in bytes
-    // undo the scanline filters in place (PNG spec 9.2)
-    for (uint32_t y = 0; y < h; y++) {
-        uint8_t* cur = &raw[(size_t)y * (row_bytes + 1)];
-        const uint8_t* up = y ? cur - (row_bytes + 1) + 1 : nullptr;
-        const int ft = *cur++;
-        for (size_t i = 0; i < row_bytes; i++) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
-            int v = cur[i];
-            switch (ft) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: v += paeth(a, b, c); break;
-                default: return fail(error, "unknown PNG filter type");
-            }
-            cur[i] = (uint8_t)v;
-        }
+    // the image is one pass of every pixel, or the seven reduced images of Adam7 (PNG spec 8.2) one after another in the stream:
+    // pass k holds the pixels (x0 + i * dx, y0 + j * dy), each pass filtered on its own
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const Pass* passes = interlace ? adam7 : &whole;
+    const int num_passes = interlace ? 7 : 1;
+    auto pass_size = [&](const Pass& ps, uint32_t& pw, uint32_t& ph, size_t& row_bytes) {
+        pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0;
+        ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+        row_bytes = ((size_t)pw * channels * depth + 7) / 8;
+    };
+    size_t total = 0;
+    for (int k = 0; k < num_passes; k++) {
+        uint32_t pw, ph; size_t rb;
+        pass_size(passes[k], pw, ph, rb);
+        if (pw && ph) total += (size_t)ph * (rb + 1);
     }
-    // to B,G,R the way cv::imread(IMREAD_COLOR) does through libpng: 16-bit samples keep their high byte, low-depth
-    // grey is scaled to 0..255, palette entries are looked up, alpha is dropped
+    std::vector<uint8_t> raw;
+    if (!zlib_inflate(idat.data(), idat.size(), raw, error, total)) return false;                         // no more than IHDR announces
+    if (raw.size() < total) return fail(error, "PNG image data too short");
+    const int bpp = std::max(1, channels * depth / 8);          // filter distance in bytes
     std::vector<uint8_t> out((size_t)w * h * 3);
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t* row = &raw[(size_t)y * (row_bytes + 1) + 1];
-        uint8_t* o = &out[(size_t)y * w * 3];
-        auto sample = [&](size_t index) -> int {                // index-th sample of the row, as stored
-            if (depth == 8) return row[index];
-            if (depth == 16) return row[2 * index];
-            const int per = 8 / depth;
-            return (row[index / per] >> ((per - 1 - (int)(index % per)) * depth)) & ((1 << depth) - 1);
-        };
-        for (uint32_t x = 0; x < w; x++) {
-            int r, g, b;
-            if (ctype == 0 || ctype == 4) {
-                int v = sample((size_t)x * channels);
-                if (depth < 8) v = v * 255 / ((1 << depth) - 1);
-                r = g = b = v;
-            } else if (ctype == 3) {
-                const size_t e = (size_t)sample(x) * 3;
-                if (e + 2 >= palette.size()) return fail(error, "palette index out of range");
-                r = palette[e]; g = palette[e + 1]; b = palette[e + 2];
-            } else {
-                r = sample((size_t)x * channels); g = sample((size_t)x * channels + 1); b = sample((size_t)x * channels + 2);
+    size_t base = 0;
+    for (int k = 0; k < num_passes; k++) {
+        const Pass& ps = passes[k];
+        uint32_t pw, ph; size_t row_bytes;
+        pass_size(ps, pw, ph, row_bytes);
+        if (!pw || !ph) continue;
+        // undo the scanline filters in place (PNG spec 9.2)
+        for (uint32_t y = 0; y < ph; y++) {
+            uint8_t* cur = &raw[base + (size_t)y * (row_bytes + 1)];
+            const uint8_t* up = y ? cur - (row_bytes + 1) + 1 : nullptr;
+            const int ft = *cur++;
+            for (size_t i = 0; i < row_bytes; i++) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+                int v = cur[i];
+                switch (ft) {
+                    case 0: break;
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) >> 1; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: return fail(error, "unknown PNG filter type");
+                }
+                cur[i] = (uint8_t)v;
             }
-            o[3 * x] = (uint8_t)b; o[3 * x + 1] = (uint8_t)g; o[3 * x + 2] = (uint8_t)r;
         }
+        // to B,G,R the way cv::imread(IMREAD_COLOR) does through libpng: 16-bit samples keep their high byte, low-depth
+        // grey is scaled to 0..255, palette entries are looked up, alpha is dropped
+        for (uint32_t y = 0; y < ph; y++) {
+            const uint8_t* row = &raw[base + (size_t)y * (row_bytes + 1) + 1];
+            uint8_t* orow = &out[(size_t)(ps.y0 + y * ps.dy) * w * 3];
+            auto sample = [&](size_t index) -> int {            // index-th sample of the row, as stored
+                if (depth == 8) return row[index];
+                if (depth == 16) return row[2 * index];
+                const int per = 8 / depth;
+                return (row[index / per] >> ((per - 1 - (int)(index % per)) * depth)) & ((1 << depth) - 1);
+            };
+            for (uint32_t x = 0; x < pw; x++) {
+                int r, g, b;
+                if (ctype == 0 || ctype == 4) {
+                    int v = sample((size_t)x * channels);
+                    if (depth < 8) v = v * 255 / ((1 << depth) - 1);
+                    r = g = b = v;
+                } else if (ctype == 3) {
+                    const size_t e = (size_t)sample(x) * 3;
+                    if (e + 2 >= palette.size()) return fail(error, "palette index out of range");
+                    r = palette[e]; g = palette[e + 1]; b = palette[e + 2];
+                } else {
+                    r = sample((size_t)x * channels); g = sample((size_t)x * channels + 1); b = sample((size_t)x * channels + 2);
+                }
+                uint8_t* o = orow + (size_t)(ps.x0 + x * ps.dx) * 3;
+                o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
+            }
+        }
+        base += (size_t)ph * (row_bytes + 1);
     }
     bgr.swap(out);
     width = (int)w; height = (int)h;
@@ -488,15 +514,19 @@ int display_image(const uchar3* d_img, int width, int height, size_t pitch, doub
 
 // ------------------------------------------------------------------------------------------------------------ JPEG
 //
-// Baseline sequential JPEG (SOF0 / SOF1 8-bit, Huffman; grey or Y'CbCr with 4:4:4, 4:2:2 or 4:2:0 chroma; restart
-// intervals).  The reference decodes with cv::imread, i.e. libjpeg with its default settings; a lossy format is only
+// Sequential and progressive JPEG (SOF0 / SOF1 / SOF2, 8-bit, Huffman; grey or Y'CbCr with 4:4:4, 4:2:2 or 4:2:0 chroma;
+// any number of scans, interleaved or not; restart intervals).  Every scan decodes into per-component coefficient arrays
+// (progressive: spectral selection and successive approximation as in jdphuff.c, ITU T.81 annex G); after the last scan
+// the blocks are dequantised and transformed.  libjpeg smooths blocks only while a progressive file is incomplete, and an
+// incomplete file is refused here, so complete files need no smoothing to match it.
+// The reference decodes with cv::imread, i.e. libjpeg with its default settings; a lossy format is only
 // "the same texture" if the decoder reproduces that arithmetic, so every stage restates libjpeg's defaults
 // (third-party, not in the reference tree; libjpeg 6b / libjpeg-turbo):
 //   * inverse DCT: the "slow but accurate" integer transform (jidctint.c: 13-bit constants, 2 extra bits after pass 1);
 //   * chroma upsampling: "fancy" triangle filters (jdsample.c: h2v1 3/4-1/4 horizontally, h2v2 9-3-3-1);
 //   * colour: 16-bit fixed-point Y'CbCr -> RGB (jdcolor.c).
 // tests/test_host_logic.py pins the output to Pillow's decoder (libjpeg-turbo, same defaults) bit for bit.
-// Progressive, arithmetic-coded, 12-bit, CMYK and other sampling layouts are refused.
+// Arithmetic-coded, lossless, 12-bit, CMYK and other sampling layouts are refused.
 
 namespace {
 
@@ -514,6 +544,9 @@ struct JpegComponent {
     int dc_pred = 0;
     int bw = 0, bh = 0;                 // blocks per row / column as stored (padded to whole MCUs)
     int dw = 0, dh = 0;                 // downsampled size in samples: ceil(image * h / hmax)
+    bool q_latched = false;
+    uint16_t q[64];                     // the quantisation table as it stood at the component's first scan (what libjpeg latches)
+    std::vector<int16_t> coef;          // bw*bh blocks of 64 coefficients, natural order
     std::vector<uint8_t> plane;         // bw*8 x bh*8 samples
 };
 
@@ -570,7 +603,7 @@ void idct_islow(const int* in, uint8_t* out, int stride)
             long z1 = (z2 + z3) * F_0_541;
             long tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
             z2 = c[0]; z3 = c[4];
-            long tmp0 = (z2 + z3) << CONST_BITS, tmp1 = (z2 - z3) << CONST_BITS;
+            long tmp0 = (z2 + z3) * (1L << CONST_BITS), tmp1 = (z2 - z3) * (1L << CONST_BITS);
             const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
             tmp0 = c[7]; tmp1 = c[5]; tmp2 = c[3]; tmp3 = c[1];
             z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
@@ -607,14 +640,15 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
     JpegHuff hdc[4], hac[4];
     std::vector<JpegComponent> comps;
     int W = 0, H = 0, restart_interval = 0, hmax = 1, vmax = 1;
-    bool have_frame = false, decoded = false;
+    int mcux = 0, mcuy = 0, scans = 0;
+    bool have_frame = false, progressive = false, saw_eoi = false;
     size_t pos = 2;
-    while (pos + 4 <= d.size() && !decoded) {
+    while (pos + 2 <= d.size()) {
         if (d[pos] != 0xFF) return fail(error, "JPEG marker expected");
         while (pos < d.size() && d[pos] == 0xFF) pos++;         // fill bytes
         if (pos >= d.size()) break;
         const int marker = d[pos++];
-        if (marker == 0xD9) break;                              // EOI
+        if (marker == 0xD9) { saw_eoi = true; break; }          // EOI
         if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;
         if (pos + 2 > d.size()) return fail(error, "truncated JPEG");
         const size_t len = be16(&d[pos]);
@@ -650,9 +684,10 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
                 h.present = true;
                 i += 17 + total;
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {          // SOF0 / SOF1: baseline / extended sequential, Huffman
+        } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {   // SOF0 / SOF1 / SOF2: baseline, extended sequential, progressive (Huffman)
             if (have_frame) return fail(error, "JPEG with more than one frame header");   // (a stale hmax / vmax would size the planes wrongly)
             if (n < 6 || s[0] != 8) return fail(error, "only 8-bit JPEG is supported");
+            progressive = marker == 0xC2;
             hmax = vmax = 1;
             H = be16(&s[1]); W = be16(&s[3]);
             const int nc = s[5];
@@ -662,6 +697,7 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
             for (int c = 0; c < nc; c++) {
                 comps[c].id = s[6 + 3 * c]; comps[c].h = s[7 + 3 * c] >> 4; comps[c].v = s[7 + 3 * c] & 15; comps[c].tq = s[8 + 3 * c];
                 if (comps[c].h < 1 || comps[c].v < 1 || comps[c].tq > 3) return fail(error, "bad JPEG component");
+                for (int k = 0; k < c; k++) if (comps[k].id == comps[c].id) return fail(error, "bad JPEG component");
                 hmax = std::max(hmax, comps[c].h); vmax = std::max(vmax, comps[c].v);
             }
             if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }       // a single component is never interleaved
@@ -670,76 +706,179 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
                 const bool luma_ok = (comps[0].h == 1 && comps[0].v == 1) || (comps[0].h == 2 && comps[0].v == 1) || (comps[0].h == 2 && comps[0].v == 2);
                 if (!chroma_ok || !luma_ok) return fail(error, "unsupported JPEG chroma subsampling (4:4:4, 4:2:2, 4:2:0 only)");
             }
-            have_frame = true;
-        } else if (marker == 0xC2 || (marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC)) {
-            return fail(error, "progressive / lossless / arithmetic JPEG is not supported");
-        } else if (marker == 0xDD) {                            // DRI
-            if (n < 2) return fail(error, "bad DRI");
-            restart_interval = be16(s);
-        } else if (marker == 0xDA) {                            // SOS: the one scan of a baseline file
-            if (!have_frame) return fail(error, "JPEG scan before frame header");
-            if (n < 1) return fail(error, "bad SOS");
-            const int ns = s[0];
-            if (ns != (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail(error, "multi-scan JPEG is not supported");
-            for (int k = 0; k < ns; k++) {
-                JpegComponent* c = nullptr;
-                for (auto& cc : comps) if (cc.id == s[1 + 2 * k]) c = &cc;
-                if (!c || c != &comps[k]) return fail(error, "unexpected JPEG scan component order");
-                c->td = s[2 + 2 * k] >> 4; c->ta = s[2 + 2 * k] & 15;
-                if (c->td > 3 || c->ta > 3 || !hdc[c->td].present || !hac[c->ta].present || !have_qt[c->tq]) return fail(error, "JPEG scan refers to a missing table");
-            }
-            const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+            mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
             for (auto& c : comps) {
                 c.bw = mcux * c.h; c.bh = mcuy * c.v;
                 c.dw = (W * c.h + hmax - 1) / hmax; c.dh = (H * c.v + vmax - 1) / vmax;
-                c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+                c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+            }
+            have_frame = true;
+        } else if (marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {
+            return fail(error, "lossless / hierarchical / arithmetic JPEG is not supported");
+        } else if (marker == 0xDD) {                            // DRI
+            if (n < 2) return fail(error, "bad DRI");
+            restart_interval = be16(s);
+        } else if (marker == 0xDA) {                            // SOS: one scan (baseline files usually hold one, progressive files several)
+            if (!have_frame) return fail(error, "JPEG scan before frame header");
+            if (n < 1) return fail(error, "bad SOS");
+            const int ns = s[0];
+            if (ns < 1 || ns > (int)comps.size() || n < 1 + 2 * (size_t)ns + 3) return fail(error, "bad SOS");
+            JpegComponent* sc[3];
+            for (int k = 0; k < ns; k++) {
+                JpegComponent* c = nullptr;
+                for (auto& cc : comps) if (cc.id == s[1 + 2 * k]) c = &cc;
+                if (!c || (k && c <= sc[k - 1])) return fail(error, "unexpected JPEG scan component order");
+                c->td = s[2 + 2 * k] >> 4; c->ta = s[2 + 2 * k] & 15;
+                if (c->td > 3 || c->ta > 3) return fail(error, "JPEG scan refers to a missing table");
+                sc[k] = c;
+            }
+            const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+            if (progressive) {
+                // T.81 G.1.1.1: a DC scan (Ss = Se = 0) may interleave, an AC scan (1 <= Ss <= Se <= 63) holds one component;
+                // a refinement scan improves the previous scan's precision by exactly one bit
+                const bool ok = Ss <= Se && Se <= 63 && (Ss == 0 ? Se == 0 : ns == 1) && Al <= 13 && (Ah == 0 || Ah == Al + 1);
+                if (!ok) return fail(error, "invalid progressive JPEG scan parameters");
+            } else if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return fail(error, "invalid sequential JPEG scan parameters");
+            const bool need_dc = Ss == 0 && Ah == 0, need_ac = Se > 0;      // (a DC refinement scan reads raw bits only)
+            for (int k = 0; k < ns; k++) {
+                JpegComponent& c = *sc[k];
+                if ((need_dc && !hdc[c.td].present) || (need_ac && !hac[c.ta].present) || !have_qt[c.tq]) return fail(error, "JPEG scan refers to a missing table");
+                if (!c.q_latched) { memcpy(c.q, qt[c.tq], sizeof c.q); c.q_latched = true; }
                 c.dc_pred = 0;
             }
+            // an interleaved scan walks MCUs (h x v blocks of every component); a one-component scan walks that component's
+            // blocks in raster order over its real size, ceil(samples / 8) -- not the size padded to whole MCUs (T.81 A.2.2)
+            const bool interleaved = ns > 1;
+            const int ux = interleaved ? mcux : (sc[0]->dw + 7) / 8, uy = interleaved ? mcuy : (sc[0]->dh + 7) / 8;
             JpegBits br{d.data(), d.size(), pos + len};
-            int until_restart = restart_interval, next_rst = 0;
-            for (int my = 0; my < mcuy; my++)
-                for (int mx = 0; mx < mcux; mx++) {
+            int until_restart = restart_interval, next_rst = 0, eobrun = 0;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
+            auto refine = [&](int16_t& v) {                    // one correction bit for a coefficient that is already non-zero
+                if (br.bit() && (v & p1) == 0) v = (int16_t)(v >= 0 ? v + p1 : v + m1);
+            };
+            for (int my = 0; my < uy; my++)
+                for (int mx = 0; mx < ux; mx++) {
                     if (restart_interval && until_restart == 0) {
                         br.reset();
                         if (br.pos + 2 > br.n || br.p[br.pos] != 0xFF || br.p[br.pos + 1] != 0xD0 + next_rst) return fail(error, "JPEG restart marker missing");
                         br.pos += 2;
                         next_rst = (next_rst + 1) & 7;
                         until_restart = restart_interval;
-                        for (auto& c : comps) c.dc_pred = 0;
+                        eobrun = 0;
+                        for (int k = 0; k < ns; k++) sc[k]->dc_pred = 0;
                     }
-                    for (auto& c : comps)
-                        for (int by = 0; by < c.v; by++)
-                            for (int bx = 0; bx < c.h; bx++) {
-                                int coef[64];
-                                memset(coef, 0, sizeof coef);
-                                int t = jpeg_decode_huff(br, hdc[c.td]);
-                                if (t < 0 || t > 11) return fail(error, "corrupt JPEG data");
-                                if (t) c.dc_pred += jpeg_extend(br.receive(t), t);
-                                coef[0] = c.dc_pred * qt[c.tq][0];
-                                for (int k = 1; k < 64;) {
-                                    const int rs = jpeg_decode_huff(br, hac[c.ta]);
-                                    if (rs < 0) return fail(error, "corrupt JPEG data");
-                                    const int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) {
-                                        if (r == 15) { k += 16; continue; }
-                                        break;                              // end of block
+                    for (int ci = 0; ci < ns; ci++) {
+                        JpegComponent& c = *sc[ci];
+                        const int nbx = interleaved ? c.h : 1, nby = interleaved ? c.v : 1;
+                        for (int by = 0; by < nby; by++)
+                            for (int bx = 0; bx < nbx; bx++) {
+                                const int gx = interleaved ? mx * c.h + bx : mx, gy = interleaved ? my * c.v + by : my;
+                                int16_t* blk = &c.coef[((size_t)gy * c.bw + gx) * 64];
+                                if (Ss == 0) {
+                                    if (Ah == 0) {                          // DC, first (or only) pass
+                                        const int t = jpeg_decode_huff(br, hdc[c.td]);
+                                        if (t < 0 || t > 11) return fail(error, "corrupt JPEG data");
+                                        if (t) c.dc_pred += jpeg_extend(br.receive(t), t);
+                                        blk[0] = (int16_t)(c.dc_pred * p1);
+                                    } else if (br.bit()) blk[0] = (int16_t)(blk[0] | p1);   // DC refinement: one more bit
+                                }
+                                if (!progressive) {                         // sequential: the 63 AC coefficients follow at once
+                                    for (int k = 1; k < 64;) {
+                                        const int rs = jpeg_decode_huff(br, hac[c.ta]);
+                                        if (rs < 0) return fail(error, "corrupt JPEG data");
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz == 0) {
+                                            if (r == 15) { k += 16; continue; }
+                                            break;                          // end of block
+                                        }
+                                        k += r;
+                                        if (k > 63) return fail(error, "corrupt JPEG data");
+                                        blk[kZigzag[k]] = (int16_t)jpeg_extend(br.receive(sz), sz);
+                                        k++;
                                     }
-                                    k += r;
-                                    if (k > 63) return fail(error, "corrupt JPEG data");
-                                    coef[kZigzag[k]] = jpeg_extend(br.receive(sz), sz) * qt[c.tq][kZigzag[k]];
-                                    k++;
+                                } else if (Ss > 0 && Ah == 0) {             // AC band, first pass (jdphuff.c decode_mcu_AC_first)
+                                    if (eobrun > 0) eobrun--;
+                                    else
+                                        for (int k = Ss; k <= Se; k++) {
+                                            const int rs = jpeg_decode_huff(br, hac[c.ta]);
+                                            if (rs < 0) return fail(error, "corrupt JPEG data");
+                                            const int r = rs >> 4, sz = rs & 15;
+                                            if (sz) {
+                                                k += r;
+                                                if (k > Se) return fail(error, "corrupt JPEG data");
+                                                blk[kZigzag[k]] = (int16_t)(jpeg_extend(br.receive(sz), sz) * p1);
+                                            } else if (r == 15) k += 15;
+                                            else {                          // EOBr: this band ends here in this block and in the next eobrun blocks
+                                                eobrun = (1 << r) - 1;
+                                                if (r) eobrun += br.receive(r);
+                                                break;
+                                            }
+                                        }
+                                } else if (Ss > 0) {                        // AC band, refinement (decode_mcu_AC_refine)
+                                    int k = Ss;
+                                    if (eobrun == 0)
+                                        for (; k <= Se; k++) {
+                                            const int rs = jpeg_decode_huff(br, hac[c.ta]);
+                                            if (rs < 0) return fail(error, "corrupt JPEG data");
+                                            int r = rs >> 4, sz = rs & 15, value = 0;
+                                            if (sz) {
+                                                if (sz != 1) return fail(error, "corrupt JPEG data");
+                                                value = br.bit() ? p1 : m1;                 // a coefficient that becomes non-zero in this pass
+                                            } else if (r != 15) {
+                                                eobrun = 1 << r;
+                                                if (r) eobrun += br.receive(r);
+                                                break;
+                                            }
+                                            // pass r coefficients that are still zero; every non-zero one on the way takes a correction bit
+                                            for (; k <= Se; k++) {
+                                                int16_t& v = blk[kZigzag[k]];
+                                                if (v != 0) refine(v);
+                                                else if (--r < 0) break;
+                                            }
+                                            if (value) {
+                                                if (k > Se) return fail(error, "corrupt JPEG data");
+                                                blk[kZigzag[k]] = (int16_t)value;
+                                            }
+                                        }
+                                    if (eobrun > 0) {
+                                        for (; k <= Se; k++) {
+                                            int16_t& v = blk[kZigzag[k]];
+                                            if (v != 0) refine(v);
+                                        }
+                                        eobrun--;
+                                    }
                                 }
                                 if (br.bad) return fail(error, "truncated JPEG data");
-                                const int px = (mx * c.h + bx) * 8, py = (my * c.v + by) * 8;
-                                idct_islow(coef, &c.plane[(size_t)py * c.bw * 8 + px], c.bw * 8);
                             }
+                    }
                     if (restart_interval) until_restart--;
                 }
-            decoded = true;
+            scans++;
+            // the next marker follows the entropy-coded bytes (pad bits of the last byte are dropped)
+            size_t q = br.pos;
+            while (q + 1 < d.size() && !(d[q] == 0xFF && d[q + 1] != 0x00 && d[q + 1] != 0xFF && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7))) q++;
+            pos = q;
+            continue;
         }
         pos += len;
     }
-    if (!decoded) return fail(error, "JPEG without image data");
+    if (!scans) return fail(error, "JPEG without image data");
+    // every component needs its coefficients: a sequential file one scan per component, a progressive file at least the DC scan
+    // (libjpeg would show an incomplete progressive file smoothed; such a file is refused here rather than shown differently)
+    for (auto& c : comps) if (!c.q_latched) return fail(error, "JPEG component without a scan");
+    if (progressive && !saw_eoi) return fail(error, "incomplete progressive JPEG");
+    // dequantise + inverse DCT (jddctmgr.c / jidctint.c), block by block
+    for (auto& c : comps) {
+        c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+        for (int gy = 0; gy < c.bh; gy++)
+            for (int gx = 0; gx < c.bw; gx++) {
+                const int16_t* blk = &c.coef[((size_t)gy * c.bw + gx) * 64];
+                int deq[64];
+                for (int k = 0; k < 64; k++) deq[k] = blk[k] * c.q[k];
+                idct_islow(deq, &c.plane[(size_t)gy * 8 * c.bw * 8 + (size_t)gx * 8], c.bw * 8);
+            }
+        std::vector<int16_t>().swap(c.coef);
+    }
 
     std::vector<uint8_t> out((size_t)W * H * 3);
     if (comps.size() == 1) {

@@ -351,17 +351,17 @@ def test_scene_upload_validates_its_input(rt, blob5k):
 # ---------------------------------------------------------------- image files, overlay, interaction
 
 def test_image_decoders_match_committed_fixtures(rt):
-    """PNG (all colour types Pillow writes, 1/8/16 bit) and baseline JPEG (4:4:4, 4:2:2, 4:2:0, grey, custom Huffman
-    tables, restart intervals, 1x1) decode to exactly the bytes libpng / libjpeg-turbo produce
-    (tests/golden/make_image_fixtures.py); progressive JPEG is refused."""
+    """PNG (all colour types, 1/2/4/8/16 bit, plain and Adam7-interlaced) and JPEG (baseline and progressive; 4:4:4, 4:2:2,
+    4:2:0, grey, custom Huffman tables, restart intervals, 1x1) decode to exactly the bytes libpng / libjpeg-turbo produce
+    (tests/golden/make_image_fixtures.py); a progressive file cut before its last scan is refused."""
     d = os.path.join(GOLDEN, "images")
     exp = np.load(os.path.join(d, "images_expected.npz"))
-    assert len(exp.files) >= 14
+    assert len(exp.files) >= 29 and sum(n.startswith("jpg_prog") for n in exp.files) >= 7 and sum(n.startswith("png_adam7") for n in exp.files) >= 8
     for name in exp.files:
         got = rt.read_image(os.path.join(d, name))
         assert got.shape == exp[name].shape and np.array_equal(got, exp[name]), name
-    with pytest.raises(rt.RtError, match="progressive"):
-        rt.read_image(os.path.join(d, "refused_progressive.jpg"))
+    with pytest.raises(rt.RtError, match="incomplete progressive"):
+        rt.read_image(os.path.join(d, "refused_progressive_cut.jpg"))
     with pytest.raises(rt.RtError):
         rt.read_image(os.path.join(d, "images_expected.npz"))
 
@@ -376,9 +376,45 @@ def test_image_decoders_against_pillow_live(rt, tmp_path):
             p = str(tmp_path / ("a%d_%d.jpg" % (k, ss)))
             Image.fromarray(rgb).save(p, quality=40 + 20 * ss, subsampling=ss)
             assert np.array_equal(rt.read_image(p), np.asarray(Image.open(p).convert("RGB"))[..., ::-1]), (w, h, ss)
+            p = str(tmp_path / ("p%d_%d.jpg" % (k, ss)))
+            Image.fromarray(rgb).save(p, quality=30 + 30 * ss, subsampling=ss, progressive=True, optimize=bool(k & 1))
+            assert np.array_equal(rt.read_image(p), np.asarray(Image.open(p).convert("RGB"))[..., ::-1]), ("progressive", w, h, ss)
         p = str(tmp_path / ("a%d.png" % k))
         Image.fromarray(rgb).save(p, compress_level=k * 3)               # level 0 = stored blocks, 9 = dynamic Huffman
         assert np.array_equal(rt.read_image(p), rgb[..., ::-1])
+
+
+def test_corrupted_image_files_never_crash(rt, tmp_path):
+    """Byte flips, truncations and spliced garbage in every fixture: the decoders either decode something of the announced
+    size or refuse with an RtError -- never a crash, a hang or an allocation beyond the caps."""
+    d = os.path.join(GOLDEN, "images")
+    rng = np.random.default_rng(77)
+    names = [n for n in sorted(os.listdir(d)) if n.endswith((".png", ".jpg"))]
+    tried = refused = 0
+    for name in names:
+        data = open(os.path.join(d, name), "rb").read()
+        for k in range(12):
+            b = bytearray(data)
+            mode = k % 3
+            if mode == 0:                                              # a few flipped bytes past the signature
+                for _ in range(1 + k // 3):
+                    b[int(rng.integers(2, len(b)))] ^= int(rng.integers(1, 256))
+            elif mode == 1:                                            # truncated
+                b = b[:int(rng.integers(4, len(b)))]
+            else:                                                      # a run of bytes overwritten with 0xFF / 0x00 / noise
+                i = int(rng.integers(2, len(b) - 1))
+                n = int(rng.integers(1, 24))
+                b[i:i + n] = bytes(rng.integers(0, 256, n, dtype=np.uint8)) if k % 2 else b"\xff" * n
+            p = str(tmp_path / ("c_%d_%s" % (k, name)))
+            open(p, "wb").write(bytes(b))
+            tried += 1
+            try:
+                img = rt.read_image(p)
+                assert img.ndim == 3 and img.shape[2] == 3 and img.size <= 3 << 28
+            except rt.RtError:
+                refused += 1
+            os.remove(p)
+    assert tried >= 300 and refused > tried // 4
 
 
 def test_zlib_inflate_against_zlib(rt):
@@ -449,8 +485,10 @@ def test_texture_from_png_and_jpeg(rt, tmp_path):
     sc = rt.Scene()
     for name in ("png_RGB.png", "jpg_420_q75.jpg"):
         sc.add_material((1, 1, 1), texture_path=os.path.join(d, name))
+    for name in ("jpg_prog_420_q75.jpg", "png_adam7_RGB.png"):
+        sc.add_material((1, 1, 1), texture_path=os.path.join(d, name))
     with pytest.raises(rt.RtError):
-        sc.add_material((1, 1, 1), texture_path=os.path.join(d, "refused_progressive.jpg"))
+        sc.add_material((1, 1, 1), texture_path=os.path.join(d, "refused_progressive_cut.jpg"))
 
 
 def test_overlay_text(rt):
