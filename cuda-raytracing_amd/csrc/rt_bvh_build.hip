@@ -6,12 +6,13 @@
 // node numbering -- so a mesh built here is interchangeable with one built by the host builder (csrc/host).
 //
 // The reference recurses node by node on the CPU (1.7 s for 70 k triangles); here the tree grows one LEVEL per step,
-// all nodes of the level in parallel, and the level loop runs entirely on the device: the host enqueues the same
-// launches for every level up to the depth limit without ever reading anything back (where a level starts and ends is
-// device state; past the last level the launches find an empty level and return).  Per level (four launches up to 1 M
-// triangles):
-//   bins     : one thread per triangle and axis, atomics into 6 bins x 3 axes (box + count) of its node -- a plane's left
-//              side is the union of the bins below it, exactly the partition `centroid <= pos` of BVHTree.hpp:339
+// all nodes of the level in parallel, while nodes hold more than a wave of triangles; every subtree of at most 64
+// triangles is then finished by one wave on its own (small_subtree_kernel), all of them in one launch.  Where a level
+// starts and ends is device state, so the host enqueues levels without waiting and asks only from time to time whether any
+// large node is left.  Per level (four launches up to 1 M triangles):
+//   bins     : one thread per triangle, 6 bins x 3 axes (box + count) per node, collected in LDS per block and added to the
+//              node's bins once -- a plane's left side is the union of the bins below it, exactly the partition
+//              `centroid <= pos` of BVHTree.hpp:339
 //   decide   : one thread per node evaluates the 15 costs with the host builder's fp32 operations, picks axis / plane and
 //              creates the two children: sizes from the bin counts, BOXES from the bin boxes (the union of the boxes of
 //              a set of triangles is the same whichever way it is folded, so no per-level bounds pass is needed)
@@ -63,7 +64,10 @@ struct BuildState {
     int32_t bins_used[2];           // bin slots handed out for the level being created (parity of that level)
     int32_t levels;                 // non-empty levels
     int32_t overflow;               // set when the node array or the level table would overflow (cannot happen for a valid cap)
+    int32_t num_small;              // nodes of at most kSmall triangles handed to small_subtree_kernel (listed in small_roots[])
 };
+
+constexpr int kSmall = 64;                                       // a subtree of up to one wave of triangles is finished by one wave
 
 // Float min/max through integer atomics: non-negative floats order like ints, negative ones like reversed unsigned
 // ints.  -0.0 has the bit pattern of INT_MIN and would break both orders, so zeros are canonicalised to +0.0 first
@@ -95,7 +99,7 @@ __device__ __forceinline__ void clear_bins(Bins& b)
 // per-triangle centroid (TrianglePrimitive::center, TrianglePrimitive.hpp:81-83) and box; block 0 also sets up the root
 __global__ void prep_kernel(const float* __restrict__ v, int n, int max_depth, float* __restrict__ centroid, float* __restrict__ tbox,
                             int32_t* __restrict__ order, int32_t* __restrict__ node_of, BuildNode* nodes, Bins* bins, BuildState* st,
-                            int32_t* __restrict__ end_hist)
+                            int32_t* __restrict__ end_hist, int32_t* __restrict__ small_roots, int small_limit)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -103,9 +107,11 @@ __global__ void prep_kernel(const float* __restrict__ v, int n, int max_depth, f
         for (int c = 0; c < 3; c++) { r.mn[c] = FLT_MAX; r.mx[c] = -FLT_MAX; }
         r.first = 0; r.count = n; r.depth = 1; r.child_a = r.child_b = -1; r.axis = 0; r.split_pos = 0.0f; r.nl = 0;
         r.bin = (1 >= max_depth || n <= 1) ? -1 : 0;             // BVHTree.hpp:211-215
+        st->num_small = 0;
+        if (r.bin == 0 && n <= small_limit) { r.bin = -1; small_roots[0] = 0; st->num_small = 1; }     // the whole mesh fits one wave
         if (r.bin == 0) clear_bins(bins[0]);
         for (int l = 0; l < kMaxLevels + 2; l++) st->begin[l] = l == 0 ? 0 : 1;
-        st->total = 1; st->bins_used[0] = 1; st->bins_used[1] = 0; st->levels = 1; st->overflow = 0;
+        st->total = 1; st->bins_used[0] = r.bin == 0 ? 1 : 0; st->bins_used[1] = 0; st->levels = 1; st->overflow = 0;
     }
     if (i <= n) end_hist[i] = 0;
     if (i >= n) return;
@@ -149,91 +155,87 @@ __device__ __forceinline__ float plane_pos(float mn, float mx, int s)
     return mn + (mx - mn) * (split_t);                           // BVHTree.hpp:318
 }
 
+// order-preserving integer image of a float (what integer min / max atomics in LDS work on)
+__device__ __forceinline__ int ordered_int(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float ordered_float(int v) { return __int_as_float(v >= 0 ? v : v ^ 0x7fffffff); }
+constexpr int kOrderedMax = 0x7f7fffff, kOrderedLowest = (int)0x80800000;      // ordered_int(FLT_MAX), ordered_int(-FLT_MAX)
+
 // evaluate_split's partition (BVHTree.hpp:324-348), binned: bin = number of planes the centroid lies beyond.
-// When the whole wave works on one node (always, near the root: ranges are contiguous) it reduces first and issues one
-// set of atomics per bin instead of 64 on the same addresses.
-__global__ void bins_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
-                            const float* __restrict__ centroid, const float* __restrict__ tbox,
-                            const BuildNode* __restrict__ nodes, Bins* bins, const BuildState* __restrict__ st, int level)
+// A block of 256 positions covers a handful of splitting nodes at most (ranges are contiguous, and nodes of up to kSmall
+// triangles have left the loop), so it bins into LDS -- one set of bins per node it touches -- and adds the non-empty bins
+// to the nodes' bins in global memory once: a tenth of the global atomics of one-atomic-per-triangle, which is what bounded
+// the middle levels (all of a node's triangles queue on the same 126 words).  A block that touches more than kBlockNodes
+// splitting nodes (possible only with RT_BVH_SMALL below 32) falls back to one global atomic per triangle and word.
+constexpr int kBlockNodes = 8;
+__global__ __launch_bounds__(256) void bins_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ node_of, int n,
+                                                   const float* __restrict__ centroid, const float* __restrict__ tbox,
+                                                   const BuildNode* __restrict__ nodes, Bins* bins, const BuildState* __restrict__ st, int level)
 {
     const int level_begin = st->begin[level];
     if (level_begin >= st->begin[level + 1]) return;             // past the last level
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int sbin[kBlockNodes][126];                       // per node, axis and bin: min xyz, max xyz (ordered-int images), count
+    __shared__ int slot_bin[kBlockNodes];                        // the node's Bins index
+    __shared__ int wave_heads[4];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int k = p < n ? node_of[p] : -1;
     bool valid = k >= level_begin;                               // else: past the end, or its node was finished earlier
     int bin_index = -1;
     if (valid) { bin_index = nodes[k].bin; valid = bin_index >= 0; }
-    // Block-uniform case (every position of the block belongs to one splitting node: the upper levels, where a few nodes
-    // take all the triangles): the block bins into LDS and adds its 126 words to the node's bins once, instead of every
-    // wave queueing for the same words.  node_of is constant over a node's contiguous range, so comparing the block's
-    // first and last position decides it.
-    __shared__ int sbin[3][6][7];                                // per axis and bin: min xyz, max xyz (ordered-int encoded), count
-    const int p_first = blockIdx.x * blockDim.x, p_last = min(p_first + (int)blockDim.x, n) - 1;
-    const int k_first = node_of[p_first], k_last = node_of[p_last];
-    if (k_first == k_last && k_first >= level_begin && nodes[k_first].bin >= 0) {
-        const BuildNode& nd = nodes[k_first];
-        for (int i = threadIdx.x; i < 126; i += blockDim.x) { const int w = i % 7; (&sbin[0][0][0])[i] = w < 3 ? 0x7f7fffff : (w < 6 ? (int)0x80800000 : 0); }
+    // a position starts a new node of the block when its node differs from its left neighbour's (or it is the block's first)
+    const int k_left = (threadIdx.x > 0 && p < n) ? node_of[p - 1] : -2;
+    const bool head = valid && k != k_left;
+    const unsigned long long m_head = __ballot(head);
+    if (lane == 0) wave_heads[wave] = __popcll(m_head);
+    __syncthreads();
+    int heads_before = 0, nslots = 0;
+    for (int w = 0; w < 4; w++) { const int c = wave_heads[w]; if (w < wave) heads_before += c; nslots += c; }
+    if (nslots == 0) return;
+    const int slot = heads_before + __popcll(m_head & ((2ull << lane) - 1ull)) - 1;   // heads at or before me: my node's slot (for a valid lane)
+    const int t = valid ? order[p] : 0;
+    if (nslots <= kBlockNodes) {
+        if (head) slot_bin[slot] = bin_index;
+        for (int i = threadIdx.x; i < nslots * 126; i += blockDim.x) { const int w = i % 7; (&sbin[0][0])[i] = w < 3 ? kOrderedMax : (w < 6 ? kOrderedLowest : 0); }
         __syncthreads();
-        if (p < n) {
-            const int t = order[p];
+        if (valid) {
+            const BuildNode& nd = nodes[k];
             const float* tb = tbox + 6 * (size_t)t;
+            int* b = sbin[slot];
             for (int a = 0; a < 3; a++) {
                 const float c = centroid[3 * (size_t)t + a];
                 int s = 0;
                 while (s < 5 && !(c <= plane_pos(nd.mn[a], nd.mx[a], s))) s++;
+                int* w = b + (a * 6 + s) * 7;
                 for (int q = 0; q < 3; q++) {
-                    // order-preserving integer image of a float (NaN skipped, zeros canonicalised, as atomic_min_f / atomic_max_f)
-                    const float lo_v = tb[q] + 0.0f, hi_v = tb[3 + q] + 0.0f;
-                    if (lo_v == lo_v) { const int b = __float_as_int(lo_v); atomicMin(&sbin[a][s][q], b >= 0 ? b : b ^ 0x7fffffff); }
-                    if (hi_v == hi_v) { const int b = __float_as_int(hi_v); atomicMax(&sbin[a][s][3 + q], b >= 0 ? b : b ^ 0x7fffffff); }
+                    const float lo_v = tb[q] + 0.0f, hi_v = tb[3 + q] + 0.0f;       // NaN skipped, zeros canonicalised, as atomic_min_f / atomic_max_f
+                    if (lo_v == lo_v) atomicMin(&w[q], ordered_int(lo_v));
+                    if (hi_v == hi_v) atomicMax(&w[3 + q], ordered_int(hi_v));
                 }
-                atomicAdd(&sbin[a][s][6], 1);
+                atomicAdd(&w[6], 1);
             }
         }
         __syncthreads();
-        Bins& b = bins[nd.bin];
-        for (int i = threadIdx.x; i < 126; i += blockDim.x) {
-            const int a = i / 42, s = (i / 7) % 6, w = i % 7;
-            const int v = sbin[a][s][w];
-            if (w == 6) { if (v) atomicAdd(&b.cnt[a][s], v); continue; }
-            if (sbin[a][s][6] == 0) continue;                    // empty bin: nothing to add
-            const float f = __int_as_float(v >= 0 ? v : v ^ 0x7fffffff);
-            if (w < 3) atomic_min_f(&b.mn[a][s][w], f); else atomic_max_f(&b.mx[a][s][w - 3], f);
+        for (int i = threadIdx.x; i < nslots * 126; i += blockDim.x) {
+            const int j = i / 126, r = i - 126 * j, a = r / 42, s = (r / 7) % 6, w = r % 7;
+            if (sbin[j][(a * 6 + s) * 7 + 6] == 0) continue;    // empty bin: nothing to add
+            Bins& b = bins[slot_bin[j]];
+            const int v = sbin[j][r];
+            if (w == 6) atomicAdd(&b.cnt[a][s], v);
+            else if (w < 3) atomic_min_f(&b.mn[a][s][w], ordered_float(v));
+            else atomic_max_f(&b.mx[a][s][w - 3], ordered_float(v));
         }
         return;
     }
-    const unsigned long long vm = __ballot(valid);
-    if (vm == 0) return;
-    const int first = __ffsll((long long)vm) - 1;
-    const int k0 = __shfl(k, first), bin0 = __shfl(bin_index, first);
-    const bool uniform = __ballot(valid && k != k0) == 0;
-    const int t = valid ? order[p] : 0;
-    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    if (valid) { const float* tb = tbox + 6 * (size_t)t; for (int q = 0; q < 3; q++) { lo[q] = tb[q]; hi[q] = tb[3 + q]; } }
-    const BuildNode& nd = nodes[valid ? k : k0];
-    Bins& b = bins[valid ? bin_index : bin0];
+    if (!valid) return;
+    const float* tb = tbox + 6 * (size_t)t;
+    const BuildNode& nd = nodes[k];
+    Bins& b = bins[bin_index];
     for (int a = 0; a < 3; a++) {
+        const float c = centroid[3 * (size_t)t + a];
         int s = 0;
-        if (valid) {
-            const float c = centroid[3 * (size_t)t + a];
-            while (s < 5 && !(c <= plane_pos(nd.mn[a], nd.mx[a], s))) s++;
-        }
-        if (uniform) {
-            for (int bin = 0; bin < 6; bin++) {
-                const unsigned long long m = __ballot(valid && s == bin);
-                if (m == 0) continue;
-                const bool mine = valid && s == bin;
-                float rl[3], rh[3];
-                for (int q = 0; q < 3; q++) { rl[q] = wave_min(mine ? lo[q] : FLT_MAX); rh[q] = wave_max(mine ? hi[q] : -FLT_MAX); }
-                if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
-                    for (int q = 0; q < 3; q++) { atomic_min_f(&b.mn[a][bin][q], rl[q]); atomic_max_f(&b.mx[a][bin][q], rh[q]); }
-                    atomicAdd(&b.cnt[a][bin], __popcll(m));
-                }
-            }
-        } else if (valid) {
-            for (int q = 0; q < 3; q++) { atomic_min_f(&b.mn[a][s][q], lo[q]); atomic_max_f(&b.mx[a][s][q], hi[q]); }
-            atomicAdd(&b.cnt[a][s], 1);
-        }
+        while (s < 5 && !(c <= plane_pos(nd.mn[a], nd.mx[a], s))) s++;
+        for (int q = 0; q < 3; q++) { atomic_min_f(&b.mn[a][s][q], tb[q]); atomic_max_f(&b.mx[a][s][q], tb[3 + q]); }
+        atomicAdd(&b.cnt[a][s], 1);
     }
 }
 
@@ -246,119 +248,351 @@ __device__ __forceinline__ float box_cost(const float* mn, const float* mx, int 
     return half_area * (float)count;
 }
 
-// BVHTree.hpp:218-289 for every node of the level; children are appended to the node array with their boxes (the union
+// The bins of one node, as decide reads them: in global memory as floats (the level kernels) or in LDS as the
+// order-preserving integer images the LDS atomics work on (small_subtree_kernel).
+struct GlobalBinsView {
+    const Bins& b;
+    __device__ __forceinline__ float mn(int a, int q, int c) const { return b.mn[a][q][c]; }
+    __device__ __forceinline__ float mx(int a, int q, int c) const { return b.mx[a][q][c]; }
+    __device__ __forceinline__ int cnt(int a, int q) const { return b.cnt[a][q]; }
+};
+struct LdsBinsView {
+    const int* w;                                                // [3][6][7]: min xyz, max xyz, count
+    __device__ __forceinline__ float mn(int a, int q, int c) const { return ordered_float(w[(a * 6 + q) * 7 + c]); }
+    __device__ __forceinline__ float mx(int a, int q, int c) const { return ordered_float(w[(a * 6 + q) * 7 + 3 + c]); }
+    __device__ __forceinline__ int cnt(int a, int q) const { return w[(a * 6 + q) * 7 + 6]; }
+};
+
+struct SplitDecision {
+    bool split;
+    int axis, nl;
+    float split_pos;
+    float cmn[2][3], cmx[2][3];                                  // the children's boxes
+};
+
+struct AxisEval { float cost, split; int nl, s; };             // s = -1: no plane of the axis was accepted
+
+// evaluate_split (BVHTree.hpp:294-361) for one axis of a node whose bins are complete
+template <class BinsView>
+__device__ __forceinline__ AxisEval evaluate_axis(const BinsView& b, int a, float nmn_a, float nmx_a)
+{
+    AxisEval e;
+    e.cost = FLT_MAX; e.split = 0.0f; e.nl = 0; e.s = -1;
+    // right side of plane s = bins s+1..5, accumulated from the far end; the left side grows with s (each bin is read
+    // twice instead of five times; unions of boxes are exact, so the order of the folds does not matter)
+    float rmn[5][3], rmx[5][3];
+    int rcount[5];
+    {
+        float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        int n = 0;
+        for (int q = 5; q >= 1; q--) {
+            for (int c = 0; c < 3; c++) { amn[c] = fminf(amn[c], b.mn(a, q, c)); amx[c] = fmaxf(amx[c], b.mx(a, q, c)); }
+            n += b.cnt(a, q);
+            for (int c = 0; c < 3; c++) { rmn[q - 1][c] = amn[c]; rmx[q - 1][c] = amx[c]; }
+            rcount[q - 1] = n;
+        }
+    }
+    float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int ln = 0;
+    for (int s5 = 0; s5 < 5; s5++) {
+        for (int c = 0; c < 3; c++) { lmn[c] = fminf(lmn[c], b.mn(a, s5, c)); lmx[c] = fmaxf(lmx[c], b.mx(a, s5, c)); }
+        ln += b.cnt(a, s5);
+        const float cost = box_cost(lmn, lmx, ln) + box_cost(rmn[s5], rmx[s5], rcount[s5]);         // BVHTree.hpp:351
+        if (cost < e.cost) { e.cost = cost; e.split = plane_pos(nmn_a, nmx_a, s5); e.nl = ln; e.s = s5; }
+    }
+    return e;
+}
+
+// BVHTree.hpp:229-289 once the three axes are evaluated: the axis, "no split if not cheaper", the children's boxes and sizes.
+// tri_at(i) = triangle at position i of the node's range (only the degenerate-input path below looks at triangles).
+template <class BinsView, class TriAt>
+__device__ __forceinline__ void choose_split(const BinsView& b, const AxisEval e0, const AxisEval e1, const AxisEval e2, const float* nmn, const float* nmx, int count,
+                                             TriAt tri_at, const float* __restrict__ centroid, const float* __restrict__ tbox, SplitDecision& d)
+{
+    d.split = true; d.nl = 0;
+    for (int side = 0; side < 2; side++)
+        for (int c = 0; c < 3; c++) { d.cmn[side][c] = FLT_MAX; d.cmx[side][c] = -FLT_MAX; }
+    int axis;
+    if (e0.cost < e1.cost && e0.cost < e2.cost) axis = 0;       // BVHTree.hpp:229-243
+    else if (e1.cost < e0.cost && e1.cost < e2.cost) axis = 1;
+    else axis = 2;
+    const AxisEval e = axis == 0 ? e0 : (axis == 1 ? e1 : e2);
+    d.axis = axis;
+    d.split_pos = e.split;
+    if (e.cost >= box_cost(nmn, nmx, count)) { d.split = false; return; }       // BVHTree.hpp:246
+    d.nl = e.nl;
+    if (e.s >= 0) {
+        for (int q = 0; q < 6; q++) {
+            const int side = q <= e.s ? 0 : 1;
+            for (int c = 0; c < 3; c++) { d.cmn[side][c] = fminf(d.cmn[side][c], b.mn(axis, q, c)); d.cmx[side][c] = fmaxf(d.cmx[side][c], b.mx(axis, q, c)); }
+        }
+    } else {
+        // No plane was cheaper than FLT_MAX, and yet the test above let the node through: its own cost is infinite or
+        // NaN (infinite or NaN coordinates).  The reference then partitions at the initial split position 0
+        // (BVHTree.hpp:253); the bins say nothing about that plane, so this one thread walks the node's triangles.
+        // Degenerate inputs only.
+        d.nl = 0;
+        for (int i = 0; i < count; i++) {
+            const int t = tri_at(i);
+            const int side = centroid[3 * (size_t)t + axis] <= d.split_pos ? 0 : 1;
+            d.nl += side == 0 ? 1 : 0;
+            for (int c = 0; c < 3; c++) { d.cmn[side][c] = fminf(d.cmn[side][c], tbox[6 * (size_t)t + c]); d.cmx[side][c] = fmaxf(d.cmx[side][c], tbox[6 * (size_t)t + 3 + c]); }
+        }
+        for (int side = 0; side < 2; side++)                     // (the atomics of the binned path canonicalise zeros to +0.0)
+            for (int c = 0; c < 3; c++) { d.cmn[side][c] = d.cmn[side][c] + 0.0f; d.cmx[side][c] = d.cmx[side][c] + 0.0f; }
+    }
+    if (d.nl == 0 || count - d.nl == 0) d.split = false;         // BVHTree.hpp:279
+}
+
+// BVHTree.hpp:218-289 for one node whose bins are complete: the host builder's fp32 operations in the same order.
+template <class BinsView, class TriAt>
+__device__ __forceinline__ void decide_split(const BinsView& b, const float* nmn, const float* nmx, int count, TriAt tri_at,
+                                             const float* __restrict__ centroid, const float* __restrict__ tbox, SplitDecision& d)
+{
+    const AxisEval e0 = evaluate_axis(b, 0, nmn[0], nmx[0]), e1 = evaluate_axis(b, 1, nmn[1], nmx[1]), e2 = evaluate_axis(b, 2, nmn[2], nmx[2]);
+    choose_split(b, e0, e1, e2, nmn, nmx, count, tri_at, centroid, tbox, d);
+}
+
+// decide_split for every node of the level; children are appended to the node array with their boxes (the union
 // of the bin boxes on their side of the plane = BVHTree.hpp:206-209 over their triangles) and, if they will evaluate a
-// split themselves, a cleared Bins slot of the other parity
+// split themselves, a cleared Bins slot of the other parity -- or, when they hold at most small_limit triangles, a place in
+// the list of subtrees small_subtree_kernel finishes after the level loop.
 //
-// Node pairs and bin slots are handed out per WAVE (one atomic on the shared counter per wave, the lanes take consecutive
-// pieces): with one atomic per node the deep levels -- tens of thousands of nodes -- queued on a single word.
+// Node pairs, bin slots and list places are handed out per WAVE (one atomic on the shared counter per wave, the lanes take
+// consecutive pieces): with one atomic per node the deep levels -- tens of thousands of nodes -- queued on a single word.
 __global__ void decide_kernel(BuildNode* nodes, Bins* bins, int bins_per_level, BuildState* st, int level, int max_depth, int cap,
-                              const int32_t* __restrict__ order, const float* __restrict__ centroid, const float* __restrict__ tbox)
+                              const int32_t* __restrict__ order, const float* __restrict__ centroid, const float* __restrict__ tbox,
+                              int32_t* __restrict__ small_roots, int small_limit)
 {
     const int level_begin = st->begin[level], level_end = st->begin[level + 1];
     const int k = level_begin + blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(threadIdx.x & 63);
     bool split = k < level_end && nodes[k < level_end ? k : level_begin].bin >= 0;      // depth or count limit: BVHTree.hpp:211-215
     BuildNode& nd = nodes[k < level_end ? k : level_begin];
-    int axis = 2, nl = 0;
-    float split_pos = 0.0f;
-    float cmn[2][3], cmx[2][3];                                  // the children's boxes
-    for (int side = 0; side < 2; side++)
-        for (int c = 0; c < 3; c++) { cmn[side][c] = FLT_MAX; cmx[side][c] = -FLT_MAX; }
+    SplitDecision d;
+    d.nl = 0; d.axis = 2; d.split_pos = 0.0f;
     if (split) {
-        const Bins& b = bins[nd.bin];
-        float eval_cost[3], eval_split[3];
-        int eval_nl[3], eval_s[3];                               // eval_s = -1: no plane of the axis was accepted
-        for (int a = 0; a < 3; a++) {
-            float best_cost = FLT_MAX, best_split = 0.0f;
-            int best_nl = 0, best_s = -1;
-            // right side of plane s = bins s+1..5, accumulated from the far end; the left side grows with s (each bin is read
-            // twice instead of five times; unions of boxes are exact, so the order of the folds does not matter)
-            float rmn[5][3], rmx[5][3];
-            int rcount[5];
-            {
-                float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                int n = 0;
-                for (int q = 5; q >= 1; q--) {
-                    for (int c = 0; c < 3; c++) { amn[c] = fminf(amn[c], b.mn[a][q][c]); amx[c] = fmaxf(amx[c], b.mx[a][q][c]); }
-                    n += b.cnt[a][q];
-                    for (int c = 0; c < 3; c++) { rmn[q - 1][c] = amn[c]; rmx[q - 1][c] = amx[c]; }
-                    rcount[q - 1] = n;
-                }
-            }
-            float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-            int ln = 0;
-            for (int s5 = 0; s5 < 5; s5++) {
-                for (int c = 0; c < 3; c++) { lmn[c] = fminf(lmn[c], b.mn[a][s5][c]); lmx[c] = fmaxf(lmx[c], b.mx[a][s5][c]); }
-                ln += b.cnt[a][s5];
-                const float cost = box_cost(lmn, lmx, ln) + box_cost(rmn[s5], rmx[s5], rcount[s5]);     // BVHTree.hpp:351
-                if (cost < best_cost) { best_cost = cost; best_split = plane_pos(nd.mn[a], nd.mx[a], s5); best_nl = ln; best_s = s5; }
-            }
-            eval_cost[a] = best_cost; eval_split[a] = best_split; eval_nl[a] = best_nl; eval_s[a] = best_s;
-        }
-        if (eval_cost[0] < eval_cost[1] && eval_cost[0] < eval_cost[2]) axis = 0;   // BVHTree.hpp:229-243
-        else if (eval_cost[1] < eval_cost[0] && eval_cost[1] < eval_cost[2]) axis = 1;
-        else axis = 2;
-        split_pos = eval_split[axis];
-        if (eval_cost[axis] >= box_cost(nd.mn, nd.mx, nd.count)) split = false;     // BVHTree.hpp:246
-        if (split) {
-            nl = eval_nl[axis];
-            if (eval_s[axis] >= 0) {
-                for (int q = 0; q < 6; q++) {
-                    const int side = q <= eval_s[axis] ? 0 : 1;
-                    for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], b.mn[axis][q][c]); cmx[side][c] = fmaxf(cmx[side][c], b.mx[axis][q][c]); }
-                }
-            } else {
-                // No plane was cheaper than FLT_MAX, and yet the test above let the node through: its own cost is infinite or
-                // NaN (infinite or NaN coordinates).  The reference then partitions at the initial split position 0
-                // (BVHTree.hpp:253); the bins say nothing about that plane, so this one thread walks the node's triangles.
-                // Degenerate inputs only.
-                nl = 0;
-                for (int i = 0; i < nd.count; i++) {
-                    const int t = order[nd.first + i];
-                    const int side = centroid[3 * (size_t)t + axis] <= split_pos ? 0 : 1;
-                    nl += side == 0 ? 1 : 0;
-                    for (int c = 0; c < 3; c++) { cmn[side][c] = fminf(cmn[side][c], tbox[6 * (size_t)t + c]); cmx[side][c] = fmaxf(cmx[side][c], tbox[6 * (size_t)t + 3 + c]); }
-                }
-                for (int side = 0; side < 2; side++)             // (the atomics of the binned path canonicalise zeros to +0.0)
-                    for (int c = 0; c < 3; c++) { cmn[side][c] = cmn[side][c] + 0.0f; cmx[side][c] = cmx[side][c] + 0.0f; }
-            }
-            if (nl == 0 || nd.count - nl == 0) split = false;    // BVHTree.hpp:279
-        }
+        const int first = nd.first;
+        decide_split(GlobalBinsView{bins[nd.bin]}, nd.mn, nd.mx, nd.count, [&](int i) { return order[first + i]; }, centroid, tbox, d);
+        split = d.split;
     }
+    const int nl = split ? d.nl : 0;
     // ---- one allocation per wave: 2 nodes per splitting lane, one bin slot per child that will evaluate a split itself
     const int nr = nd.count - nl;
-    const bool bin_a = split && !(nd.depth + 1 >= max_depth || nl <= 1), bin_b = split && !(nd.depth + 1 >= max_depth || nr <= 1);
-    const unsigned long long m_split = __ballot(split), m_a = __ballot(bin_a), m_b = __ballot(bin_b);
+    const bool go_a = split && !(nd.depth + 1 >= max_depth || nl <= 1), go_b = split && !(nd.depth + 1 >= max_depth || nr <= 1);   // BVHTree.hpp:211-215 for the children
+    const bool small_a = go_a && nl <= small_limit, small_b = go_b && nr <= small_limit;
+    const bool bin_a = go_a && !small_a, bin_b = go_b && !small_b;
+    const unsigned long long m_split = __ballot(split), m_a = __ballot(bin_a), m_b = __ballot(bin_b), m_sa = __ballot(small_a), m_sb = __ballot(small_b);
     if (m_split == 0ull) return;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int leader = __ffsll((long long)m_split) - 1;
-    int node_base = 0, bin_base = 0;
+    int node_base = 0, bin_base = 0, small_base = 0;
     if (lane == leader) {
         node_base = atomicAdd(&st->total, 2 * __popcll(m_split));
         if ((m_a | m_b) != 0ull) bin_base = atomicAdd(&st->bins_used[(level + 1) & 1], __popcll(m_a) + __popcll(m_b));
+        if ((m_sa | m_sb) != 0ull) small_base = atomicAdd(&st->num_small, __popcll(m_sa) + __popcll(m_sb));
     }
     node_base = __shfl(node_base, leader);
     bin_base = __shfl(bin_base, leader);
+    small_base = __shfl(small_base, leader);
     if (!split) return;
     const int a = node_base + 2 * __popcll(m_split & below);
     if (a + 2 > cap || level + 2 > kMaxLevels) { st->overflow = 1; return; }
-    nd.axis = axis; nd.split_pos = split_pos; nd.nl = nl;
+    nd.axis = d.axis; nd.split_pos = d.split_pos; nd.nl = nl;
     nd.child_a = a; nd.child_b = a + 1;
     const int other = ((level + 1) & 1) * bins_per_level;        // children use the other half of the bin array
     const int slot_a = bin_base + __popcll(m_a & below) + __popcll(m_b & below);       // (<= n / 2 such nodes per level)
+    const int place_a = small_base + __popcll(m_sa & below) + __popcll(m_sb & below);
     for (int side = 0; side < 2; side++) {
         BuildNode& ch = nodes[a + side];
-        for (int c = 0; c < 3; c++) { ch.mn[c] = cmn[side][c]; ch.mx[c] = cmx[side][c]; }
+        for (int c = 0; c < 3; c++) { ch.mn[c] = d.cmn[side][c]; ch.mx[c] = d.cmx[side][c]; }
         ch.first = side == 0 ? nd.first : nd.first + nl;
         ch.count = side == 0 ? nl : nr;
         ch.depth = nd.depth + 1;
         ch.child_a = ch.child_b = -1; ch.axis = 0; ch.split_pos = 0.0f; ch.nl = 0;
-        ch.bin = -1;
+        ch.bin = -1;                                             // a leaf for the level kernels (also when a wave will finish it later)
         if (side == 0 ? bin_a : bin_b) {
             ch.bin = other + slot_a + (side == 1 && bin_a ? 1 : 0);
             clear_bins(bins[ch.bin]);
         }
+        if (side == 0 ? small_a : small_b) small_roots[place_a + (side == 1 && small_a ? 1 : 0)] = a + side;
+    }
+}
+
+// A subtree of at most 64 triangles is finished by ONE wave, lane = triangle, instead of travelling through fifteen more
+// levels of the loop above (where such nodes are the bulk of the work: tens of thousands of nodes of a few triangles each,
+// 21 global atomics per triangle and level).  Everything stays in the wave: the triangles' centroids and boxes in
+// registers, the bins of all nodes of the subtree's current level in LDS (LDS atomics on the ordered-integer images), one
+// lane per node runs decide_split -- the same function the level kernels use -- and the stable partition is a permutation
+// of lanes (ranks from ballots, data through LDS).  The subtree's nodes collect in LDS and are appended to the node array
+// in one piece at the end; the numbering pass does not care in which order nodes were created.
+struct SmallLds {
+    int bins[32][126];                                           // a node that evaluates a split holds >= 2 triangles: <= 32 per level
+    float nbox[64][6];                                           // node records, keyed by the lane where the node's range starts
+    int ncount[64], ndepth[64], nid[64];
+    int slot_head[32];
+    int r_split[32], r_axis[32], r_nl[32], r_go_a[32], r_go_b[32];
+    float r_pos[32];
+    float e_cost[96], e_split[96];                               // per (node, axis) evaluation, item 3 j + a
+    int e_nl[96], e_s[96];
+    // the subtree's nodes stay here until its last level is done (children as indices into this array) and then take one
+    // contiguous piece of the node array: one atomic on the shared node counter per subtree instead of one per level
+    float l_mn[126][3], l_mx[126][3];
+    int l_first[126], l_count[126], l_depth[126], l_child[126], l_axis[126], l_nl[126];
+    float l_pos[126];
+    int root_child, root_axis, root_nl;
+    float root_pos;
+    int tri[64];                                                 // triangle at every position of the subtree's range
+    int p_t[64], p_seg[64], p_cnt[64];                           // staging of the lane permutation
+    float p_c[64][3], p_b[64][6];
+};
+
+__global__ __launch_bounds__(64) void small_subtree_kernel(BuildNode* nodes, BuildState* st, const int32_t* __restrict__ small_roots,
+                                                           int32_t* order, const float* __restrict__ centroid, const float* __restrict__ tbox,
+                                                           int max_depth, int cap)
+{
+    __shared__ SmallLds L;
+    if ((int)blockIdx.x >= st->num_small) return;
+    const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int root = small_roots[blockIdx.x];
+    const int first = nodes[root].first, total = nodes[root].count;
+    if (lane == 0) {
+        for (int c = 0; c < 3; c++) { L.nbox[0][c] = nodes[root].mn[c]; L.nbox[0][3 + c] = nodes[root].mx[c]; }
+        L.ncount[0] = total; L.ndepth[0] = nodes[root].depth; L.nid[0] = -1;      // (-1: the subtree's root, already in the node array)
+        L.root_child = -1;
+    }
+    int created = 0;                                             // nodes of the subtree so far (wave-uniform)
+    int seg = lane < total ? 0 : -1, cnt = total;                // my node: the lane its range starts at (-1: finished), its size
+    int deepest = 0;                                             // depth of the deepest node this lane created
+    int t = 0;
+    float cen[3] = {0.0f, 0.0f, 0.0f}, box[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (lane < total) {
+        t = order[first + lane];
+        for (int c = 0; c < 3; c++) cen[c] = centroid[3 * (size_t)t + c];
+        for (int c = 0; c < 6; c++) box[c] = tbox[6 * (size_t)t + c];
+    }
+    L.tri[lane] = t;
+    __syncthreads();
+    for (int iteration = 0; iteration < kMaxLevels; iteration++) {
+        const bool active = seg >= 0;
+        const unsigned long long m_head = __ballot(active && lane == seg);
+        if (m_head == 0ull) break;
+        const int nslots = __popcll(m_head);
+        const int slot = __popcll(m_head & (below | (1ull << lane))) - 1;     // the nearest head at or below an active lane is its own
+        if (active && lane == seg) L.slot_head[slot] = lane;
+        for (int i = lane; i < nslots * 126; i += 64) { const int w = i % 7; (&L.bins[0][0])[i] = w < 3 ? kOrderedMax : (w < 6 ? kOrderedLowest : 0); }
+        __syncthreads();
+        // ---- bins (bins_kernel for one wave)
+        if (active) {
+            int* b = L.bins[slot];
+            for (int a = 0; a < 3; a++) {
+                const float nmn = L.nbox[seg][a], nmx = L.nbox[seg][3 + a];
+                int s = 0;
+                while (s < 5 && !(cen[a] <= plane_pos(nmn, nmx, s))) s++;
+                int* w = b + (a * 6 + s) * 7;
+                for (int q = 0; q < 3; q++) {
+                    const float lo_v = box[q] + 0.0f, hi_v = box[3 + q] + 0.0f;          // NaN skipped, zeros canonicalised (atomic_min_f / atomic_max_f)
+                    if (lo_v == lo_v) atomicMin(&w[q], ordered_int(lo_v));
+                    if (hi_v == hi_v) atomicMax(&w[3 + q], ordered_int(hi_v));
+                }
+                atomicAdd(&w[6], 1);
+            }
+        }
+        __syncthreads();
+        // ---- decide (decide_kernel for the <= 32 nodes of this level of the subtree): lane j owns slot j
+        {
+            const bool owner = lane < nslots;
+            const int h = owner ? L.slot_head[lane] : 0;
+            SplitDecision d;
+            d.split = false; d.nl = 0; d.axis = 2; d.split_pos = 0.0f;
+            float nmn[3], nmx[3];
+            for (int c = 0; c < 3; c++) { nmn[c] = L.nbox[h][c]; nmx[c] = L.nbox[h][3 + c]; }
+            const int count = L.ncount[h], depth = L.ndepth[h], id = L.nid[h];
+            // the three axes of a node on three lanes (item 3 j + a), then the node's lane j collects them: a third of the
+            // longest dependent chain while few nodes are alive, which is most of a subtree's life
+            for (int item = lane; item < nslots * 3; item += 64) {
+                const int j = item / 3, a = item - 3 * j, hj = L.slot_head[j];
+                const AxisEval e = evaluate_axis(LdsBinsView{L.bins[j]}, a, L.nbox[hj][a], L.nbox[hj][3 + a]);
+                L.e_cost[item] = e.cost; L.e_split[item] = e.split; L.e_nl[item] = e.nl; L.e_s[item] = e.s;
+            }
+            __syncthreads();
+            if (owner) {
+                auto stored = [&](int a) { AxisEval e; e.cost = L.e_cost[3 * lane + a]; e.split = L.e_split[3 * lane + a]; e.nl = L.e_nl[3 * lane + a]; e.s = L.e_s[3 * lane + a]; return e; };
+                choose_split(LdsBinsView{L.bins[lane]}, stored(0), stored(1), stored(2), nmn, nmx, count, [&](int i) { return L.tri[h + i]; }, centroid, tbox, d);
+            }
+            const bool split = owner && d.split;
+            const unsigned long long m_split = __ballot(split);
+            const int a = created + 2 * __popcll(m_split & below);
+            created += 2 * __popcll(m_split);
+            if (owner) {
+                const int nl = d.nl, nr = count - d.nl;
+                const bool go_a = split && !(depth + 1 >= max_depth || nl <= 1), go_b = split && !(depth + 1 >= max_depth || nr <= 1);
+                L.r_split[lane] = split ? 1 : 0; L.r_axis[lane] = d.axis; L.r_pos[lane] = d.split_pos; L.r_nl[lane] = nl;
+                L.r_go_a[lane] = go_a ? 1 : 0; L.r_go_b[lane] = go_b ? 1 : 0;
+                if (split) {
+                    if (id < 0) { L.root_child = a; L.root_axis = d.axis; L.root_pos = d.split_pos; L.root_nl = nl; }
+                    else { L.l_child[id] = a; L.l_axis[id] = d.axis; L.l_pos[id] = d.split_pos; L.l_nl[id] = nl; }
+                    for (int side = 0; side < 2; side++) {
+                        const int ch = a + side;
+                        for (int c = 0; c < 3; c++) { L.l_mn[ch][c] = d.cmn[side][c]; L.l_mx[ch][c] = d.cmx[side][c]; }
+                        L.l_first[ch] = side == 0 ? first + h : first + h + nl;
+                        L.l_count[ch] = side == 0 ? nl : nr;
+                        L.l_depth[ch] = depth + 1;
+                        L.l_child[ch] = -1; L.l_axis[ch] = 0; L.l_pos[ch] = 0.0f; L.l_nl[ch] = 0;
+                        const int key = side == 0 ? h : h + nl;          // (side 0 reuses the parent's entry: this lane is its only reader)
+                        for (int c = 0; c < 3; c++) { L.nbox[key][c] = d.cmn[side][c]; L.nbox[key][3 + c] = d.cmx[side][c]; }
+                        L.ncount[key] = side == 0 ? nl : nr; L.ndepth[key] = depth + 1; L.nid[key] = ch;
+                    }
+                    deepest = depth + 1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stable partition (flags_scan_kernel + scatter_kernel for one wave): a permutation of lanes
+        int q = lane, new_seg = -1, new_cnt = 0;
+        const bool splits = active && L.r_split[slot] != 0;
+        const int split_axis = splits ? L.r_axis[slot] : 0;
+        const bool left = splits && (split_axis == 0 ? cen[0] : (split_axis == 1 ? cen[1] : cen[2])) <= L.r_pos[slot];
+        const unsigned long long m_left = __ballot(left);
+        if (splits) {
+            const unsigned long long range = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << seg;
+            const int nl = L.r_nl[slot];
+            const int lrank = __popcll(m_left & range & below);       // left-going triangles of my node before me
+            if (left) { q = seg + lrank; new_seg = L.r_go_a[slot] ? seg : -1; new_cnt = nl; }
+            else { q = seg + nl + (lane - seg - lrank); new_seg = L.r_go_b[slot] ? seg + nl : -1; new_cnt = cnt - nl; }
+        }
+        L.p_t[q] = t; L.p_seg[q] = new_seg; L.p_cnt[q] = new_cnt;
+        for (int c = 0; c < 3; c++) L.p_c[q][c] = cen[c];
+        for (int c = 0; c < 6; c++) L.p_b[q][c] = box[c];
+        __syncthreads();
+        t = L.p_t[lane]; seg = L.p_seg[lane]; cnt = L.p_cnt[lane];
+        for (int c = 0; c < 3; c++) cen[c] = L.p_c[lane][c];
+        for (int c = 0; c < 6; c++) box[c] = L.p_b[lane][c];
+        L.tri[lane] = t;
+        __syncthreads();
+    }
+    if (lane < total) order[first + lane] = t;
+    // ---- the subtree's nodes into the node array: one piece, one atomic (and one for the depth: every lane of every level
+    //      adding its own put a million atomics in line for that one word)
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(deepest, o); deepest = v > deepest ? v : deepest; }
+    if (created == 0) return;
+    int base = 0;
+    if (lane == 0) { base = atomicAdd(&st->total, created); atomicMax(&st->levels, deepest); }
+    base = __shfl(base, 0);
+    if (base + created > cap) { if (lane == 0) st->overflow = 1; return; }
+    for (int i = lane; i < created; i += 64) {
+        BuildNode& g = nodes[base + i];
+        for (int c = 0; c < 3; c++) { g.mn[c] = L.l_mn[i][c]; g.mx[c] = L.l_mx[i][c]; }
+        g.first = L.l_first[i]; g.count = L.l_count[i]; g.depth = L.l_depth[i];
+        const int child = L.l_child[i];
+        g.child_a = child < 0 ? -1 : base + child; g.child_b = child < 0 ? -1 : base + child + 1;
+        g.axis = L.l_axis[i]; g.split_pos = L.l_pos[i]; g.nl = L.l_nl[i]; g.bin = -1;
+    }
+    if (lane == 0) {
+        BuildNode& g = nodes[root];
+        g.child_a = base + L.root_child; g.child_b = base + L.root_child + 1;
+        g.axis = L.root_axis; g.split_pos = L.root_pos; g.nl = L.root_nl;
     }
 }
 
@@ -503,7 +737,7 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     const int bins_per_level = n / 2 + 1;                        // nodes that evaluate a split hold >= 2 triangles each
     std::lock_guard<std::mutex> lock(g_arena_mutex);
     float *d_v, *d_centroid, *d_tbox, *d_bounds;
-    int32_t *d_order[2], *d_nodeof[2], *d_flags, *d_scan, *d_btot, *d_hist, *d_hscan, *d_children, *d_lfirst, *d_lcount;
+    int32_t *d_order[2], *d_nodeof[2], *d_flags, *d_scan, *d_btot, *d_hist, *d_hscan, *d_children, *d_lfirst, *d_lcount, *d_small;
     BuildNode* d_nodes;
     Bins* d_bins;
     BuildState* d_state;
@@ -525,7 +759,7 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
                      o_state = take(sizeof(BuildState)), o_nodes = take(((size_t)cap + 2) * sizeof(BuildNode)),
                      o_bins = take(2 * (size_t)bins_per_level * sizeof(Bins)), o_tmp = take(tmp_bytes ? tmp_bytes : 1),
                      o_bounds = take((size_t)cap * 6 * 4), o_children = take((size_t)cap * 2 * 4), o_lfirst = take((size_t)cap * 4),
-                     o_lcount = take((size_t)cap * 4);
+                     o_lcount = take((size_t)cap * 4), o_small = take((n1 / 2 + 2) * 4);
         int device = 0;
         hipError_t he = hipGetDevice(&device);
         if (he != hipSuccess) return he == hipErrorNoDevice ? RT_E_NODEVICE : (int)he;
@@ -544,8 +778,12 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
         d_state = (BuildState*)(arena + o_state);
         d_nodes = (BuildNode*)(arena + o_nodes); d_bins = (Bins*)(arena + o_bins); d_tmp = arena + o_tmp;
         d_bounds = (float*)(arena + o_bounds); d_children = (int32_t*)(arena + o_children);
-        d_lfirst = (int32_t*)(arena + o_lfirst); d_lcount = (int32_t*)(arena + o_lcount);
+        d_lfirst = (int32_t*)(arena + o_lfirst); d_lcount = (int32_t*)(arena + o_lcount); d_small = (int32_t*)(arena + o_small);
     }
+    // subtrees of at most this many triangles leave the level loop and are finished by one wave each (RT_BVH_SMALL=0: everything
+    // goes through the level loop, the tests' way of keeping that path covered)
+    int small_limit = kSmall;
+    if (const char* e = getenv("RT_BVH_SMALL")) { const int v = atoi(e); small_limit = v < 0 ? 0 : (v > kSmall ? kSmall : v); }
 
     const bool debug = getenv("RT_BVH_DEBUG") != nullptr;           // diagnostics: phase timings (with extra synchronisation) and a state dump
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -553,32 +791,54 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     if (n > 0) RT_HIP(hipMemcpyAsync(d_v, vertices, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, 0));
     if (debug) { (void)hipDeviceSynchronize(); t_in = now(); }
     hipLaunchKernelGGL(prep_kernel, dim3((n + 1 + T - 1) / T), dim3(T), 0, 0, d_v, n, max_depth, d_centroid, d_tbox, d_order[0], d_nodeof[0],
-                       d_nodes, d_bins, d_state, d_hist);
+                       d_nodes, d_bins, d_state, d_hist, d_small, small_limit);
     if (n > 0) hipLaunchKernelGGL(root_bounds_kernel, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, 0, n, d_tbox, d_nodes);
 
-    // ---- the level loop: four launches per level, nothing read back.  A tree over n triangles has at most n levels,
-    //      the depth limit caps it at max_depth; levels past the last one find begin[l] == begin[l + 1] and return. ----
-    if (n > 1) {
-        const bool library_scan = getenv("RT_BVH_LIBRARY_SCAN") != nullptr;     // tests: force the path meshes above 1 M triangles take
-        const int levels_to_run = max_depth < n ? max_depth : n;
-        for (int l = 0; l < levels_to_run; l++) {
-            const long long width = l < 30 ? (1ll << l) : (1ll << 30);
-            const int gridL = (int)(((width < n ? width : (long long)n) + T - 1) / T);
-            hipLaunchKernelGGL(bins_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_tbox, d_nodes, d_bins, d_state, l);
-            hipLaunchKernelGGL(decide_kernel, dim3(gridL), dim3(T), 0, 0, d_nodes, d_bins, bins_per_level, d_state, l, max_depth, cap,
-                               d_order[cur], d_centroid, d_tbox);
-            if (gridN <= kScanBlocks && !library_scan) {
-                hipLaunchKernelGGL(flags_scan_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l,
-                                   d_flags, d_scan, d_btot);
-                hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
-                                   d_btot, gridN, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
-            } else {                                             // very large meshes: library scan over the whole array
-                hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l, d_flags);
-                RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n));
-                hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
-                                   (const int32_t*)nullptr, 0, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
+    // ---- the level loop: four launches per level.  Where a level starts and ends is device state, so the host enqueues
+    //      levels without waiting; it only has to learn when to stop.  Nodes of more than small_limit triangles are gone
+    //      after about log2(n / small_limit) levels, so that is where the host first asks (one 4-byte-class read-back; a
+    //      level that is not needed costs four empty launches, about as much), then every other level.  A tree over n
+    //      triangles has at most n levels, the depth limit caps it at max_depth. ----
+    st.num_small = 0;
+    {
+        bool have_state = false;
+        if (n > 1 && n > small_limit) {
+            const bool library_scan = getenv("RT_BVH_LIBRARY_SCAN") != nullptr;     // tests: force the path meshes above 1 M triangles take
+            const int levels_to_run = max_depth < n ? max_depth : n;
+            int check_at = 2;
+            for (long long m = small_limit > 0 ? small_limit : 1; m < n; m *= 2) check_at++;
+            for (int l = 0; l < levels_to_run; l++) {
+                const long long width = l < 30 ? (1ll << l) : (1ll << 30);
+                const int gridL = (int)(((width < n ? width : (long long)n) + T - 1) / T);
+                hipLaunchKernelGGL(bins_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_tbox, d_nodes, d_bins, d_state, l);
+                hipLaunchKernelGGL(decide_kernel, dim3(gridL), dim3(T), 0, 0, d_nodes, d_bins, bins_per_level, d_state, l, max_depth, cap,
+                                   d_order[cur], d_centroid, d_tbox, d_small, small_limit);
+                if (gridN <= kScanBlocks && !library_scan) {
+                    hipLaunchKernelGGL(flags_scan_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l,
+                                       d_flags, d_scan, d_btot);
+                    hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
+                                       d_btot, gridN, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
+                } else {                                         // very large meshes: library scan over the whole array
+                    hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l, d_flags);
+                    RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n));
+                    hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
+                                       (const int32_t*)nullptr, 0, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
+                }
+                cur ^= 1;
+                have_state = false;
+                if (l + 1 >= check_at && l + 1 < levels_to_run) {
+                    RT_HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
+                    have_state = true;
+                    if (st.bins_used[(l + 1) & 1] == 0) break;   // no node of the next level evaluates a split
+                    check_at = l + 3;
+                }
             }
-            cur ^= 1;
+        }
+        if (small_limit > 0 && n > 1) {
+            if (!have_state) RT_HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
+            if (st.num_small > 0)
+                hipLaunchKernelGGL(small_subtree_kernel, dim3(st.num_small), dim3(64), 0, 0, d_nodes, d_state, d_small, d_order[cur], d_centroid, d_tbox,
+                                   max_depth, cap);
         }
     }
     // ---- breadth-first -> the reference's depth-first numbering ----
@@ -590,7 +850,8 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     RT_HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
     total = st.total;
     if (debug) {
-        fprintf(stderr, "bvh: n %d total %d levels %d overflow %d bins_used %d %d begin", n, st.total, st.levels, st.overflow, st.bins_used[0], st.bins_used[1]);
+        fprintf(stderr, "bvh: n %d total %d levels %d overflow %d bins_used %d %d small subtrees %d (limit %d) begin", n, st.total, st.levels, st.overflow,
+                st.bins_used[0], st.bins_used[1], st.num_small, small_limit);
         for (int l = 0; l < 8; l++) fprintf(stderr, " %d", st.begin[l]);
         fprintf(stderr, "\n");
         std::vector<BuildNode> hn((size_t)(total < 7 ? total : 7));

@@ -14,6 +14,7 @@
  * RT_EX_SCRATCH_BYTES=<n> overrides the scratch budget of rt_render_ex (forces the chunked path);
  * RT_TILE_ORDER=0 turns the heavy-first dispatch order of single-frame launches off; RT_BVH_LIBRARY_SCAN=1 makes
  * rt_bvh_build use the partition path of meshes above 1 M triangles; RT_BVH_DEBUG=1 prints its phase timings;
+ * RT_BVH_SMALL=k (0..64) lowers the size of the subtrees one wave finishes on its own (0: level loop only; tests);
  * RT_RCCL_LIBRARY=<path> makes rt_comm_* load that library instead of librccl.so.1 (tests: an in-process mock).
  */
 #ifndef RT_HIP_H

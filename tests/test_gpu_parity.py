@@ -646,15 +646,28 @@ def _same_tree(a, b):
     assert np.array_equal(a["tris"].view(np.uint32), b["tris"].view(np.uint32))
 
 
-def test_gpu_bvh_build_matches_host_builder(rt, scenes, blob5k, blob70k, atrium):
-    """rt_bvh_build: the level-parallel GPU build gives the host builder's (= the reference's) tree node
-    for node -- children, leaf lists, bounds, pre-order numbering -- on OBJ meshes, soups, degenerate and deep inputs."""
+@pytest.fixture(params=[None, "0", "7", "33"], ids=["small64", "levels_only", "small7", "small33"])
+def bvh_small_limit(request):
+    """RT_BVH_SMALL: subtrees of at most that many triangles are finished by one wave each (default 64); 0 sends every
+    node through the level loop.  Both paths, and mixtures in between, must give the same tree."""
+    if request.param is None:
+        os.environ.pop("RT_BVH_SMALL", None)
+    else:
+        os.environ["RT_BVH_SMALL"] = request.param
+    yield request.param
+    os.environ.pop("RT_BVH_SMALL", None)
+
+
+def test_gpu_bvh_build_matches_host_builder(rt, scenes, blob5k, blob70k, atrium, bvh_small_limit):
+    """rt_bvh_build: the GPU build (level loop + one wave per small subtree) gives the host builder's
+    (= the reference's) tree node for node -- children, leaf lists, bounds, pre-order numbering -- on OBJ meshes, soups,
+    degenerate and deep inputs."""
     for path in (blob5k, blob70k, atrium):
         host = rt.Mesh.load_obj(path)
         dev = rt.Mesh.load_obj(path, gpu_build=True)
         assert dev.num_nodes == host.num_nodes and dev.max_level == host.max_level
         _same_tree(dev.dump(), host.dump())
-    for seed, n in [(1, 0), (2, 1), (3, 2), (4, 3), (5, 64), (6, 1500)]:
+    for seed, n in [(1, 0), (2, 1), (3, 2), (4, 3), (5, 64), (7, 63), (8, 65), (9, 128), (6, 1500)]:
         tris = sd.random_triangles(n, seed=seed) if n else np.zeros((0, 18), np.float32)
         _same_tree(rt.Mesh.from_triangles(tris, gpu_build=True).dump(), rt.Mesh.from_triangles(tris).dump())
     base = sd.random_triangles(6, seed=3, spread=0.5, size=0.6)
