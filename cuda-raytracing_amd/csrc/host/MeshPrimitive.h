@@ -14,9 +14,15 @@ public:
     int num_triangles;
     BVHTree bvh_top;
     const std::vector<TrianglePrimitive>& triangle_array() const { return triangles; }
-    // deformation with fixed connectivity: replaces the triangles (same count) and refits the BVH bounds; false if the count differs
-    bool refit(std::vector<TrianglePrimitive> moved);
+    // deformation with fixed connectivity: replaces the triangles (same count) and refits the BVH bounds; false if the count differs.
+    // defer_tree = true leaves bvh_top's bounds as they are until sync_tree() -- Scene::refit_mesh does that for an uploaded
+    // scene, whose device copy is refitted by the GPU at once: walking the host tree costs twenty times the device refit
+    // and is only needed if the mesh is uploaded again or bvh_top is read (call sync_tree() first).
+    bool refit(std::vector<TrianglePrimitive> moved, bool defer_tree = false);
+    void sync_tree();
+    bool tree_is_stale() const { return tree_stale; }
 
 private:
     std::vector<TrianglePrimitive> triangles;
+    bool tree_stale = false;
 };

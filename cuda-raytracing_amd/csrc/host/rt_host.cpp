@@ -287,6 +287,7 @@ void Scene::upload_to_device()
     std::vector<Flat> flat(meshes.size());
     std::vector<RtMeshDesc> md(meshes.size());
     for (size_t i = 0; i < meshes.size(); i++) {
+        meshes[i].sync_tree();                                   // (a mesh refitted on the device only: its host tree catches up now)
         const MeshPrimitive& m = meshes[i];
         Flat& f = flat[i];
         const auto& tris = m.triangle_array();
@@ -343,17 +344,26 @@ void Scene::upload_to_device()
     if (last_error) std::cerr << "Scene::upload_to_device: " << rt_error_string(last_error) << std::endl;
 }
 
-bool MeshPrimitive::refit(std::vector<TrianglePrimitive> moved)
+bool MeshPrimitive::refit(std::vector<TrianglePrimitive> moved, bool defer_tree)
 {
     if ((int)moved.size() != num_triangles) return false;
     triangles = std::move(moved);
-    bvh_top.refit(triangles.data(), num_triangles);
+    tree_stale = true;
+    if (!defer_tree) sync_tree();
     return true;
+}
+
+void MeshPrimitive::sync_tree()
+{
+    if (!tree_stale) return;
+    bvh_top.refit(triangles.data(), num_triangles);
+    tree_stale = false;
 }
 
 void Scene::refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream)
 {
-    if (mesh_index < 0 || mesh_index >= (int)meshes.size() || !meshes[(size_t)mesh_index].refit(std::move(moved))) { last_error = RT_E_INVALID; return; }
+    // (an uploaded scene's device copy is refitted below; the host tree catches up when it is next needed)
+    if (mesh_index < 0 || mesh_index >= (int)meshes.size() || !meshes[(size_t)mesh_index].refit(std::move(moved), d_scene != nullptr)) { last_error = RT_E_INVALID; return; }
     if (!d_scene) { last_error = RT_OK; return; }               // not uploaded yet: upload_to_device() will send the moved mesh
     const MeshPrimitive& m = meshes[(size_t)mesh_index];
     std::vector<float> v((size_t)m.num_triangles * 9), n((size_t)m.num_triangles * 3);
