@@ -478,6 +478,28 @@ class Comm:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(libs()[0].rt_comm_init_rank(buf, rank, num_ranks, C.byref(self.h)), "rt_comm_init_rank")
 
+    @classmethod
+    def init_all(cls, devices):
+        """rt_comm_init_all: one process drives every device; returns one Comm per entry of `devices` (rank i on devices[i]).
+        Collectives of several of them issued from one thread must sit between group_start() and group_end()."""
+        n = len(devices)
+        handles = (_vp * n)()
+        check(libs()[0].rt_comm_init_all((C.c_int32 * n)(*devices), n, handles), "rt_comm_init_all")
+        out = []
+        for r in range(n):
+            c = cls.__new__(cls)
+            c.h, c.rank, c.num_ranks = _vp(handles[r]), r, n
+            out.append(c)
+        return out
+
+    @staticmethod
+    def group_start():
+        check(libs()[0].rt_group_start(), "rt_group_start")
+
+    @staticmethod
+    def group_end():
+        check(libs()[0].rt_group_end(), "rt_group_end")
+
     def gather(self, d_send, nbytes, d_recv, root=0, stream=None):
         check(libs()[0].rt_gather(self.h, d_send, nbytes, d_recv, root, stream), "rt_gather")
 

@@ -1093,6 +1093,10 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             s->max_stack = std::max(s->max_stack, max_level);
             // pass 2: emit records
             bool exact_uv = false;
+            records.reserve(records.size() + (size_t)(n_int + n_slot) * 4 + 4);
+            tri_uv.reserve(tri_uv.size() + (size_t)(n_int + n_slot) * 6);
+            tri_id.reserve(tri_id.size() + (size_t)(n_int + n_slot));
+            leaf_count.reserve(leaf_count.size() + (size_t)(n_int + n_slot));
             records.resize(records.size() + (size_t)n_int * 4);
             tri_uv.resize(tri_uv.size() + (size_t)n_int * 6, 0.0f);
             tri_id.resize(tri_id.size() + (size_t)n_int, -1);

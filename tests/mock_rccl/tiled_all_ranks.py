@@ -57,7 +57,51 @@ def main(blob):
         for r in range(n):
             rt.check(h.rt_comm_destroy(comms[r]))
     cases += rotating_groups(h, blob)
+    cases += exchange_objects(h, blob)
     print("OK", cases)
+
+
+def exchange_objects(h, blob):
+    """The same two exchanges through the objects bench.py drives (tiling.RcclExchange on rt.Comm, torch device tensors, torch's
+    current stream): N ranks' to_root() and rotating() calls inside one group, checked against what the exchange is defined
+    to deliver -- gathered[r] = rank r's local buffer; received (source-major) = every source's block for this rank."""
+    import torch
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    cases = 0
+    for n, count, max_rows, pitch in ((2, 4, 5, 96), (3, 5, 7, 33), (8, 3, 2, 48), (8, 32, 3, 24)):
+        comms = rt.Comm.init_all([0] * n)
+        ex = [tiling.RcclExchange(c) for c in comms]
+        slots, counts, offsets, real = tiling.rotating_plan(count, n)
+        local = [torch.randint(0, 256, (slots * max_rows, pitch), dtype=torch.uint8, generator=gen).to(dev) for _ in range(n)]
+        # every frame of a group to rank `root`
+        for root in (0, n - 1):
+            gathered = [torch.zeros((n, slots * max_rows, pitch), dtype=torch.uint8, device=dev) if r == root else None for r in range(n)]
+            rt.Comm.group_start()
+            for r in range(n):
+                ex[r].to_root(local[r], gathered[r], root)
+            rt.Comm.group_end()
+            torch.cuda.synchronize()
+            for r in range(n):
+                assert torch.equal(gathered[root][r], local[r]), ("to_root", n, root, r)
+        # rotating root: slot s of every rank to the rank that assembles it
+        received = [torch.zeros((n * counts[r] * max_rows, pitch), dtype=torch.uint8, device=dev) for r in range(n)]
+        for rep in range(2):                                      # (the second call takes the cached plan)
+            rt.Comm.group_start()
+            for r in range(n):
+                ex[r].rotating(local[r], received[r], count, max_rows)
+            rt.Comm.group_end()
+        torch.cuda.synchronize()
+        for d in range(n):
+            got = received[d].reshape(n, counts[d] * max_rows, pitch)
+            for src in range(n):
+                want = local[src][offsets[d] * max_rows:(offsets[d] + counts[d]) * max_rows]
+                assert torch.equal(got[src], want), ("rotating", n, count, d, src)
+        for c in comms:
+            c.close()
+        cases += 1
+    return cases
 
 
 def rotating_groups(h, blob):
