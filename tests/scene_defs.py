@@ -54,7 +54,8 @@ class SceneDesc:
             s.add_instance(mesh, mat, pose, scale)
         return s
 
-    def build_product(self, rt):
+    def build_product(self, rt, gpu_build=False):
+        """gpu_build: the meshes' trees come from rt_bvh_build instead of the host builder (same tree, so same planes)"""
         s = rt.Scene()
         for mat in self.materials:
             albedo, tex = mat[0], mat[1]
@@ -63,9 +64,9 @@ class SceneDesc:
         self.product_meshes = []
         for kind, arg in self.meshes:
             if kind == "obj":
-                m = rt.Mesh.load_obj(arg)
+                m = rt.Mesh.load_obj(arg, gpu_build=gpu_build)
             elif kind == "tris":
-                m = rt.Mesh.from_triangles(arg)
+                m = rt.Mesh.from_triangles(arg, gpu_build=gpu_build)
             else:
                 m = rt.Mesh.single_triangle(arg)
             self.product_meshes.append(m)
