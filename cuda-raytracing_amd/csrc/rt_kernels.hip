@@ -759,6 +759,31 @@ __global__ void refit_level_kernel(float4* records, const int32_t* __restrict__ 
     q[2] = make_float4(bmn[2], bmx[0], bmx[1], bmx[2]);
 }
 
+// A run of consecutive NARROW levels (the top of every tree, and the thin bottom of a deep one: each a launch of a few dozen
+// threads otherwise) in one launch of one workgroup: level after level with a barrier in between.  Children written by
+// this workgroup are read by this workgroup only, so the barrier orders them.
+constexpr int kRefitRunLevels = 32, kRefitRunThreads = 256;
+struct RefitRun { int32_t levels; int32_t bound[kRefitRunLevels + 1]; };       // level k of the run = sched[bound[k] .. bound[k + 1])
+__global__ __launch_bounds__(kRefitRunThreads) void refit_run_kernel(float4* records, const int32_t* __restrict__ tri_id,
+                                                                   const int32_t* __restrict__ leaf_count, const float* __restrict__ vertices,
+                                                                   const int32_t* __restrict__ sched, const RefitRun run)
+{
+    for (int l = 0; l < run.levels; l++) {
+        for (int i = run.bound[l] + (int)threadIdx.x; i < run.bound[l + 1]; i += kRefitRunThreads) {
+            float4* q = records + (size_t)sched[i] * 4;
+            const float4 q3 = q[3];
+            float amn[3], amx[3], bmn[3], bmx[3];
+            refit_child_box(records, tri_id, leaf_count, vertices, __float_as_int(q3.x), amn, amx);
+            refit_child_box(records, tri_id, leaf_count, vertices, __float_as_int(q3.y), bmn, bmx);
+            q[0] = make_float4(amn[0], amn[1], amn[2], amx[0]);
+            q[1] = make_float4(amx[1], amx[2], bmn[0], bmn[1]);
+            q[2] = make_float4(bmn[2], bmx[0], bmx[1], bmx[2]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // rt_scene_update_instance_async: the new record travels as a kernel argument, so the update is ordered on the stream
 // like any launch and needs no host buffer that outlives the call
 __global__ void set_instance_kernel(DevInstance* dst, const DevInstance value) { *dst = value; }
@@ -1221,35 +1246,73 @@ int rt_scene_update_instance_async(RtScene* s, int32_t index, const RtInstanceDe
     return RT_OK;
 }
 
-int rt_scene_refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, const float* normals, int32_t num_triangles, void* stream)
+namespace {
+int refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, const float* normals, int32_t num_triangles, void* stream, bool on_device)
 {
     if (!s || !vertices || !normals || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size()) return RT_E_INVALID;
     const RtScene::MeshRefit& rf = s->mesh_refit[(size_t)mesh_index];
     if (num_triangles != rf.num_triangles) return RT_E_INVALID;
     if (rf.num_triangles == 0) return RT_OK;
     hipStream_t st = (hipStream_t)stream;
-    const size_t nv = (size_t)rf.num_triangles * 9, nn = (size_t)rf.num_triangles * 3, need = (nv + nn) * sizeof(float);
-    if (s->refit_scratch_bytes < need) {
-        (void)hipFree(s->d_refit_scratch);                      // (synchronises with a refit still in flight)
-        s->d_refit_scratch = nullptr; s->refit_scratch_bytes = 0;
-        RT_HIP(hipMalloc((void**)&s->d_refit_scratch, need));
-        s->refit_scratch_bytes = need;
+    const float* d_v = vertices;
+    const float* d_n = normals;
+    if (!on_device) {
+        const size_t nv = (size_t)rf.num_triangles * 9, nn = (size_t)rf.num_triangles * 3, need = (nv + nn) * sizeof(float);
+        if (s->refit_scratch_bytes < need) {
+            (void)hipFree(s->d_refit_scratch);                  // (synchronises with a refit still in flight)
+            s->d_refit_scratch = nullptr; s->refit_scratch_bytes = 0;
+            RT_HIP(hipMalloc((void**)&s->d_refit_scratch, need));
+            s->refit_scratch_bytes = need;
+        }
+        // (the host arrays may be pageable: the copies return once the bytes are staged, and stay ordered on the stream)
+        RT_HIP(hipMemcpyAsync(s->d_refit_scratch, vertices, nv * sizeof(float), hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(s->d_refit_scratch + nv, normals, nn * sizeof(float), hipMemcpyHostToDevice, st));
+        d_v = s->d_refit_scratch;
+        d_n = s->d_refit_scratch + nv;
     }
-    float* d_v = s->d_refit_scratch;
-    float* d_n = d_v + nv;
-    // (the host arrays may be pageable: the copies return once the bytes are staged, and stay ordered on the stream)
-    RT_HIP(hipMemcpyAsync(d_v, vertices, nv * sizeof(float), hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemcpyAsync(d_n, normals, nn * sizeof(float), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(refit_triangles_kernel, dim3((unsigned)((rf.num_slots + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
                        rf.slot_base, rf.num_slots, d_v, d_n);
+    // deepest level first: children before parents.  A wide level is a launch of its own; consecutive levels of at most
+    // kRefitRunThreads nodes share one single-workgroup launch (a 28-level tree: 10 launches instead of 28 -- with the arrays
+    // already on the device the call is launch-bound)
     int begin = 0;
-    for (int32_t end : rf.level_end) {                           // deepest level first: children before parents
-        hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)((end - begin + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
-                           s->d_leaf_count, d_v, rf.d_sched, begin, end);
+    RefitRun run;
+    run.levels = 0;
+    auto flush = [&] {
+        if (run.levels == 0) return;
+        if (run.levels == 1)
+            hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)((run.bound[1] - run.bound[0] + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
+                               s->d_leaf_count, d_v, rf.d_sched, run.bound[0], run.bound[1]);
+        else
+            hipLaunchKernelGGL(refit_run_kernel, dim3(1), dim3(kRefitRunThreads), 0, st, s->d_records, s->d_tri_id, s->d_leaf_count, d_v, rf.d_sched, run);
+        run.levels = 0;
+    };
+    for (int32_t end : rf.level_end) {
+        if (end - begin > kRefitRunThreads) {
+            flush();
+            hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)((end - begin + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
+                               s->d_leaf_count, d_v, rf.d_sched, begin, end);
+        } else {
+            if (run.levels == kRefitRunLevels) flush();
+            if (run.levels == 0) run.bound[0] = begin;
+            run.bound[++run.levels] = end;
+        }
         begin = end;
     }
+    flush();
     RT_HIP(hipGetLastError());
     return RT_OK;
+}
+}  // namespace
+
+int rt_scene_refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, const float* normals, int32_t num_triangles, void* stream)
+{
+    return refit_mesh(s, mesh_index, vertices, normals, num_triangles, stream, false);
+}
+
+int rt_scene_refit_mesh_device(RtScene* s, int32_t mesh_index, const float* d_vertices, const float* d_normals, int32_t num_triangles, void* stream)
+{
+    return refit_mesh(s, mesh_index, d_vertices, d_normals, num_triangles, stream, true);
 }
 
 int rt_scene_destroy(RtScene* s)

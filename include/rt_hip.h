@@ -136,6 +136,10 @@ int rt_scene_update_instance_async(RtScene *scene, int32_t index, const RtInstan
  * (rt_stream_synchronize, or any later synchronising call).  No counterpart in the reference. */
 int rt_scene_refit_mesh(RtScene *scene, int32_t mesh_index, const float *vertices, const float *normals,
                         int32_t num_triangles, void *stream);
+/* the same with DEVICE arrays (a deformation computed on the GPU: skinning, simulation): no copy, the arrays are read by
+ * kernels ordered on `stream` and must stay untouched until the stream has passed them */
+int rt_scene_refit_mesh_device(RtScene *scene, int32_t mesh_index, const float *d_vertices, const float *d_normals,
+                               int32_t num_triangles, void *stream);
 int rt_scene_destroy(RtScene *scene);
 /* bytes of device memory the scene holds, and the traversal-stack depth it needs */
 int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);

@@ -253,12 +253,25 @@ def test_refit_of_a_deforming_mesh(rt, orc, scenes, blob5k):
             v[..., 1] *= np.float32(1.0 + 0.1 * step)
             for i in range(len(moved)):                         # normals as the 3-vertex constructor computes them
                 moved[i, :12] = o.tri_from_vertices(moved[i, :9])[:12]
+            if step == 2:
+                # the deformation arrives in device memory (rt_scene_refit_mesh_device): same result, no host arrays
+                hl = rt.libs()[0]
+                vert, nrm = np.ascontiguousarray(moved[:, :9]), np.ascontiguousarray(moved[:, 9:12])
+                d_v, d_n = rt.DeviceBuffer(nbytes=vert.nbytes), rt.DeviceBuffer(nbytes=nrm.nbytes)
+                rt.check(hl.rt_memcpy_h2d(d_v.ptr, vert.ctypes.data, vert.nbytes, None))
+                rt.check(hl.rt_memcpy_h2d(d_n.ptr, nrm.ctypes.data, nrm.nbytes, None))
+                rt.check(hl.rt_scene_refit_mesh_device(sp.device_handle, 0, d_v.ptr, d_n.ptr, len(moved), None), "rt_scene_refit_mesh_device")
+                rt.check(hl.rt_device_synchronize())
+                from_device = rt.render_debug(sp, cam)
             sp.refit_mesh(0, moved)
             o.mesh_refit(om, moved)
             ref = so.render(W, H, K, scenes.D_REF, pose, threads=8)
             dbg = rt.render_debug(sp, cam)
             ids = rt.render_ids(sp, cam)
             assert np.array_equal(dbg["img"], ref["img"]) and np.array_equal(ids["img"], ref["img"]), step
+            if step == 2:
+                for n in ("img",) + PLANES:
+                    assert np.array_equal(from_device[n], ref[n]), ("device arrays", n)
             for n in PLANES:
                 assert np.array_equal(dbg[n], ref[n]), (n, step)
             assert np.array_equal(ids["hit_tri"], ref["hit_tri"])

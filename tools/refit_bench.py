@@ -56,5 +56,15 @@ for name in ("blob5k", "blob70k", "atrium"):
         rt.check(h.rt_scene_refit_mesh(sc.device_handle, 0, va[k % 2].ctypes.data_as(C.POINTER(C.c_float)), na[k % 2].ctypes.data_as(C.POINTER(C.c_float)), len(tris), None))
         rt.check(h.rt_device_synchronize())
         tc.append(time.perf_counter() - t0)
+    d_v, d_n = rt.DeviceBuffer(nbytes=va[0].nbytes), rt.DeviceBuffer(nbytes=na[0].nbytes)
+    rt.check(h.rt_memcpy_h2d(d_v.ptr, va[0].ctypes.data, va[0].nbytes, None))
+    rt.check(h.rt_memcpy_h2d(d_n.ptr, na[0].ctypes.data, na[0].nbytes, None))
+    td = []
+    for k in range(10):
+        t0 = time.perf_counter()
+        rt.check(h.rt_scene_refit_mesh_device(sc.device_handle, 0, d_v.ptr, d_n.ptr, len(tris), None))
+        rt.check(h.rt_device_synchronize())
+        td.append(time.perf_counter() - t0)
+    print("%-8s rt_scene_refit_mesh_device (arrays already on the GPU) %.3f ms" % (name, min(td) * 1e3))
     print("%-8s %7d triangles: Scene::refit_mesh %.3f ms, rt_scene_refit_mesh alone %.3f ms (min of 10 each, synchronised); "
           "mesh from triangles (GPU build) %.1f ms + scene upload %.1f ms" % (name, len(tris), min(ts) * 1e3, min(tc) * 1e3, t_mesh * 1e3, (t_build - t_mesh) * 1e3), flush=True)
