@@ -338,8 +338,13 @@ def main():
     # ---- the exchange backend (N > 1): RCCL through the C-ABI, or the gloo rehearsal ----
     comm = exchange = None
     exchange_note = None
+    mock_transport = False
     if dist_on:
-        if rehearsal:
+        # rehearsal with RT_RCCL_LIBRARY set (the tests' shared-memory mock of RCCL, tests/mock_rccl): the ranks share one GPU, torch
+        # talks gloo, and the DATA path is the product's -- RtComm, rt_all_to_all / rt_gather / rt_render_tiled, the pipeline on
+        # its streams -- with only the transport faked.  Rehearsal without it: host-staged exchange through gloo.
+        mock_transport = rehearsal and args.exchange == "rccl" and bool(os.environ.get("RT_RCCL_LIBRARY"))
+        if rehearsal and not mock_transport:
             exchange = tiling.TorchExchange(rank, world)
         else:
             # the product path: RtComm (RCCL through the C-ABI).  If it cannot be created on every rank the run goes on with
@@ -356,7 +361,7 @@ def main():
                     comm = rt.Comm(box[0], rank, world)
                 except rt.RtError as e:
                     err = str(e)
-            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
                 exchange = tiling.RcclExchange(comm)
@@ -364,6 +369,8 @@ def main():
                 if comm is not None:
                     comm.close()
                     comm = None
+                if rehearsal:
+                    sys.exit("bench.py: RT_RCCL_LIBRARY is set but the communicator could not be created: " + err)
                 exchange = tiling.TorchExchange(rank, world, on_device=True)
                 exchange_note = "torch.distributed (nccl backend) instead of rt_comm: " + (err or ("--exchange torch" if args.exchange != "rccl" else "another rank failed to create its RtComm"))
                 log("bench.py rank %d: %s" % (rank, exchange_note))
@@ -393,7 +400,8 @@ def base_line(args, env, value, dt, warmup_done, config, roof, extra):
     world, rehearsal = env["world"], env["rehearsal"]
     out = {"metric": METRIC, "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world}
     if rehearsal:
-        out["REHEARSAL_NOT_A_MEASUREMENT"] = "gloo backend, host-staged exchanges"
+        out["REHEARSAL_NOT_A_MEASUREMENT"] = ("gloo control plane; data path = the C-ABI exchange over the library RT_RCCL_LIBRARY names (the tests' shared-memory mock)"
+                                              if env.get("mock_transport") else "gloo backend, host-staged exchanges")
     if args.force_collective and world == 1:
         out["FORCED_COLLECTIVE_PATH"] = "N > 1 code path run with one rank"
     if env.get("exchange_note"):
@@ -412,7 +420,7 @@ def run_stream(args, env):
     W, H, K, D, pitch, scene, cam, stream, hlib, timer = g["W"], g["H"], g["K"], g["D"], g["pitch"], g["scene"], g["cam"], g["stream"], g["hlib"], g["timer"]
     base_pose, exchange, make_camera = g["base_pose"], g["exchange"], g["make_camera"]
     rotate = dist_on and args.gather in ("auto", "rotate")
-    two = (dist_on or args.two_streams) and not args.one_stream and not rehearsal
+    two = (dist_on or args.two_streams) and not args.one_stream and not (rehearsal and not (exchange is not None and exchange.on_device))
     cstreams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else None
     cams = [make_camera(cstreams[0]), make_camera(cstreams[1])] if two else [cam, cam]
 

@@ -159,6 +159,38 @@ def test_bench_self_launches_two_ranks(workload):
     assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
 
 
+@pytest.fixture(scope="module")
+def mock_rccl(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("mock") / "librccl_mock.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), "-lrt"],
+                   check=True, timeout=600)
+    return so
+
+
+@pytest.mark.parametrize("extra", [["--gpus", "2", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "40", "--warmup", "8"],
+                                   ["--gpus", "4", "--workload", "c2", "--width", "322", "--height", "203", "--steps", "21", "--warmup", "5", "--frames-per-launch", "7"],
+                                   ["--gpus", "3", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "12", "--warmup", "3", "--gather", "root0"],
+                                   ["--gpus", "2", "--workload", "c5", "--width", "480", "--height", "272", "--spp", "2", "--bounces", "1", "--steps", "2", "--warmup", "1"],
+                                   ["--gpus", "4", "--workload", "c3", "--width", "322", "--height", "203", "--spp", "3", "--bounces", "2", "--steps", "3", "--warmup", "1"]])
+def test_bench_ranks_as_processes_over_mock_transport(mock_rccl, extra):
+    """bench.py --gpus N with one process per rank, the ranks sharing the box's GPU: torch.distributed talks gloo, and the data
+    path is the product's own N-rank code -- RtComm from a broadcast id, rt_all_to_all with the rotating plan or rt_gather,
+    rt_unstripe_batch, rt_render_tiled, the double-buffered pipeline on its three streams -- over the tests' shared-memory
+    stand-in for RCCL (real RCCL refuses two ranks on one device).  Every rank compares frames it assembled with the
+    instrumented kernel's; the line must say it is a rehearsal."""
+    env = dict(os.environ, RT_RCCL_LIBRARY=mock_rccl)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--debug-backend", "gloo", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == int(extra[1]) and "RT_RCCL_LIBRARY" in line["REHEARSAL_NOT_A_MEASUREMENT"] and "EXCHANGE_FALLBACK" not in line
+    assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
+    assert "rt_" in line["config"]["parallelism"]
+
+
 def test_cpp_tiled_application(rt, orc, scenes, blob5k, tmp_path):
     """examples/tiled_main.cpp: ONE C++ process, a scene replica and an RCCL communicator per visible GPU
     (rt_comm_init_all), the frame through rt_render_tiled_all -- no Python, no torch in the process.  Its PNG must equal
@@ -189,7 +221,7 @@ def test_tiled_all_with_several_ranks_over_mock_rccl(blob5k, tmp_path):
     closes), loaded through RT_RCCL_LIBRARY in a child process.  What runs for real is the product's N-rank code: stripes of
     every rank, scratch sizing, offsets of the gathered blocks, roots other than 0, ragged last stripes, the un-stripe."""
     mock = str(tmp_path / "librccl_mock.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", mock, os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")],
+    subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", mock, os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), "-lrt"],
                    check=True, timeout=600)
     env = dict(os.environ, RT_RCCL_LIBRARY=mock)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "tiled_all_ranks.py"), blob5k], capture_output=True, text=True,
