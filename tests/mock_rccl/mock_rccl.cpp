@@ -61,7 +61,7 @@ static ncclResult_t flush_p2p()
 {
     // the k-th send of rank s to rank d pairs with the k-th receive of rank d from rank s (NCCL's matching rule)
     if (g_p2p.empty()) return ncclSuccess;
-    if (hipDeviceSynchronize() != hipSuccess) return ncclUnhandledCudaError;
+    for (auto& c : g_p2p) if (hipStreamSynchronize(c.stream) != hipSuccess) return ncclUnhandledCudaError;        // (per stream, like the real library)
     ncclResult_t rc = ncclSuccess;
     for (auto& s : g_p2p) {
         if (!s.send) continue;
@@ -72,20 +72,19 @@ static ncclResult_t flush_p2p()
         r->done = s.done = true;
     }
     for (auto& c : g_p2p) if (!c.done && rc == ncclSuccess) rc = ncclInvalidUsage;                // a receive nobody sends to
+    for (auto& c : g_p2p) if (hipStreamSynchronize(c.stream) != hipSuccess) rc = ncclUnhandledCudaError;
     g_p2p.clear();
-    if (hipDeviceSynchronize() != hipSuccess) return ncclUnhandledCudaError;
     return rc;
 }
 
 static ncclResult_t flush()
 {
-    // every rank's block to the root's buffer; ordered after everything the ranks queued before (one device: a device
-    // synchronise is the simplest correct ordering), then on the root's stream
+    // every rank's block to the root's buffer, on the root's stream, after what each rank queued on ITS stream
     if (g_pending.empty()) return ncclSuccess;
     void* root_recv = nullptr; hipStream_t root_stream = nullptr; int nroot = 0;
     for (auto& g : g_pending) if (g.rank == g.root) { root_recv = g.recv; root_stream = g.stream; nroot++; }
     if (nroot != 1 || !root_recv) { g_pending.clear(); return ncclInvalidUsage; }
-    if (hipDeviceSynchronize() != hipSuccess) return ncclUnhandledCudaError;
+    for (auto& g : g_pending) if (hipStreamSynchronize(g.stream) != hipSuccess) return ncclUnhandledCudaError;    // (per stream, like the real library)
     for (auto& g : g_pending)
         if (hipMemcpyAsync((char*)root_recv + (size_t)g.rank * g.count, g.send, g.count, hipMemcpyDeviceToDevice, root_stream) != hipSuccess) return ncclUnhandledCudaError;
     g_pending.clear();
@@ -164,14 +163,15 @@ static ncclResult_t flush_shm()
     ShmHeader* h = c->shm;
     const int me = c->rank;
     ncclResult_t rc = ncclSuccess;
-    if (hipDeviceSynchronize() != hipSuccess) rc = ncclUnhandledCudaError;       // everything queued before the collective has run
+    // Ordering is per STREAM, as with the real library: only work queued on the stream an operation was given is waited for
+    // (a device-wide synchronise here would hide a missing dependency between the caller's compute and exchange streams).
     char* mine = c->data + (size_t)me * h->region_bytes;
     size_t used = 0;
     for (int d = 0; d < h->n; d++) h->len[me][d] = 0;
     for (auto& o : ops) {
         if (!o.send || rc != ncclSuccess) continue;
         if (h->len[me][o.peer] != 0 || used + o.count > h->region_bytes || o.count == 0) { rc = ncclInvalidUsage; break; }   // one message per pair and group
-        if (hipMemcpy(mine + used, o.buf, o.count, hipMemcpyDeviceToHost) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
+        if (hipMemcpyAsync(mine + used, o.buf, o.count, hipMemcpyDeviceToHost, o.stream) != hipSuccess || hipStreamSynchronize(o.stream) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
         h->off[me][o.peer] = used; h->len[me][o.peer] = o.count;
         used += (o.count + 255) & ~(size_t)255;
     }
@@ -181,7 +181,7 @@ static ncclResult_t flush_shm()
         if (o.send) continue;
         if (h->len[o.peer][me] != o.count) { h->failed.store(1); rc = ncclInvalidUsage; break; }     // counts must agree pairwise (real RCCL hangs or corrupts)
         const char* src = c->data + (size_t)o.peer * h->region_bytes + h->off[o.peer][me];
-        if (hipMemcpy(o.buf, src, o.count, hipMemcpyHostToDevice) != hipSuccess) { h->failed.store(1); rc = ncclUnhandledCudaError; break; }
+        if (hipMemcpyAsync(o.buf, src, o.count, hipMemcpyHostToDevice, o.stream) != hipSuccess || hipStreamSynchronize(o.stream) != hipSuccess) { h->failed.store(1); rc = ncclUnhandledCudaError; break; }
     }
     if (!shm_barrier(c)) return rc != ncclSuccess ? rc : ncclInvalidUsage;       // regions may be overwritten by the next group
     return rc;
