@@ -29,6 +29,7 @@
  *   - float -> uchar stores go through int (x86 cvttss2si then low byte), which is what
  *     g++ emits for raycast.cu:292-294.
  */
+#define _POSIX_C_SOURCE 200809L   /* getline */
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
