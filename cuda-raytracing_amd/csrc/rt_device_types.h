@@ -55,6 +55,10 @@ struct DevMaterial {            // Material.hpp:6-16
     float roughness, metallic;  // read only by the extension kernel (dead in the reference)
 };
 
+// wavefront path queues (ex_wave_kernel): a segment = the 64 slots one wave may push to, a group = exq_k segments
+constexpr int kExMaxGroup = 32;
+constexpr int kExPlanesA = 5, kExPlanesS = 7;
+
 constexpr int kMaxBatch = 32;   // frames per launch (rt_render_batch); 32 x 88 B of per-frame parameters keep the kernel
                                 // arguments under the 4 KB limit
 
@@ -92,6 +96,19 @@ struct RenderParams {
     float4* ex_samples;         // [chunk][local_rows * width] radiance xyz + node pops (int bits) of one sample
     float4* ex_acc;             // [local_rows * width] running sums between chunks
     int32_t* total_pops;
+    // wavefront form of the extension renderer (ex_wave_kernel): path queues between casts, see rt_kernels.hip
+    float4* exq_s;              // shadow-ray items: kExPlanesS planes of exq_nseg * 64 float4
+    float4* exq_a[3];           // bounce-ray items: kExPlanesA planes each; three arrays in rotation (exq_in1 / in2 / out)
+    int32_t* exq_cnt_s;         // [segment] items in the segment (0..64)
+    int32_t* exq_cnt_a[3];
+    int32_t exq_nseg;           // segments per queue array = waves of the primary launch
+    int32_t exq_k;              // segments per group (<= 32): a group's paths stay in the group through every stage
+    int32_t exq_in1, exq_in2;   // A(depth) = the segments of exq_a[in1] (pushed by the cast launch of depth - 1) then those of exq_a[in2]
+                                // (pushed by its shadow launch; -1 = none)
+    int32_t exq_out;            // the exq_a array this launch pushes A(depth + 1) items to
+    int32_t depth;              // depth of the rays this launch casts
+    int32_t gen_samples;        // primary launch: sample indices in this chunk
+    int32_t gen_spw;            // primary launch: sample indices per workgroup (4, 2 or 1: one, two or four 8x8 quads)
     // parity planes (tight [height][width], frame coordinates), any may be null
     int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;
 };

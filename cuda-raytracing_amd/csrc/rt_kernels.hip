@@ -614,6 +614,256 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Wavefront form of the extension renderer (opt-in: RT_EX_WAVEFRONT=1, bounces > 0 or lighting): ONE CAST PER LAUNCH, live paths
+// compacted in between (the hook the reference leaves for this is its commented-out shadow / light pass, raycast.cu:262-287;
+// BASELINE north_star: "wavefront ballot/popc used to compact active rays after the hit test").
+//
+// render_ex_kernel<false> keeps a path in its lane from the primary ray to its last bounce: the lanes of a wave whose
+// paths have ended (sky), or that need no shadow ray, wait for the others at every cast -- 36 of 64 lanes active on the
+// blob with sun + 8 bounces.  Here a path is a queue item between two casts:
+//
+//   depth 0:  ex_wave_kernel<kExGen>      camera ray -> cast -> shade  -+-> sample plane (path ended)
+//   depth d:  ex_wave_kernel<kExShadow>   S(d) item  -> shadow cast -> finish the shade   +-> S(d): needs a shadow ray
+//             ex_wave_kernel<kExBounce>   A(d) item  -> cast -> shade                   -+-> A(d + 1): next bounce
+//
+// Queues without atomics and without losing ray coherence: a wave pushes what its lanes produce, compacted with a
+// ballot / popc prefix, into the 64-slot SEGMENT that belongs to it, and stores the segment's item count.  exq_k
+// consecutive segments form a GROUP; the primary launch orders its waves so that a group is one 8x8-pixel quad (or two
+// neighbouring ones) times many samples.  A queue launch gives every group a workgroup: each wave scans the group's
+// segment counts (one count per lane, a wave prefix sum), then takes every fourth "pass" of 64 consecutive items of
+// the group's concatenated segments -- full waves of rays from the same few pixels, as coherent as primary rays --
+// and pushes to the segment (group, pass).  A group's paths never leave the group, so it never holds more than its
+// exq_k x 64 primary paths: pass < exq_k, slots are fixed by construction, nothing is counted with atomics and the
+// layout of every queue is deterministic.  (A first version with sharded atomic counters mixed rays from unrelated tiles in
+// one wave: full waves, but each piece traversed alone -- 55 ms against the 33 ms of the per-lane kernel.)
+// A(d + 1) is pushed by two launches (the cast launch of depth d directly, its shadow launch for the shaded rest): two
+// segment arrays, concatenated by the reader; the three A arrays rotate (launch_ex).
+// An item is the path state between casts as float4 planes (SoA: a wave's store of one plane is 1 KB contiguous).  The
+// arithmetic of a path is render_ex_kernel's, operation for operation -- per-(pixel, sample) random streams and the
+// index-ordered resolve make the result independent of which lane of which launch ran a cast -- so both forms are
+// bit-identical (tests/test_gpu_parity.py runs them against each other and the oracle).  The state a lane would have to
+// keep across the traversal loop (32 spilled VGPRs in render_ex_kernel) is re-read from the item after the cast instead.
+//
+// Item planes (float4 each; `rng` = the six words of the path's XORWOW stream):
+//   A: 0 = origin, id      1 = direction, pops      2 = weight, rng.d     3 = sample, rng.v0     4 = rng.v1..v4
+//   S: 0 = hit location, id   1 = incoming direction, pops   2..4 as A   5 = base colour, material index   6 = normal
+enum { kExGen = 0, kExBounce = 1, kExShadow = 2 };
+
+__device__ __forceinline__ float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ float4 f4(V3 v, int w) { return make_float4(v.x, v.y, v.z, __int_as_float(w)); }
+__device__ __forceinline__ float4 f4(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 8) void ex_wave_kernel(const RenderParams p)
+{
+    extern __shared__ int lds_stack[];
+    const FrameParams& f = p.frames[0];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t cap = (size_t)p.exq_nseg * 64;                 // slots (float4) per plane
+    const V3 sun = normalize(v3(-0.2f, 0.0f, 1.0f));                                                    // raycast.cu:249-250
+    const V3 sky = v3(1.0f, 0.8f, 0.6f);
+    const int K = p.exq_k;
+
+    int spill[kMaxStack - kLdsStack];
+    Stack stack;
+    stack.lds = (lds_int*)lds_stack + tid; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
+
+    // ---- what this wave reads: GEN = its pixel quad and sample; queue launches = every fourth pass of the group's items ----
+    int pass = MODE == kExGen ? 0 : wave, npass = 1, total = 0, incl = 0, count = 0;
+    const int group = (int)blockIdx.x;
+    const float4* qin = nullptr;
+    if constexpr (MODE != kExGen) {
+        // one segment count per lane: lanes 0..K-1 the group's segments of the first array, lanes 32..32+K-1 of the second
+        const int j = lane & 31, seg = group * K + j;
+        if (j < K && seg < p.exq_nseg) {
+            if constexpr (MODE == kExShadow) { if (lane < 32) count = p.exq_cnt_s[seg]; }
+            else if (lane < 32) count = p.exq_cnt_a[p.exq_in1][seg];
+            else if (p.exq_in2 >= 0) count = p.exq_cnt_a[p.exq_in2][seg];
+        }
+        incl = count;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        total = __builtin_amdgcn_readlane(incl, 63);
+        npass = (total + 63) >> 6;
+        if (npass > K) npass = K;                               // (cannot happen: a group holds at most K x 64 paths)
+        // segments this group will not push to in this launch hold nothing
+        if (wave == 0 && lane >= npass && lane < K && group * K + lane < p.exq_nseg) {
+            if (MODE == kExBounce && p.lighting) p.exq_cnt_s[group * K + lane] = 0;
+            if (p.depth < p.bounces) p.exq_cnt_a[p.exq_out][group * K + lane] = 0;
+        }
+    }
+
+    for (; pass < npass; pass += kBlock / 64) {
+        bool valid;
+        size_t in_slot = 0;
+        int id = 0, pops = 0, out_seg;
+        V3 org = v3(0.0f, 0.0f, 0.0f), dir = v3(0.0f, 0.0f, 0.0f);
+        int x = 0, y = 0, s = 0;
+        if constexpr (MODE == kExGen) {
+            // workgroup = one 8x8-pixel quad x 4 sample indices (wave = sample), or 2 quads x 2 / 4 quads x 1 for chunks of
+            // fewer samples; quads of a 16x16 tile are consecutive, and so are the sample indices of a quad: consecutive
+            // waves -- the groups of the queue launches -- trace nearly the same rays
+            const int spw = p.gen_spw, qpw = 4 / spw;           // samples, quads per workgroup
+            const int per_qg = (p.gen_samples + spw - 1) / spw; // workgroups per set of qpw quads
+            const int quad = ((int)blockIdx.x / per_qg) * qpw + wave / spw, sl = ((int)blockIdx.x % per_qg) * spw + wave % spw;
+            const int tile = quad >> 2, sub = quad & 3;
+            const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+            x = tx * kTile + (sub & 1) * 8 + (lane & 7);
+            const int ly = ty * kTile + (sub >> 1) * 8 + (lane >> 3);
+            valid = x < p.width && ly < p.local_rows && sl < p.gen_samples;
+            y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;    // stripes: local -> frame row
+            s = p.sample_base + sl;
+            id = (int)((size_t)sl * ((size_t)p.local_rows * p.width) + (size_t)ly * p.width + x);
+            out_seg = (int)blockIdx.x * (kBlock / 64) + wave;
+            if (valid) {
+                // stream of (pixel, sample): the reference's per-pixel seed (raycast.cu:190: int idx * 1000) plus the sample index
+                Xorwow rng;
+                xorwow_init(rng, (unsigned long long)((long long)(int32_t)((uint32_t)(y * p.width + x) * 1000u) + (long long)s));
+                float px = (float)x, py = (float)y;
+                if (s > 0) { px = px + (xorwow_uniform(rng) - 0.5f); py = py + (xorwow_uniform(rng) - 0.5f); }
+                org = v3(f.origin[0], f.origin[1], f.origin[2]);
+                dir = camera_direction(f, px, py);
+            }
+        } else {
+            out_seg = group * K + pass;
+            const int i = pass * 64 + lane;                     // item i of the group's concatenated segments
+            valid = i < total;
+            // the segment holding item i = the first lane whose inclusive count exceeds i
+            int lo = 0;
+            for (int step = 32; step > 0; step >>= 1) {
+                const int v = __shfl(incl, lo + step - 1);
+                if (v <= i) lo += step;
+            }
+            lo = lo > 63 ? 63 : lo;
+            const int rank = i - (__shfl(incl, lo) - __shfl(count, lo));
+            const int arr = lo < 32 ? p.exq_in1 : p.exq_in2;
+            qin = MODE == kExShadow ? p.exq_s : p.exq_a[arr < 0 ? 0 : arr];
+            in_slot = ((size_t)(group * K + (lo & 31)) << 6) + (size_t)(valid ? rank : 0);
+            if (valid) {
+                const float4 q0 = qin[in_slot];
+                id = __float_as_int(q0.w);
+                org = v3(q0.x, q0.y, q0.z);
+                if constexpr (MODE == kExBounce) {
+                    const float4 q1 = qin[cap + in_slot];
+                    dir = v3(q1.x, q1.y, q1.z);
+                    pops = __float_as_int(q1.w);
+                } else {
+                    org = org + sun * (float)1e-4;                                  // shadow ray from the hit location, raycast.cu:262-266
+                    dir = sun;
+                }
+            }
+        }
+
+        Hit hit;
+        hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
+        hit.loc = v3(0.0f, 0.0f, 0.0f);
+        if (valid) {
+            if constexpr (MODE == kExShadow) hit = cast_ray_ex<false>(p, org, dir, stack, pops);   // only hit-or-miss survives
+            else hit = cast_ray_ex(p, org, dir, stack, pops);
+        }
+
+        // ---- after the cast: the rest of the path state comes from the item (GEN: from the pixel), not across the loop ----
+        int action = 0;                                         // 1 = path ended, 2 = push S(depth), 3 = push A(depth + 1)
+        V3 weight = v3(1.0f, 1.0f, 1.0f), sample = v3(0.0f, 0.0f, 0.0f);
+        V3 base = v3(0.0f, 0.0f, 0.0f), n = v3(0.0f, 0.0f, 0.0f), loc = v3(0.0f, 0.0f, 0.0f);
+        int mat_index = 0;
+        Xorwow rng;
+        rng.d = 0; rng.v[0] = rng.v[1] = rng.v[2] = rng.v[3] = rng.v[4] = 0;
+        if (valid) {
+            if constexpr (MODE == kExGen) {
+                xorwow_init(rng, (unsigned long long)((long long)(int32_t)((uint32_t)(y * p.width + x) * 1000u) + (long long)s));
+                if (s > 0) { (void)xorwow_next(rng); (void)xorwow_next(rng); }     // the two jitter values drawn above
+            } else {
+                const float4 q2 = qin[2 * cap + in_slot], q3 = qin[3 * cap + in_slot], q4 = qin[4 * cap + in_slot];
+                weight = v3(q2.x, q2.y, q2.z); sample = v3(q3.x, q3.y, q3.z);
+                rng.d = __float_as_uint(q2.w); rng.v[0] = __float_as_uint(q3.w);
+                rng.v[1] = __float_as_uint(q4.x); rng.v[2] = __float_as_uint(q4.y); rng.v[3] = __float_as_uint(q4.z); rng.v[4] = __float_as_uint(q4.w);
+            }
+            float illum = 1.0f;
+            bool shade = false;
+            if constexpr (MODE != kExShadow) {
+                if (hit.min == FLT_MAX) { sample = sample + weight * sky; action = 1; }
+                else {
+                    base = base_colour(p, hit);
+                    n = hit_normal(p, hit);
+                    loc = hit.loc;
+                    mat_index = p.instances[hit.instance].material_index;
+                    shade = true;
+                    if (p.lighting) {                               // raycast.cu:249-287 with the commented lines active
+                        const float cos_illum = dot(n, sun);
+                        illum = (float)(0.4 * (double)cos_illum);
+                        if (dot(n, sun) > 0) { action = 2; shade = false; }
+                    }
+                }
+            } else {
+                const float4 q1 = qin[cap + in_slot], q5 = qin[5 * cap + in_slot], q6 = qin[6 * cap + in_slot];
+                dir = v3(q1.x, q1.y, q1.z);                         // the direction the path arrived with
+                pops += __float_as_int(q1.w);
+                base = v3(q5.x, q5.y, q5.z); mat_index = __float_as_int(q5.w);
+                n = v3(q6.x, q6.y, q6.z);
+                const float4 q0 = qin[in_slot];                     // (org was advanced along the sun: the location comes from the item again)
+                loc = v3(q0.x, q0.y, q0.z);
+                const float cos_illum = dot(n, sun);
+                illum = (float)(0.4 * (double)cos_illum);
+                if (hit.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);
+                shade = true;
+            }
+            if (shade) {
+                illum = fminf(1.0f, illum);                         // raycast.cu:289-290
+                illum = fmaxf(0.4f, illum);
+                const V3 local = v3(illum * base.x, illum * base.y, illum * base.z);
+                const DevMaterial& mat = p.materials[mat_index];
+                const float m = p.depth < p.bounces ? mat.metallic : 0.0f;
+                sample = sample + weight * (local * (1.0f - m));
+                action = 1;
+                if (m > 0.0f) {
+                    weight = weight * (base * m);
+                    const float k = 2.0f * dot(dir, n);
+                    V3 r = dir - n * k;
+                    if (mat.roughness > 0.0f) {
+                        float rx = 2.0f * xorwow_uniform(rng) - 1.0f, ry = 2.0f * xorwow_uniform(rng) - 1.0f, rz = 2.0f * xorwow_uniform(rng) - 1.0f;
+                        r = r + v3(rx, ry, rz) * mat.roughness;
+                    }
+                    r = normalize(r);
+                    org = loc + r * (float)1e-4;
+                    dir = r;
+                    action = 3;
+                }
+            }
+        }
+
+        // ---- push (ballot / popc compaction into this wave's segment) and store: the whole wave arrives here together ----
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (MODE != kExShadow && p.lighting) {
+            const unsigned long long mask = __ballot(action == 2);
+            if (lane == 0) p.exq_cnt_s[out_seg] = __popcll(mask);
+            if (action == 2) {
+                float4* q = p.exq_s + ((size_t)out_seg << 6) + __popcll(mask & below);
+                q[0] = f4(loc, id);
+                q[cap] = f4(dir, pops);
+                q[2 * cap] = f4(weight, rng.d);
+                q[3 * cap] = f4(sample, rng.v[0]);
+                q[4 * cap] = make_float4(__uint_as_float(rng.v[1]), __uint_as_float(rng.v[2]), __uint_as_float(rng.v[3]), __uint_as_float(rng.v[4]));
+                q[5 * cap] = f4(base, mat_index);
+                q[6 * cap] = f4(n, 0.0f);
+            }
+        }
+        if (p.depth < p.bounces) {
+            const unsigned long long mask = __ballot(action == 3);
+            if (lane == 0) p.exq_cnt_a[p.exq_out][out_seg] = __popcll(mask);
+            if (action == 3) {
+                float4* q = p.exq_a[p.exq_out] + ((size_t)out_seg << 6) + __popcll(mask & below);
+                q[0] = f4(org, id);
+                q[cap] = f4(dir, pops);
+                q[2 * cap] = f4(weight, rng.d);
+                q[3 * cap] = f4(sample, rng.v[0]);
+                q[4 * cap] = make_float4(__uint_as_float(rng.v[1]), __uint_as_float(rng.v[2]), __uint_as_float(rng.v[3]), __uint_as_float(rng.v[4]));
+            }
+        }
+        if (action == 1) p.ex_samples[id] = make_float4(sample.x, sample.y, sample.z, __int_as_float(pops));
+    }
+}
+
 // pixel = u8(sum of its samples in index order / spp * 255); a frame with many samples arrives in several chunks of
 // `count` samples, the running sum (and node-pop total) waits in ex_acc in between.
 __global__ void resolve_ex_kernel(const RenderParams p, int count, int first, int last)
@@ -1379,9 +1629,17 @@ int rt_render_debug(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_
     return launch(p, true, (hipStream_t)stream, synchronize);
 }
 
-// Samples are rendered in chunks of as many sample indices as fit the scratch budget (all of them up to 4K x 16 spp):
-// one render_ex_kernel launch with grid.y = chunk, one resolve_ex_kernel.
-constexpr size_t kExScratchBudget = (size_t)2 << 30;
+// Samples are rendered in chunks of as many sample indices as fit the scratch budget: per chunk either one
+// render_ex_kernel launch with grid.y = chunk (samples only, or RT_EX_WAVEFRONT=0), or the wavefront sequence of
+// ex_wave_kernel launches; then one resolve_ex_kernel.
+constexpr size_t kExScratchBudget = (size_t)2 << 30;           // per-lane form: 16 B per path
+constexpr size_t kExWaveScratchBudget = (size_t)16 << 30;      // wavefront form: 16 B + (7 + 3 x 5) x 16 B of queue room per path
+
+static int ex_env_int(const char* name, int fallback)
+{
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : fallback;
+}
 
 static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, int32_t* d_total_pops, hipStream_t stream, int synchronize)
 {
@@ -1391,10 +1649,35 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
     p.tiles_x = (p.width + kTile - 1) / kTile;
     p.tiles_y = (p.local_rows + kTile - 1) / kTile;
     const size_t npix = (size_t)p.local_rows * p.width;
-    size_t budget = kExScratchBudget;
+    const size_t ntiles = (size_t)p.tiles_x * p.tiles_y, nquads = ntiles * 4;
+    const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only: first chunk, per-lane form
+    const bool simple = p.bounces == 0 && !p.lighting;
+    // (read per call, not cached: the parity tests switch between the two forms)
+    // The wavefront form is opt-in (RT_EX_WAVEFRONT=1): measured 37-52 ms against 32.8 ms on the blob with sun + 8 bounces, see
+    // the comment above ex_wave_kernel and profiles/r03_experiments/ex_wavefront.md
+    const bool wavefront = !simple && !trace_file && ex_env_int("RT_EX_WAVEFRONT", 0) != 0;
+    size_t budget = wavefront ? kExWaveScratchBudget : kExScratchBudget;
     if (const char* e = getenv("RT_EX_SCRATCH_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);   // tests: force several chunks
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)p.spp, budget / (npix * sizeof(float4)), (size_t)65535}));
-    const size_t need = (size_t)(chunk + 1) * npix * sizeof(float4);
+    // bytes per sample index: its plane of samples, and for the wavefront form a slot for every path of the plane (tiles
+    // padded to whole quads) in the S queue and in the three A arrays (worst case: no path ends)
+    constexpr size_t kSlotBytes = (kExPlanesS + 3 * kExPlanesA) * sizeof(float4) + 4 * sizeof(int32_t) / 64 + 1;
+    const size_t per_sample = npix * sizeof(float4) + (wavefront ? nquads * 64 * kSlotBytes : 0);
+    // (a chunk's path ids and slot numbers are 32-bit)
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)p.spp, budget / per_sample, (size_t)65535, (((size_t)1 << 31) - 1) / (nquads * 64)}));
+    if (wavefront && chunk >= 4) chunk &= ~3;                   // the primary launch takes sample indices four at a time
+    {                                                           // chunks of equal size
+        const int nchunks = (p.spp + chunk - 1) / chunk;
+        int even = (p.spp + nchunks - 1) / nchunks;
+        if (wavefront && even >= 4) even = (even + 3) & ~3;
+        chunk = std::min(chunk, even);
+    }
+    // the primary launch's workgroup: 4 / 2 / 1 sample indices of 1 / 2 / 4 quads; segments = its waves
+    auto gen_shape = [&](int n, int& spw, size_t& groups) { spw = n >= 4 ? 4 : (n >= 2 ? 2 : 1); groups = nquads / (size_t)(4 / spw) * (size_t)((n + spw - 1) / spw); };
+    int spw_full; size_t gen_full;
+    gen_shape(chunk, spw_full, gen_full);
+    // the queue geometry of a full chunk (the last chunk of a frame may use fewer segments of the same arrays)
+    const size_t max_seg = gen_full * 4, cap = wavefront ? max_seg * 64 : 0;
+    const size_t need = (size_t)(chunk + 1) * npix * sizeof(float4) + cap * (kExPlanesS + 3 * kExPlanesA) * sizeof(float4) + 4 * max_seg * sizeof(int32_t);
     if (s->ex_scratch_bytes < need) {
         (void)hipFree(s->d_ex_scratch);                                             // (synchronises with renders in flight)
         s->d_ex_scratch = nullptr; s->ex_scratch_bytes = 0;
@@ -1404,18 +1687,59 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
     p.ex_acc = s->d_ex_scratch;
     p.ex_samples = s->d_ex_scratch + npix;
     const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int);
-    const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only: first chunk
     for (int base = 0; base < p.spp; base += chunk) {
         const int n = std::min(chunk, p.spp - base);
-        const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)n);
-        const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
-        const bool tracing = trace_file && base == 0;
         p.sample_base = base;
-        if (tracing) RT_HIP(trace_begin(p, trace_n));
-        if (p.bounces == 0 && !p.lighting) hipLaunchKernelGGL(render_ex_kernel<true>, grid, dim3(kBlock), lds, stream, p);
-        else hipLaunchKernelGGL(render_ex_kernel<false>, grid, dim3(kBlock), lds, stream, p);
-        RT_HIP(hipGetLastError());
-        if (tracing) RT_HIP(trace_end(p, trace_n, trace_file, stream));
+        if (wavefront) {
+            int spw; size_t gen_groups;
+            gen_shape(n, spw, gen_groups);
+            const size_t nseg = gen_groups * 4, slots = nseg * 64;
+            if (nseg > max_seg) return RT_E_INVALID;            // (cannot happen: n <= chunk)
+            p.gen_spw = spw;
+            float4* q = p.ex_samples + (size_t)chunk * npix;
+            p.exq_s = q; q += slots * kExPlanesS;
+            for (int k = 0; k < 3; k++) { p.exq_a[k] = q; q += slots * kExPlanesA; }
+            int32_t* c = (int32_t*)(p.ex_samples + (size_t)chunk * npix + cap * (kExPlanesS + 3 * kExPlanesA));
+            p.exq_cnt_s = c; c += nseg;
+            for (int k = 0; k < 3; k++) { p.exq_cnt_a[k] = c; c += nseg; }
+            p.exq_nseg = (int32_t)nseg;
+            p.gen_samples = n;
+            // segments per group: 32 (one quad x 32 samples) unless that leaves the chip short of workgroups
+            int K = std::min(kExMaxGroup, std::max(1, ex_env_int("RT_EX_GROUP", kExMaxGroup)));
+            while (K > 4 && nseg / (size_t)K < 4096) K >>= 1;
+            p.exq_k = K;
+            const dim3 qgrid((unsigned)((nseg + K - 1) / K));
+            // A(d) = segments of a[x] (from the cast launch of d - 1) then of a[y] (from its shadow launch); a[z] is free
+            int ax = 0, ay = 1, az = 2;
+            p.depth = 0; p.exq_in1 = p.exq_in2 = -1; p.exq_out = ax;
+            hipLaunchKernelGGL(ex_wave_kernel<kExGen>, dim3((unsigned)gen_groups), dim3(kBlock), lds, stream, p);
+            RT_HIP(hipGetLastError());
+            if (p.lighting) {
+                p.exq_out = ay;
+                hipLaunchKernelGGL(ex_wave_kernel<kExShadow>, qgrid, dim3(kBlock), lds, stream, p);
+            }
+            for (int d = 1; d <= p.bounces; d++) {
+                p.depth = d;
+                p.exq_in1 = ax; p.exq_in2 = p.lighting ? ay : -1; p.exq_out = az;
+                hipLaunchKernelGGL(ex_wave_kernel<kExBounce>, qgrid, dim3(kBlock), lds, stream, p);
+                if (p.lighting) {
+                    p.exq_out = ax;                             // A(d) has been read: its first array takes the shadow launch's pushes
+                    hipLaunchKernelGGL(ex_wave_kernel<kExShadow>, qgrid, dim3(kBlock), lds, stream, p);
+                }
+                const int nx = az, ny = ax, nz = ay;
+                ax = nx; ay = ny; az = nz;
+            }
+            RT_HIP(hipGetLastError());
+        } else {
+            const dim3 grid((unsigned)ntiles, (unsigned)n);
+            const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
+            const bool tracing = trace_file && base == 0;
+            if (tracing) RT_HIP(trace_begin(p, trace_n));
+            if (simple) hipLaunchKernelGGL(render_ex_kernel<true>, grid, dim3(kBlock), lds, stream, p);
+            else hipLaunchKernelGGL(render_ex_kernel<false>, grid, dim3(kBlock), lds, stream, p);
+            RT_HIP(hipGetLastError());
+            if (tracing) RT_HIP(trace_end(p, trace_n, trace_file, stream));
+        }
         hipLaunchKernelGGL(resolve_ex_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, p, n, base == 0 ? 1 : 0,
                            base + n == p.spp ? 1 : 0);
         RT_HIP(hipGetLastError());

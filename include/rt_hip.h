@@ -12,6 +12,8 @@
  * Environment (diagnostics and tests only): RT_TRACE_FILE=<path> makes every render launch synchronise and write
  * per-wave start / end stamps there (tools/trace_one.py), with RT_TRACE_PROF=1 through a stamped copy of the kernel;
  * RT_EX_SCRATCH_BYTES=<n> overrides the scratch budget of rt_render_ex (forces the chunked path);
+ * RT_EX_WAVEFRONT=1 renders bounces / lighting with one cast per launch and path queues in between (bit-identical, slower
+ * on the measured workloads: DESIGN.md section 3), RT_EX_GROUP=<4..32> sets its queue group size;
  * RT_TILE_ORDER=0 turns the heavy-first dispatch order of single-frame launches off; RT_BVH_LIBRARY_SCAN=1 makes
  * rt_bvh_build use the partition path of meshes above 1 M triangles; RT_BVH_DEBUG=1 prints its phase timings;
  * RT_BVH_SMALL=k (0..64) lowers the size of the subtrees one wave finishes on its own (0: level loop only; tests);

@@ -583,6 +583,49 @@ def test_ex_samples_in_chunks(rt, orc, scenes, blob5k, monkeypatch):
     _compare_ex(rt, orc, sd.shiny_scene(scenes, blob5k), m["width"], m["height"], scenes.scaled_K(m["width"]), m["pose"], 4, 2, 1)
 
 
+@pytest.mark.parametrize("spp,bounces,lighting,size", [(3, 2, 1, (200, 120)), (2, 5, 0, (203, 117)), (5, 0, 1, (64, 48)), (6, 4, 1, (333, 190))])
+def test_ex_wavefront_equals_per_lane_form(rt, orc, scenes, blob5k, monkeypatch, spp, bounces, lighting, size):
+    """The wavefront form (RT_EX_WAVEFRONT=1: one cast per launch, live paths compacted between launches) and the per-lane form
+    (the default: a lane keeps its path from the camera to the last bounce) give the same frame and the same
+    node-pop totals, and both equal the oracle -- also with small queue groups (4 segments), with the samples in chunks
+    of 2 and of 1 (the primary launch's workgroup then covers 2 or 4 pixel quads), and for a rank's stripes."""
+    W, H = size
+    desc = sd.shiny_scene(scenes, blob5k)
+    K, pose = scenes.scaled_K(W), sd.SHINY_CAMERA["pose"]
+    got, ref = _compare_ex(rt, orc, desc, W, H, K, pose, spp, bounces, lighting)
+    sp = desc.build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, sd_D)
+    cam.set_pose(pose)
+    cam.set_options(spp, bounces, lighting)
+    variants = [{"RT_EX_WAVEFRONT": "1"}, {"RT_EX_WAVEFRONT": "1", "RT_EX_GROUP": "4"},
+                {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": str(2 * (W + 16) * (H + 16) * 380)},
+                {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": "1"}]
+    for env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = rt.render_ex(sp, cam)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(other["img"], got["img"]), env
+        assert np.array_equal(other["total_pops"], got["total_pops"]), env
+    # a rank's stripes through the wavefront form
+    monkeypatch.setenv("RT_EX_WAVEFRONT", "1")
+    import importlib
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    world, stripe = 3, 16
+    pitch = W * 3
+    max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+    gathered = rt.DeviceBuffer(nbytes=world * max_rows * pitch)
+    for r in range(world):
+        cam.render_scene_stripes(sp, gathered.ptr.value + r * max_rows * pitch, pitch, stripe, r, world, synchronize=True)
+    out = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    rt.check(h.rt_unstripe(gathered.ptr, pitch, max_rows * pitch, out.ptr, out.pitch, W, H, stripe, world, None))
+    rt.check(h.rt_device_synchronize())
+    assert np.array_equal(out.to_host().reshape(H, W, 3), ref["img"])
+
+
 def test_c3_bunny_64spp_8bounces(rt, orc, scenes, blob70k):
     """BASELINE.json configs[2] shape: the 70k blob, 64 spp, 8 bounces, sun + shadow -- at 480x270 so that the oracle
     finishes in seconds (the semantics are the extension's, parity unpinned)."""
