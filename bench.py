@@ -60,7 +60,8 @@ VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 2 / 1e9     # wave64 VALU instructions per
 L1_PEAK_GBS = 256 * 64 * CLOCK_HZ / 1e9           # vector L1: one 64-B access per CU per clock
 STRIPE_ROWS = 16
 MIN_WARM_FRAMES = 320            # 1-spp stream workloads: untimed frames before the timed region, whatever --warmup asks (see run_stream)
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r03_counters.json")
+_build = importlib.import_module("cuda-raytracing_amd._build")
 
 
 def log(*a):
@@ -195,18 +196,28 @@ def counters_entry(key):
         return None
 
 
-def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_frame=None):
-    """What bounds the kernel.  Instruction and cache-access counts per frame are properties of (scene, camera, size) --
+def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_frame=None, code_hash=None):
+    """What bounds the kernel.  Instruction and cache-access counts per frame are properties of (code, scene, camera, size) --
     the kernel's control flow depends on nothing else -- so they come from the committed PMC pass of the same workload
-    (profiles/r02_counters.json); the time they are divided by is measured live, here.  `share` = the fraction of
-    every frame this rank renders."""
+    (profiles/r03_counters.json); the time they are divided by is measured live, here.  `share` = the fraction of
+    every frame this rank renders.  The counters entry carries the hash of the kernel source and build flags it was taken
+    from (cuda-raytracing_amd/_build.py kernel_code_hash): when that differs from the code running now the instruction
+    count may no longer be this kernel's, so the line says `profile_stale` and prices nothing."""
     e = counters_entry(key)
     sec = kernel_ms * 1e-3
-    out = {"kernel": kernel, "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch, "profile_key": key}
+    now = code_hash if code_hash is not None else _build.kernel_code_hash()
+    out = {"kernel": kernel, "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch, "profile_key": key, "code_hash": now}
     if e is None:
         out.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s", "frac": None,
-                    "traffic": None, "note": "no PMC profile committed for this workload key: only the live kernel time is known"})
+                    "traffic": None, "profile_stale": False,
+                    "note": "no PMC profile committed for this workload key: only the live kernel time is known"})
+    elif e.get("code_hash") != now:
+        out.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s", "frac": None,
+                    "traffic": None, "profile_stale": True, "profile": e.get("tag"), "profile_code_hash": e.get("code_hash"),
+                    "note": "the committed PMC profile of this workload was taken from other kernel code or build flags: re-run "
+                            "tools/profile_bench.sh + tools/summarize_profile.py; only the live kernel time is reported"})
     else:
+        out["profile_stale"] = False
         n = frames_per_launch * share
         valu = e["valu_insts_per_frame"] * n / sec / 1e9
         out.update({"bound": "valu_issue", "achieved": round(valu, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
@@ -583,7 +594,11 @@ def run_stream(args, env):
     single = F == 1 and not dist_on
     roof = roofline("render_kernel<false,false,true>" if single else "render_kernel<false,false,false>", g["key"] + ("_f1" if single else ""),
                     kernel_ms, F, 1.0 / world, alg)
-    extra = {"frame_matches_debug_kernel": frame_ok, "production_hit_ids_match_debug_kernel": ids_ok}
+    # ms_per_step is the throughput figure of a batch (F frames per launch); what one frame takes on its own is spelled out next to it
+    extra = {"frames_per_launch": F,
+             "ms_per_frame_single_launch": None if latency is None else latency["f1_kernel_ms"],
+             "ms_per_frame_reference_loop": None if latency is None else latency["reference_loop_2_renders_per_sync_wall_ms_per_frame"],
+             "frame_matches_debug_kernel": frame_ok, "production_hit_ids_match_debug_kernel": ids_ok}
     value = W * H * args.steps / dt / 1e6
     out = base_line(args, g, value, dt, len(warm_groups) * F, config, roof, extra)
     if not dist_on and not args.no_cpu_baseline:

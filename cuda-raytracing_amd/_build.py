@@ -25,6 +25,22 @@ HIP_DEPS = HIP_SRCS + [os.path.join(CSRC, n) for n in ("rt_math.h", "rt_device_t
 HOST_SRCS = [os.path.join(CSRC, "host", n) for n in ("rt_host.cpp", "rt_host_capi.cpp", "rt_image_io.cpp")]
 
 
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
+
+
+def kernel_code_hash(sources=None, flags=None):
+    """What a committed PMC profile of the render kernels describes: sha256 over the kernel translation unit, the two
+    headers it is built from and the compiler flags.  tools/summarize_profile.py stores it with every counters entry and
+    bench.py refuses to price a roofline fraction with counters taken from other code (`profile_stale`)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in (sources if sources is not None else [os.path.join(CSRC, n) for n in ("rt_kernels.hip", "rt_math.h", "rt_device_types.h")]):
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    h.update(" ".join(flags if flags is not None else HIP_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -55,8 +71,7 @@ def build(force=False, verbose=False):
 
 def _build_locked(force, verbose):
     if force or _stale(HIP_SO, HIP_DEPS):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-               "-o", HIP_SO] + HIP_SRCS
+        cmd = [HIPCC] + HIP_FLAGS + ["-o", HIP_SO] + HIP_SRCS
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

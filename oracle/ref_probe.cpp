@@ -48,6 +48,13 @@ API void ref_lre2homo(const float* l, float* o16) { lre a; memcpy(&a, l, 24); fl
 API void ref_invert_intrinsic(const float* K9, float* o9) { float3x3 k; memcpy(&k, K9, 36); float3x3 r = invert_intrinsic(k); memcpy(o9, &r, 36); }
 API void ref_apply_matrix33(const float* K9, const float* v, float* o) { float3x3 k; memcpy(&k, K9, 36); S3(o, apply_matrix(k, F3(v))); }
 
+// Ray::Ray (Ray.hpp:17-23): origin, direction, direction_inv = 1 / d per component, color (1,1,1), illumination 0
+API void ref_ray_ctor(const float* o, const float* d, float* out13)
+{
+    Ray r(F3(o), F3(d), make_uint2(3, 4));
+    S3(out13, r.origin); S3(out13 + 3, r.direction); S3(out13 + 6, r.direction_inv); S3(out13 + 9, r.color); out13[12] = r.illumination;
+}
+
 API float ref_aabb_ray_intersects(const float* bmin, const float* bmax, const float* o, const float* d)
 {
     Ray r(F3(o), F3(d), make_uint2(0, 0));

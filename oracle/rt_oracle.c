@@ -1103,6 +1103,18 @@ int orc_on_key(float *pose6, int key)
 }
 void orc_lre2homo(const float *l, float *o16) { lre_t a; m44 h; memcpy(&a, l, sizeof a); h = lre2homo(a); memcpy(o16, &h, sizeof h); }
 void orc_invert_intrinsic(const float *K9, float *o9) { m33 k, r; memcpy(&k, K9, sizeof k); r = invert_intrinsic(&k); memcpy(o9, &r, sizeof r); }
+void orc_apply_matrix33(const float *K9, const float *v, float *o)                  /* utils.hpp:134-140 */
+{ m33 k; f3 r; memcpy(&k, K9, sizeof k); r = apply_matrix33(&k, mk3(v[0], v[1], v[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+/* Ray::Ray, Ray.hpp:17-23: what make_ray keeps (origin, direction, direction_inv) and the two constants the shading code
+   assumes of a fresh ray (color 1,1,1 -- raycast.cu:226-244 multiplies by it -- and illumination 0) */
+void orc_ray_ctor(const float *o, const float *d, float *out13)
+{
+    ray_t r = make_ray(mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]));
+    out13[0] = r.origin.x; out13[1] = r.origin.y; out13[2] = r.origin.z;
+    out13[3] = r.direction.x; out13[4] = r.direction.y; out13[5] = r.direction.z;
+    out13[6] = r.direction_inv.x; out13[7] = r.direction_inv.y; out13[8] = r.direction_inv.z;
+    out13[9] = 1.0f; out13[10] = 1.0f; out13[11] = 1.0f; out13[12] = 0.0f;
+}
 float orc_aabb_ray_intersects(const float *bmin, const float *bmax, const float *o, const float *d)
 { ray_t r = make_ray(mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2])); return aabb_ray_intersects(mk3(bmin[0], bmin[1], bmin[2]), mk3(bmax[0], bmax[1], bmax[2]), &r); }
 /* tri18 layout as orc_mesh_from_triangles; out: isect xyz, uv xy */

@@ -50,6 +50,20 @@ def main():
     Ks = np.array([scenes.K_1080, scenes.C1["K"], scenes.scaled_K(3840)], np.float32)
     g["K_in"] = Ks
     g["invert_intrinsic_out"] = np.stack([r.invert_intrinsic(k) for k in Ks])
+    # apply_matrix(float3x3, float3) (utils.hpp:134-140): the first operation of ray generation, K_inv x (x, y, 1) (raycast.cu:161),
+    # on pixel vectors of the three intrinsics above and on random matrices
+    mats = np.concatenate([g["invert_intrinsic_out"].reshape(-1, 9)[[0] * 40 + [1] * 40 + [2] * 40], rng.normal(0, 2, (80, 9)).astype(np.float32)])
+    px = np.concatenate([np.stack([rng.integers(0, 3840, 120), rng.integers(0, 2160, 120), np.ones(120)], 1), rng.normal(0, 50, (80, 3))]).astype(np.float32)
+    g["matrix33_in"] = mats
+    g["matrix33_vec_in"] = px
+    g["apply_matrix33_out"] = np.stack([r.apply_matrix33(m, a) for m, a in zip(mats, px)])
+    # Ray::Ray (Ray.hpp:17-23): direction_inv incl. zero / negative-zero / denormal / huge components
+    ro_ = rng.uniform(-5, 5, (120, 3)).astype(np.float32)
+    rd_ = rng.normal(0, 1, (120, 3)).astype(np.float32)
+    rd_[0] = [0.0, 1.0, -0.0]; rd_[1] = [1e-45, -1e-40, 3e38]; rd_[2] = [-0.0, -0.0, 1.0]; rd_[3::11, 1] = 0.0
+    g["ray_in"] = np.concatenate([ro_, rd_], 1)
+    with np.errstate(all="ignore"):
+        g["ray_ctor_out"] = np.stack([r.ray_ctor(a, b) for a, b in zip(ro_, rd_)])
     # MeshInstance::build_inv: the whole 104-byte struct
     import ctypes as C
     scl = rng.uniform(0.3, 2.0, (poses.shape[0], 3)).astype(np.float32)

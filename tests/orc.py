@@ -71,6 +71,8 @@ class _Lib:
     def apply_lre(self, l, v): return self._v("apply_lre", l, v, n_out=3)
     def lre2homo(self, l): return self._v("lre2homo", l, n_out=16)
     def invert_intrinsic(self, K): return self._v("invert_intrinsic", K, n_out=9)
+    def apply_matrix33(self, K, v): return self._v("apply_matrix33", K, v, n_out=3)
+    def ray_ctor(self, o, d): return self._v("ray_ctor", o, d, n_out=13)
     def tri_test(self, tri18, o, d): return self._v("tri_test", tri18, o, d, n_out=5)
     def tri_from_vertices(self, abc9): return self._v("tri_from_vertices", abc9, n_out=18)
     def tri_center(self, tri18): return self._v("tri_center", tri18, n_out=3)

@@ -835,8 +835,9 @@ def test_fuzz_random_scenes(rt, orc, scenes, blob5k, seed):
 
 
 @pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("RT_FUZZ_SEEDS", 4)) // 3)))
-def test_fuzz_extension_modes(rt, orc, scenes, blob5k, seed):
-    """Random spp / bounces / lighting, random metallic / roughness, rotated and scaled instances: extension kernel vs oracle."""
+def test_fuzz_extension_modes(rt, orc, scenes, blob5k, seed, monkeypatch):
+    """Random spp / bounces / lighting, random metallic / roughness, rotated and scaled instances: extension kernel vs oracle,
+    and its wavefront form (RT_EX_WAVEFRONT=1) vs both."""
     rng = np.random.default_rng(7000 + seed)
     mats = [(tuple(rng.uniform(0.1, 1, 3)), sd.checker_texture(16, 12, seed=seed) if rng.random() < 0.5 else None,
              dict(roughness=float(rng.choice([0.0, 0.05, 0.3])), metallic=float(rng.choice([0.0, 0.3, 0.8])))) for _ in range(3)]
@@ -844,8 +845,11 @@ def test_fuzz_extension_modes(rt, orc, scenes, blob5k, seed):
     inst = [(int(rng.integers(2)), int(rng.integers(3)), tuple(np.concatenate([rng.uniform(-1.2, 1.2, 3), rng.uniform(-1, 1, 3)])),
              tuple(rng.uniform(0.5, 1.4, 3))) for _ in range(3)]
     W, H = 96, 64
-    _compare_ex(rt, orc, sd.SceneDesc(mats, meshes, inst), W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02),
-                int(rng.integers(1, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 2)))
+    opts = (int(rng.integers(1, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 2)))
+    desc = sd.SceneDesc(mats, meshes, inst)
+    _compare_ex(rt, orc, desc, W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02), *opts)
+    monkeypatch.setenv("RT_EX_WAVEFRONT", "1")
+    _compare_ex(rt, orc, desc, W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02), *opts)
 
 
 def test_million_triangle_mesh(rt, orc, scenes, tmp_path):

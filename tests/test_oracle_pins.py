@@ -51,6 +51,18 @@ def test_l0_math_golden(oracle, g):
     assert same(np.stack([o.invert_intrinsic(k) for k in g["K_in"]]), g["invert_intrinsic_out"])
 
 
+def test_ray_generation_pins(oracle, g):
+    """The two reference operations that open the path and were only pinned indirectly before: apply_matrix(float3x3, float3)
+    (utils.hpp:134-140; K_inv x (x, y, 1), raycast.cu:161) and the Ray constructor (Ray.hpp:17-23: direction_inv = 1 / d,
+    also for zero, negative-zero, denormal and huge components; color (1,1,1), illumination 0)."""
+    o = oracle
+    assert same(np.stack([o.apply_matrix33(m, v) for m, v in zip(g["matrix33_in"], g["matrix33_vec_in"])]), g["apply_matrix33_out"])
+    R = g["ray_in"]
+    got = np.stack([o.ray_ctor(r[:3], r[3:]) for r in R])
+    assert same(got, g["ray_ctor_out"])
+    assert np.isinf(g["ray_ctor_out"][0, 6]) and np.signbit(g["ray_ctor_out"][0, 8])       # 1 / 0 = +inf, 1 / -0 = -inf
+
+
 def test_survey_kats(oracle):
     """SURVEY.md section 4 known-answer rows."""
     o = oracle
@@ -197,6 +209,9 @@ def test_oracle_vs_reference_live(orc, oracle):
         t = oracle.tri_from_vertices(rng.uniform(-1, 1, 9).astype(np.float32))
         assert same(t[:12], r.tri_from_vertices(t[:9])[:12])
         assert same(oracle.tri_test(t, o3, d3), r.tri_test(t, o3, d3))
+        m9 = rng.normal(0, 2, 9).astype(np.float32)
+        assert same(oracle.apply_matrix33(m9, v), r.apply_matrix33(m9, v))
+        assert same(oracle.ray_ctor(o3, d3), r.ray_ctor(o3, d3))
 
 
 def test_oracle_bvh_vs_reference_live(orc, oracle):

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""One-off differential fuzz campaign on the GPU box: tests/test_gpu_parity.py::test_fuzz_random_scenes with N seeds (scene
+`seed` is numpy default_rng(1000 + seed)) and ::test_fuzz_extension_modes with N // 3 seeds (default_rng(7000 + seed), per-lane and
+wavefront form), every case against the CPU oracle on all parity planes.  Writes the seeds and the result as JSON so that a
+campaign is a reproducible artifact (profiles/rNN_experiments/fuzz_campaign.json), not a line in a log.
+   python tools/fuzz_campaign.py <n_seeds> <out.json>"""
+import importlib, json, os, subprocess, sys, time
+import xml.etree.ElementTree as ET
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+n, out = int(sys.argv[1]), sys.argv[2]
+xml = out + ".junit.xml"
+env = dict(os.environ, RT_FUZZ_SEEDS=str(n))
+t0 = time.time()
+r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-k", "fuzz",
+                    "--junitxml", xml, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True)
+cases = list(ET.parse(xml).getroot().iter("testcase"))
+bad = [c.get("name") for c in cases if any(ch.tag in ("failure", "error") for ch in c)]
+skipped = [c.get("name") for c in cases if any(ch.tag == "skipped" for ch in c)]
+res = {"campaign": "differential fuzz, HIP path vs CPU oracle, all parity planes", "date": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
+       "kernel_code_hash": importlib.import_module("cuda-raytracing_amd._build").kernel_code_hash(),
+       "test_fuzz_random_scenes": {"seeds": [0, n], "rng": "numpy.random.default_rng(1000 + seed)", "gpu_built_tree": "seed % 3 == 2"},
+       "test_fuzz_extension_modes": {"seeds": [0, max(4, n // 3)], "rng": "numpy.random.default_rng(7000 + seed)", "forms": ["per-lane", "wavefront"]},
+       "cases": len(cases), "passed": len(cases) - len(bad) - len(skipped), "failed": bad, "skipped": skipped,
+       "pytest_exit_code": r.returncode, "pytest_summary": r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "", "seconds": round(time.time() - t0, 1)}
+json.dump(res, open(out, "w"), indent=1)
+os.remove(xml)
+print(json.dumps({k: res[k] for k in ("cases", "passed", "failed", "pytest_summary", "seconds")}))
+sys.exit(0 if r.returncode == 0 and not bad else 1)

@@ -2,15 +2,19 @@
 """Turns a tools/profile_bench.sh output directory into the committed summaries under profiles/:
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
   profiles/<tag>_bench_line.json    the line bench.py printed under the profiler
-  profiles/r02_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME
+  profiles/r03_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
+                                    hash of the kernel source + build flags they were taken from (bench.py checks it)
 A frame = width x height x spp primary rays.  A dispatch of G work-items renders G / (tiles * 256 * spp) frames (one 256-thread
 workgroup per 16x16 tile per frame of the batch, or per sample of the frame), so counters are summed over every dispatch of
 the kernel and divided by the frames those dispatches rendered: the result does not depend on --steps or frames per launch.
    python tools/summarize_profile.py <profdir> <tag>"""
 import collections, csv, glob, json, os, shutil, sys
 
+import importlib
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+code_hash = importlib.import_module("cuda-raytracing_amd._build").kernel_code_hash()
 dst = os.path.join(ROOT, "profiles")
 bench_line = None
 for line in open(os.path.join(src, "stats.log"), errors="ignore"):
@@ -40,7 +44,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if kernel in r["Kernel_Name"]:
             frames_by_pass[r["Counter_Name"]] = frames
 pf = {k: v / frames_by_pass[k] for k, v in tot.items() if frames_by_pass.get(k)}
-entry = {"tag": tag, "kernel": kernel, "dispatch": meta, "frames_profiled": {k: round(v, 2) for k, v in frames_by_pass.items()},
+entry = {"tag": tag, "code_hash": code_hash, "kernel": kernel, "dispatch": meta, "frames_profiled": {k: round(v, 2) for k, v in frames_by_pass.items()},
          "per_frame": pf, "bench_line_under_rocprof": {k: bench_line[k] for k in ("value", "ms_per_step", "steps")}}
 if "SQ_INSTS_VALU" in pf:
     entry["valu_insts_per_frame"] = pf["SQ_INSTS_VALU"]
@@ -70,10 +74,20 @@ if kt:
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-json.dump(bench_line, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
-tp = os.path.join(dst, "r02_counters.json")
+tp = os.path.join(dst, "r03_counters.json")
 out = json.load(open(tp)) if os.path.exists(tp) else {}
 out[key] = entry
 json.dump(out, open(tp, "w"), indent=1, sort_keys=True)
+# The line was printed before these counters existed: price its roofline block now, with bench.py's own function, from the
+# kernel time the line measured under the profiler and the counters of the same profiling run.
+import bench
+old = bench_line["roofline"]
+alg = old.get("hbm_algorithmic", {}).get("bytes_per_launch")
+share = 1.0 / bench_line.get("n_gpus", 1)
+roof = bench.roofline(old["kernel"], key, old["kernel_ms"], old["frames_per_launch"], share,
+                      None if alg is None else alg / (old["frames_per_launch"] * share))
+roof["filled_by"] = "tools/summarize_profile.py from the PMC passes of the same profiling run"
+bench_line["roofline"] = roof
+json.dump(bench_line, open(os.path.join(dst, "%s_bench_line.json" % tag), "w"), indent=1)
 print(key, json.dumps({k: entry.get(k) for k in ("valu_insts_per_frame", "lanes_active_per_valu", "tcp_accesses_per_frame", "hbm_bytes_per_frame",
                                                   "valu_issue_frac_under_profiler", "frames_profiled")}, indent=0))
