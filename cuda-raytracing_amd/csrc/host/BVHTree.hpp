@@ -7,6 +7,8 @@
 // binning pass instead of 15 partition passes.
 #pragma once
 #include <cstdint>
+#include <string>
+#include <utility>
 #include <vector>
 #include "TrianglePrimitive.hpp"
 
@@ -30,6 +32,25 @@ public:
     void refit(const TrianglePrimitive* triangles, int num_triangles);
     int max_level() const { return levels_; }
     void print_stats() const;                      // same report as BVHTree.hpp:117-172
+
+    // ---- the reference's per-node queries (BVHTree.hpp:175-201, :294-361) on the flat tree: a node is named by its index ----
+    // (the builder itself does not call them: it gets all fifteen candidate costs of a node from one binning pass;
+    // tests/test_host_logic.py checks that both give the same numbers)
+    void grow_to_include(int node, float3 vertex);                                      // BVHTree.hpp:183-190
+    void grow_to_include(int node, const TrianglePrimitive& triangle);                  // BVHTree.hpp:175-181
+    float cost(int node) const;                                                         // BVHTree.hpp:192-201: half area x triangle count
+    // best of the five candidate planes of `axis` ("x", "y", anything else = z): {cost, split position}, BVHTree.hpp:294-361
+    std::pair<float, float> evaluate_split(int node, const std::string& axis, const TrianglePrimitive* triangles) const;
+    // The arrays the device upload takes (the role of compile_tree / to_device_compatible, BVHTree.hpp:364-383, whose
+    // device-side form is an array of d_BVHTree with per-leaf index lists): per node bounds, children, leaf range; and the
+    // leaf index list.  Exactly what RtMeshDesc of include/rt_hip.h points at; Scene::upload_to_device uses it.
+    struct DeviceCompatible {
+        std::vector<float> node_bounds;            // [node][min xyz, max xyz]
+        std::vector<int32_t> node_children;        // [node][a, b], -1 -1 = leaf
+        std::vector<int32_t> node_leaf_first, node_leaf_count;
+        std::vector<int32_t> leaf_indices;
+    };
+    DeviceCompatible to_device_compatible() const;
 
 private:
     void fill(int self, int depth, int max_depth);

@@ -144,6 +144,66 @@ void BVHTree::fill(int self, int depth, int max_depth)
     fill(b, depth + 1, max_depth);
 }
 
+void BVHTree::grow_to_include(int node, float3 v)
+{
+    BVHNode& n = nodes[(size_t)node];
+    n.min = make_float3(fminf(n.min.x, v.x), fminf(n.min.y, v.y), fminf(n.min.z, v.z));
+    n.max = make_float3(fmaxf(n.max.x, v.x), fmaxf(n.max.y, v.y), fmaxf(n.max.z, v.z));
+}
+void BVHTree::grow_to_include(int node, const TrianglePrimitive& t) { for (int k = 0; k < 3; k++) grow_to_include(node, t.vertices[k]); }
+
+float BVHTree::cost(int node) const
+{
+    const BVHNode& n = nodes[(size_t)node];
+    Box b;
+    b.mn[0] = n.min.x; b.mn[1] = n.min.y; b.mn[2] = n.min.z; b.mx[0] = n.max.x; b.mx[1] = n.max.y; b.mx[2] = n.max.z;
+    return box_cost(b, (size_t)n.count);
+}
+
+// The reference's own way (BVHTree.hpp:294-361): for each of the five planes partition the node's triangles by centroid,
+// grow a left and a right box vertex by vertex, add the two costs.
+std::pair<float, float> BVHTree::evaluate_split(int node, const std::string& axis, const TrianglePrimitive* triangles) const
+{
+    const BVHNode& n = nodes[(size_t)node];
+    const int ax = axis == "x" ? 0 : (axis == "y" ? 1 : 2);
+    const float lo[3] = {n.min.x, n.min.y, n.min.z}, hi[3] = {n.max.x, n.max.y, n.max.z};
+    float best_cost = FLT_MAX, best_split = 0.0f;
+    for (int s = 0; s < 5; s++) {
+        const float split_t = ((float)s + 1) / (5.0f + 1);
+        const float pos = lo[ax] + (hi[ax] - lo[ax]) * (split_t);
+        Box left, right;
+        size_t nl = 0, nr = 0;
+        for (int i = 0; i < n.count; i++) {
+            const TrianglePrimitive& t = triangles[order[(size_t)(n.first + i)]];
+            const float3 c = t.center();
+            const float check = ax == 0 ? c.x : (ax == 1 ? c.y : c.z);
+            Box& side = check <= pos ? left : right;
+            (check <= pos ? nl : nr)++;
+            for (int k = 0; k < 3; k++) { const float v[3] = {t.vertices[k].x, t.vertices[k].y, t.vertices[k].z}; side.grow(v, v); }
+        }
+        const float c = box_cost(left, nl) + box_cost(right, nr);
+        if (c < best_cost) { best_cost = c; best_split = pos; }
+    }
+    return std::make_pair(best_cost, best_split);
+}
+
+BVHTree::DeviceCompatible BVHTree::to_device_compatible() const
+{
+    DeviceCompatible f;
+    f.node_bounds.resize(nodes.size() * 6); f.node_children.resize(nodes.size() * 2);
+    f.node_leaf_first.resize(nodes.size()); f.node_leaf_count.resize(nodes.size());
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const BVHNode& nd = nodes[k];
+        f.node_bounds[6 * k] = nd.min.x; f.node_bounds[6 * k + 1] = nd.min.y; f.node_bounds[6 * k + 2] = nd.min.z;
+        f.node_bounds[6 * k + 3] = nd.max.x; f.node_bounds[6 * k + 4] = nd.max.y; f.node_bounds[6 * k + 5] = nd.max.z;
+        f.node_children[2 * k] = nd.child_index_a; f.node_children[2 * k + 1] = nd.child_index_b;
+        const bool leaf = nd.child_index_a == -1 && nd.child_index_b == -1;             // BVHTree.hpp:100
+        f.node_leaf_first[k] = nd.first; f.node_leaf_count[k] = leaf ? nd.count : 0;
+    }
+    f.leaf_indices.assign(order.begin(), order.end());
+    return f;
+}
+
 void BVHTree::refit(const TrianglePrimitive* triangles, int n)
 {
     tris_ = triangles;
@@ -283,7 +343,7 @@ static RtInstanceDesc to_desc(const MeshInstance& in)
 void Scene::upload_to_device()
 {
     if (d_scene) { rt_scene_destroy(d_scene); d_scene = nullptr; }     // Scene.cpp:28-39
-    struct Flat { std::vector<float> v, n, uv, bounds; std::vector<int32_t> child, lfirst, lcount, leaf; };
+    struct Flat { std::vector<float> v, n, uv; BVHTree::DeviceCompatible tree; };
     std::vector<Flat> flat(meshes.size());
     std::vector<RtMeshDesc> md(meshes.size());
     for (size_t i = 0; i < meshes.size(); i++) {
@@ -299,24 +359,14 @@ void Scene::upload_to_device()
             }
             f.n[3 * t] = tris[t].normal.x; f.n[3 * t + 1] = tris[t].normal.y; f.n[3 * t + 2] = tris[t].normal.z;
         }
-        const auto& nodes = m.bvh_top.nodes;
-        f.bounds.resize(nodes.size() * 6); f.child.resize(nodes.size() * 2); f.lfirst.resize(nodes.size()); f.lcount.resize(nodes.size());
-        for (size_t k = 0; k < nodes.size(); k++) {
-            const BVHNode& nd = nodes[k];
-            f.bounds[6 * k] = nd.min.x; f.bounds[6 * k + 1] = nd.min.y; f.bounds[6 * k + 2] = nd.min.z;
-            f.bounds[6 * k + 3] = nd.max.x; f.bounds[6 * k + 4] = nd.max.y; f.bounds[6 * k + 5] = nd.max.z;
-            f.child[2 * k] = nd.child_index_a; f.child[2 * k + 1] = nd.child_index_b;
-            const bool leaf = nd.child_index_a == -1 && nd.child_index_b == -1;         // BVHTree.hpp:100
-            f.lfirst[k] = nd.first; f.lcount[k] = leaf ? nd.count : 0;
-        }
-        f.leaf.assign(m.bvh_top.order.begin(), m.bvh_top.order.end());
+        f.tree = m.bvh_top.to_device_compatible();                // BVHTree.hpp:364-383
         RtMeshDesc& d = md[i];
         d.num_triangles = m.num_triangles;
         d.vertices = f.v.data(); d.normals = f.n.data(); d.uvs = f.uv.data();
-        d.num_nodes = (int32_t)nodes.size();
-        d.node_bounds = f.bounds.data(); d.node_children = f.child.data();
-        d.node_leaf_first = f.lfirst.data(); d.node_leaf_count = f.lcount.data();
-        d.num_leaf_indices = (int32_t)f.leaf.size(); d.leaf_indices = f.leaf.data();
+        d.num_nodes = (int32_t)m.bvh_top.nodes.size();
+        d.node_bounds = f.tree.node_bounds.data(); d.node_children = f.tree.node_children.data();
+        d.node_leaf_first = f.tree.node_leaf_first.data(); d.node_leaf_count = f.tree.node_leaf_count.data();
+        d.num_leaf_indices = (int32_t)f.tree.leaf_indices.size(); d.leaf_indices = f.tree.leaf_indices.data();
     }
     std::vector<RtMaterialDesc> mat(materials.size());
     for (size_t i = 0; i < materials.size(); i++) {

@@ -49,4 +49,33 @@ inline void print(const lre& l) { std::cout << l.x << ", " << l.y << ", " << l.z
 inline void print(const float3 v) { std::cout << v.x << ", " << v.y << ", " << v.z << std::endl; }
 inline void print(const float4 v) { std::cout << v.x << ", " << v.y << ", " << v.z << ", " << v.w << std::endl; }
 
+// transforms.hpp:238-290: the reference's self-check of the pose algebra (commented out at the top of its main(),
+// kernel.cu:142): a pose, its homogeneous matrix, the inverse, the inverse pose, and a vector taken through them
+inline void test_all()
+{
+    float3 v = make_float3(6, -2, 5);
+    lre l = lre();
+    l.y = 10;
+    l.pitch = 0.5;
+    std::cout << "lre in: \n";
+    print(l);
+    float4x4 homo = lre2homo(l);
+    std::cout << "homo: \n";
+    print(homo);
+    float4x4 homo_inv = invert_homo(homo);
+    std::cout << "inverted: \n";
+    print(homo_inv);
+    lre l_inv = homo2lre(homo_inv);
+    std::cout << "lre inv: \n";
+    print(l_inv);
+    float3 subtracted = make_float3(v.x - l_inv.x, v.y - l_inv.y, v.z - l_inv.z);
+    std::cout << "subtracted: \n";
+    print(subtracted);
+    float4 quat = euler2quat(make_float3(l_inv.yaw, l_inv.pitch, l_inv.roll));
+    std::cout << "Quat: \n";
+    print(quat);
+    float3 v_appl = apply_quat(quat, subtracted);
+    std::cout << "vec out: " << v_appl.x << ", " << v_appl.y << ", " << v_appl.z << std::endl;
+}
+
 }  // namespace transforms
