@@ -68,7 +68,7 @@ RT_HIP_SYMBOLS = [
     "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
-    "rth_obj_load", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
+    "rth_obj_load", "rth_obj_parse", "rth_scan_float", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
     "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
     "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
     "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance", "rth_scene_update_mesh_instance_async", "rth_scene_refit_mesh",
@@ -156,7 +156,7 @@ def _declare(h, s):
     h.rt_timer_destroy.argtypes = [_vp]
 
     s.rth_last_error.restype = C.c_char_p
-    for n in ("rth_obj_load", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
+    for n in ("rth_obj_load", "rth_obj_parse", "rth_scan_float", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
               "rth_scene_device_handle"):
         getattr(s, n).restype = _vp
     s.rth_obj_load.argtypes = [C.c_char_p]

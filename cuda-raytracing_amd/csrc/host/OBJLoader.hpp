@@ -14,6 +14,8 @@ namespace OBJLoader {
 // lenient = true additionally accepts `v//vn` (no texture index) and negative (relative) indices as the OBJ
 // format defines them: -1 is the most recent `v` / `vt` record before the face line.
 bool parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error, bool lenient = false);
+// The float scanner of parse() on one token (std::stof semantics, correctly rounded like strtof; exposed for tests)
+bool scan_float_token(const char* begin, const char* end, float& out);
 // parse(lenient = true) + MeshPrimitive; throws std::runtime_error on failure
 MeshPrimitive load_lenient(std::string fp);
 // Reference behaviour: prints the progress lines, and on an unreadable file prints

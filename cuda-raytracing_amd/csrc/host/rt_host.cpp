@@ -1,6 +1,10 @@
 // rt_host.cpp -- implementation of the host C++ API (Scene / Camera / OBJLoader / MeshPrimitive /
 // BVHTree / Material).  Pure host code: talks to the GPU only through the C-ABI of
 // include/rt_hip.h.  Built with -ffp-contract=off like every file that touches rt_math.h.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cctype>
 #include <cfloat>
 #include <cstdio>
@@ -11,6 +15,7 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 #include "../../../include/rt_hip.h"
 #include "Camera.h"
@@ -595,113 +600,350 @@ int save_png(const char* path, const uchar3* d_img, int width, int height, size_
 // ----------------------------------------------------------------------------- OBJLoader
 
 namespace {
-// std::stoi semantics on a token prefix: optional sign + digits, anything after is ignored
-bool lead_int(const char* s, int& out)
+// ---- scanner over the memory-mapped file: no stream, no per-token std::string, no strtof in the common case ----
+inline bool is_space(unsigned char c) { return c == ' ' || (unsigned)(c - '\t') <= (unsigned)('\r' - '\t'); }     // isspace() in the "C" locale
+
+// std::stoi semantics on [p, end): optional sign + digits, anything after is ignored; false if there is no digit or the
+// value does not fit an int (stoi throws in both cases)
+inline bool scan_int(const char* p, const char* end, int& out)
 {
-    char* end = nullptr;
-    long v = strtol(s, &end, 10);
-    if (end == s) return false;
+    bool neg = false;
+    if (p < end && (*p == '+' || *p == '-')) { neg = *p == '-'; p++; }
+    if (p >= end || *p < '0' || *p > '9') return false;
+    long long v = 0;
+    while (p < end && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > (1LL << 31)) return false; p++; }
+    if (neg) v = -v;
+    if (v > 2147483647LL || v < -2147483648LL) return false;
     out = (int)v;
     return true;
+}
+
+// the same, moving p past the sign and digits it consumed
+inline bool scan_int_prefix(const char*& p, const char* end, int& out)
+{
+    const char* q = p;
+    bool neg = false;
+    if (q < end && (*q == '+' || *q == '-')) { neg = *q == '-'; q++; }
+    if (q >= end || (unsigned)(*q - '0') > 9u) return false;
+    long long v = 0;
+    while (q < end && (unsigned)(*q - '0') <= 9u) { v = v * 10 + (*q - '0'); if (v > (1LL << 31)) return false; q++; }
+    if (neg) v = -v;
+    if (v > 2147483647LL || v < -2147483648LL) return false;
+    out = (int)v;
+    p = q;
+    return true;
+}
+
+const float kPow10f[11] = {1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+const double kPow10d[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// std::stof semantics on the token [p, end): the float nearest to the decimal value of the longest numeric prefix (what
+// glibc's strtof returns: correctly rounded, ties to even).  Decimal digits are gathered exactly; then
+//   * at most 7 significant digits and |exponent| <= 10 (every number a "%.6f" file holds): float(m) and 10^k are exact in
+//     fp32, so ONE fp32 multiplication or division rounds the exact value once -- the correctly rounded result;
+//   * up to 19 digits and |exponent| <= 22: the same in double (exact operands, one rounding), then double -> float.  Two
+//     roundings could differ from one only if the double landed exactly on the midpoint of two floats; that case falls
+//     through;
+//   * everything else (longer mantissas, huge exponents, inf / nan / hex) goes to strtof on a bounded copy of the token.
+// false = no conversion (stof would throw).
+bool scan_float(const char* p, const char* end, float& out)
+{
+    const char* const tok = p;
+    bool neg = false;
+    if (p < end && (*p == '+' || *p == '-')) { neg = *p == '-'; p++; }
+    unsigned long long m = 0;
+    int digits = 0, sig = 0, e10 = 0;
+    bool any = false, exact = true;
+    if (p + 1 < end && p[0] == '0' && (p[1] == 'x' || p[1] == 'X')) exact = false;    // hexadecimal float: strtof's business
+    while (p < end && *p >= '0' && *p <= '9') {
+        any = true;
+        if (sig < 19) { m = m * 10 + (unsigned)(*p - '0'); if (m) sig++; } else { e10++; if (*p != '0') exact = false; }
+        p++; digits++;
+    }
+    if (p < end && *p == '.') {
+        p++;
+        while (p < end && *p >= '0' && *p <= '9') {
+            any = true;
+            if (sig < 19) { m = m * 10 + (unsigned)(*p - '0'); if (m) sig++; e10--; } else if (*p != '0') exact = false;
+            p++; digits++;
+        }
+    }
+    bool simple = any && exact;
+    if (any && p < end && (*p == 'e' || *p == 'E')) {
+        const char* q = p + 1;
+        bool eneg = false;
+        if (q < end && (*q == '+' || *q == '-')) { eneg = *q == '-'; q++; }
+        if (q < end && *q >= '0' && *q <= '9') {
+            int ev = 0;
+            while (q < end && *q >= '0' && *q <= '9') { if (ev < 100000) ev = ev * 10 + (*q - '0'); q++; }
+            e10 += eneg ? -ev : ev;
+            p = q;
+        }
+    }
+    if (simple) {
+        if (m == 0) { out = neg ? -0.0f : 0.0f; return true; }
+        if (m < (1ull << 24) && e10 >= -10 && e10 <= 10) {
+            const float f = e10 < 0 ? (float)m / kPow10f[-e10] : (float)m * kPow10f[e10];
+            out = neg ? -f : f;
+            return true;
+        }
+        if (m < (1ull << 53) && e10 >= -22 && e10 <= 22) {
+            const double d = e10 < 0 ? (double)m / kPow10d[-e10] : (double)m * kPow10d[e10];
+            uint64_t bits;
+            memcpy(&bits, &d, 8);
+            const bool normal_float_range = d >= 1.1754943508222875e-38 && d <= 3.4028234663852886e38;
+            if (normal_float_range && (bits & 0x1fffffffull) != 0x10000000ull) {     // not a float midpoint: rounding once more is safe
+                const float f = (float)d;
+                out = neg ? -f : f;
+                return true;
+            }
+        }
+    }
+    // the general case: strtof on a NUL-terminated copy (the mapping has no terminator, and strtof would run on into the next line)
+    char buf[128];
+    size_t n = (size_t)(end - tok);
+    std::string big;
+    const char* src;
+    if (n < sizeof buf) { memcpy(buf, tok, n); buf[n] = 0; src = buf; } else { big.assign(tok, n); src = big.c_str(); }
+    if (is_space((unsigned char)src[0])) return false;
+    char* e = nullptr;
+    const float f = strtof(src, &e);
+    if (e == src) return false;
+    out = f;
+    return true;
+}
+
+// next whitespace-separated token of [p, end): false at the end of the line
+inline bool next_token(const char*& p, const char* end, const char*& tb, const char*& te)
+{
+    while (p < end && is_space((unsigned char)*p)) p++;
+    if (p >= end) return false;
+    tb = p;
+    while (p < end && !is_space((unsigned char)*p)) p++;
+    te = p;
+    return true;
+}
+
+struct MappedFile {
+    const char* data = nullptr;
+    size_t size = 0;
+    bool ok = false;
+    explicit MappedFile(const char* path)
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            size = (size_t)st.st_size;
+            if (size == 0) ok = true;
+            else {
+                void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+                if (m != MAP_FAILED) { data = (const char*)m; ok = true; (void)madvise(m, size, MADV_SEQUENTIAL); }
+            }
+        } else if (fstat(fd, &st) == 0) {
+            // not a regular file (a pipe, /dev/stdin): read it
+            std::string* s = new std::string;
+            char buf[1 << 16];
+            ssize_t n;
+            while ((n = read(fd, buf, sizeof buf)) > 0) s->append(buf, (size_t)n);
+            owned = s; data = s->data(); size = s->size(); ok = true;
+        }
+        close(fd);
+    }
+    ~MappedFile() { if (owned) delete owned; else if (data) munmap((void*)data, size); }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+private:
+    std::string* owned = nullptr;
+};
+}  // namespace
+
+bool OBJLoader::scan_float_token(const char* begin, const char* end, float& out) { return scan_float(begin, end, out); }
+
+// One pass over the mapped file gathers the `v` / `vt` records and the extents of the `f` lines, a second pass over those
+// lines builds the fan triangles -- the reference reads the whole file twice for the same reason (OBJLoader.hpp:36-88 then
+// :90-171): a face may name a vertex that is defined after it.  Files of more than a megabyte are cut at line ends into
+// one piece per thread for both passes (records and triangles are concatenated in file order, so the result -- and the
+// first error reported -- is the sequential one).
+namespace {
+struct ObjFace { const char* begin; const char* end; int nv, nt; };     // the line after "f", and the #v / #vt records before it
+struct ObjPiece {
+    const char *begin = nullptr, *end = nullptr;
+    std::vector<float3> vertices;
+    std::vector<float2> tex_coords;
+    std::vector<ObjFace> faces;                    // nv / nt count this piece's records only until the pieces are joined
+    std::string error;
+};
+
+// the next `n` whitespace-separated tokens of the line as floats; p moves past them.  false: a token is missing or not a number
+inline bool line_floats(const char*& p, const char* end, float* out, int n)
+{
+    for (int k = 0; k < n; k++) {
+        while (p < end && *p != '\n' && is_space((unsigned char)*p)) p++;
+        if (p >= end || *p == '\n') return false;
+        const char* tb = p;
+        while (p < end && !is_space((unsigned char)*p)) p++;
+        if (!scan_float(tb, p, out[k])) return false;
+    }
+    return true;
+}
+
+void obj_pass1(ObjPiece& pc)
+{
+    const size_t bytes = (size_t)(pc.end - pc.begin);
+    pc.vertices.reserve(bytes / 96); pc.tex_coords.reserve(bytes / 96); pc.faces.reserve(bytes / 56);
+    const char* const end = pc.end;
+    for (const char* p = pc.begin; p < end;) {
+        while (p < end && *p != '\n' && is_space((unsigned char)*p)) p++;          // leading blanks of the line
+        // the record type is the first token: "v", "vt", "f" (anything else, "vn" included, is skipped: OBJLoader.hpp:55-62)
+        if (p + 1 < end && p[0] == 'v' && is_space((unsigned char)p[1])) {
+            p += 1;
+            float c[3];
+            if (!line_floats(p, end, c, 3)) { pc.error = "malformed v record"; return; }
+            pc.vertices.push_back(make_float3(c[0], c[1], c[2]));
+        } else if (p + 2 < end && p[0] == 'v' && p[1] == 't' && is_space((unsigned char)p[2])) {
+            p += 2;
+            float c[2];
+            if (!line_floats(p, end, c, 2)) { pc.error = "malformed vt record"; return; }
+            pc.tex_coords.push_back(make_float2(c[0], c[1]));
+        } else if (p < end && p[0] == 'f' && (p + 1 == end || is_space((unsigned char)p[1]))) {
+            const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
+            if (!eol) eol = end;
+            pc.faces.push_back(ObjFace{p + 1, eol, (int)pc.vertices.size(), (int)pc.tex_coords.size()});
+            p = eol;
+        } else if (p + 1 == end && p[0] == 'v') { pc.error = "malformed v record"; return; }
+        else if (p + 2 == end && p[0] == 'v' && p[1] == 't') { pc.error = "malformed vt record"; return; }
+        const char* eol = p < end ? (const char*)memchr(p, '\n', (size_t)(end - p)) : nullptr;
+        p = eol ? eol + 1 : end;
+    }
+}
+
+// faces [f0, f1) -> fan triangles (OBJLoader.hpp:90-171)
+void obj_pass2(const std::vector<ObjFace>& faces, size_t f0, size_t f1, const std::vector<float3>& vertices,
+               const std::vector<float2>& tex_coords, bool lenient, std::vector<TrianglePrimitive>& triangles, std::string& error)
+{
+    triangles.reserve(triangles.size() + (f1 - f0) + (f1 - f0) / 8);
+    std::vector<int> vi, ti;
+    const int nv = (int)vertices.size(), nt = (int)tex_coords.size();
+    for (size_t fi = f0; fi < f1; fi++) {
+        const ObjFace& fl = faces[fi];
+        vi.clear(); ti.clear();
+        const char* p = fl.begin;
+        const char* const lend = fl.end;
+        for (;;) {
+            while (p < lend && is_space((unsigned char)*p)) p++;
+            if (p >= lend) break;
+            // one token v, v/vt or v/vt/vn, every character visited once: each number is read with std::stoi's prefix rule
+            // (digits, then anything up to the next '/' or the end of the token is ignored), the slashes found as
+            // string::find finds them (OBJLoader.hpp:104-122)
+            int v;
+            const char* d = p;
+            if (!scan_int_prefix(p, lend, v) || p == d) { error = "malformed face token"; return; }
+            vi.push_back(lenient && v < 0 ? fl.nv + v : v - 1);
+            while (p < lend && *p != '/' && !is_space((unsigned char)*p)) p++;
+            if (p < lend && *p == '/') {
+                p++;
+                const bool no_tex = lenient && p < lend && *p == '/';                   // v//vn
+                if (!no_tex) {
+                    if (!scan_int_prefix(p, lend, v)) { error = "malformed face token (v//vn is not supported)"; return; }
+                    ti.push_back(lenient && v < 0 ? fl.nt + v : v - 1);
+                }
+                while (p < lend && *p != '/' && !is_space((unsigned char)*p)) p++;
+                if (p < lend && *p == '/') {
+                    p++;
+                    if (!scan_int_prefix(p, lend, v)) { error = "malformed face token"; return; }
+                    while (p < lend && !is_space((unsigned char)*p)) p++;
+                }
+            }
+        }
+        for (size_t i = 1; i + 1 < vi.size(); i++) {
+            const int ia = vi[0], ib = vi[i], ic = vi[i + 1];
+            if (ia < 0 || ib < 0 || ic < 0 || ia >= nv || ib >= nv || ic >= nv) { error = "face vertex index out of range"; return; }
+            const float3 &A = vertices[ia], &B = vertices[ib], &C = vertices[ic];
+            float3 normal = normalize(cross(TrianglePrimitive::sub(B, A), TrianglePrimitive::sub(C, A)));   // :141-143
+            if (!ti.empty()) {
+                if (ti.size() <= i + 1) { error = "face mixes v and v/vt tokens"; return; }
+                const int ta = ti[0], tb2 = ti[i], tc = ti[i + 1];
+                if (ta < 0 || tb2 < 0 || tc < 0 || ta >= nt || tb2 >= nt || tc >= nt) { error = "face texture index out of range"; return; }
+                triangles.push_back(TrianglePrimitive(A, B, C, normal, tex_coords[ta], tex_coords[tb2], tex_coords[tc]));
+            } else {
+                triangles.push_back(TrianglePrimitive(A, B, C, normal));
+            }
+        }
+    }
+}
+
+template <class F>
+void run_pieces(int n, F&& body)                    // body(k) for k in [0, n), piece 0 on the calling thread
+{
+    std::vector<std::thread> th;
+    for (int k = 1; k < n; k++) th.emplace_back([&body, k] { body(k); });
+    body(0);
+    for (auto& t : th) t.join();
 }
 }  // namespace
 
 bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error, bool lenient)
 {
     auto fail = [&](const std::string& msg) { if (error) *error = msg; return false; };
-    FILE* f = fopen(fp.c_str(), "rb");
-    if (!f) return fail("Could not open file " + fp);
-    std::string data;
-    {
-        char buf[1 << 16];
-        size_t n;
-        while ((n = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
-        fclose(f);
+    MappedFile file(fp.c_str());
+    if (!file.ok) return fail("Could not open file " + fp);
+    const char* const data = file.data;
+    const char* const fend = data + file.size;
+    int threads = 1;
+    if (file.size > ((size_t)1 << 20)) {
+        threads = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)8, file.size >> 19});
+        if (const char* e = getenv("RT_OBJ_THREADS")) threads = std::max(1, std::min(64, atoi(e)));
     }
+    // pieces end at line ends
+    std::vector<ObjPiece> pieces((size_t)threads);
+    {
+        const char* at = data;
+        for (int k = 0; k < threads; k++) {
+            pieces[(size_t)k].begin = at;
+            const char* cut = k + 1 == threads ? fend : data + file.size * (size_t)(k + 1) / (size_t)threads;
+            if (cut < at) cut = at;
+            if (cut < fend) { const char* nl = (const char*)memchr(cut, '\n', (size_t)(fend - cut)); cut = nl ? nl + 1 : fend; }
+            pieces[(size_t)k].end = at = cut;
+        }
+    }
+    // pass 1: v / vt records (vn is accepted and unused, OBJLoader.hpp:55-62); remember face lines
+    run_pieces(threads, [&](int k) { obj_pass1(pieces[(size_t)k]); });
+    for (const ObjPiece& pc : pieces) if (!pc.error.empty()) return fail(pc.error);
     std::vector<float3> vertices;
     std::vector<float2> tex_coords;
-    std::vector<const char*> tok;
-    std::vector<size_t> face_lines;
-    // pass 1: v / vt records (vn is accepted and unused, OBJLoader.hpp:55-62); remember face lines
-    size_t pos = 0;
-    const size_t N = data.size();
-    std::vector<std::pair<size_t, size_t>> faces;      // [begin, end) of each "f" line
-    std::vector<std::pair<int, int>> counts_at_face;   // #v, #vt records seen before that line (relative indices)
-    while (pos < N) {
-        size_t eol = data.find('\n', pos);
-        if (eol == std::string::npos) eol = N;
-        size_t a = pos;
-        while (a < eol && isspace((unsigned char)data[a])) a++;
-        size_t b = a;
-        while (b < eol && !isspace((unsigned char)data[b])) b++;
-        const size_t len = b - a;
-        if (len == 1 && data[a] == 'v') {
-            char* p = &data[b]; char* e;
-            float x = strtof(p, &e); if (e == p) return fail("malformed v record"); p = e;
-            float y = strtof(p, &e); if (e == p) return fail("malformed v record"); p = e;
-            float z = strtof(p, &e); if (e == p) return fail("malformed v record");
-            vertices.push_back(make_float3(x, y, z));
-        } else if (len == 2 && data[a] == 'v' && data[a + 1] == 't') {
-            char* p = &data[b]; char* e;
-            float x = strtof(p, &e); if (e == p) return fail("malformed vt record"); p = e;
-            float y = strtof(p, &e); if (e == p) return fail("malformed vt record");
-            tex_coords.push_back(make_float2(x, y));
-        } else if (len == 1 && data[a] == 'f') {
-            faces.push_back(std::make_pair(b, eol));
-            counts_at_face.push_back(std::make_pair((int)vertices.size(), (int)tex_coords.size()));
-        }
-        pos = eol + 1;
-    }
-    // pass 2: faces -> fan triangles (OBJLoader.hpp:90-171)
-    std::vector<int> vi, ti;
-    for (size_t fi = 0; fi < faces.size(); fi++) {
-        const auto& fl = faces[fi];
-        const int nv_here = counts_at_face[fi].first, nt_here = counts_at_face[fi].second;
-        vi.clear(); ti.clear();
-        size_t p = fl.first;
-        while (p < fl.second) {
-            while (p < fl.second && isspace((unsigned char)data[p])) p++;
-            if (p >= fl.second) break;
-            size_t q = p;
-            while (q < fl.second && !isspace((unsigned char)data[q])) q++;
-            // token [p, q): v, v/vt or v/vt/vn
-            size_t s1 = p;
-            while (s1 < q && data[s1] != '/') s1++;
-            int v;
-            {
-                std::string head(&data[p], s1 - p);
-                if (!lead_int(head.c_str(), v)) return fail("malformed face token");
-                vi.push_back(lenient && v < 0 ? nv_here + v : v - 1);
-            }
-            if (s1 < q) {
-                std::string rest(&data[s1 + 1], q - s1 - 1);
-                const bool no_tex = lenient && !rest.empty() && rest[0] == '/';         // v//vn
-                if (!no_tex) {
-                    if (!lead_int(rest.c_str(), v)) return fail("malformed face token (v//vn is not supported)");
-                    ti.push_back(lenient && v < 0 ? nt_here + v : v - 1);
-                }
-                size_t s2 = rest.find('/');
-                if (s2 != std::string::npos && !lead_int(rest.c_str() + s2 + 1, v)) return fail("malformed face token");
-            }
-            p = q;
-        }
-        for (size_t i = 1; i + 1 < vi.size(); i++) {
-            const int ia = vi[0], ib = vi[i], ic = vi[i + 1];
-            const int nv = (int)vertices.size();
-            if (ia < 0 || ib < 0 || ic < 0 || ia >= nv || ib >= nv || ic >= nv) return fail("face vertex index out of range");
-            const float3 &A = vertices[ia], &B = vertices[ib], &C = vertices[ic];
-            float3 normal = normalize(cross(TrianglePrimitive::sub(B, A), TrianglePrimitive::sub(C, A)));   // :141-143
-            if (!ti.empty()) {
-                const int nt = (int)tex_coords.size();
-                if (ti.size() <= i + 1) return fail("face mixes v and v/vt tokens");
-                const int ta = ti[0], tb = ti[i], tc = ti[i + 1];
-                if (ta < 0 || tb < 0 || tc < 0 || ta >= nt || tb >= nt || tc >= nt) return fail("face texture index out of range");
-                triangles.push_back(TrianglePrimitive(A, B, C, normal, tex_coords[ta], tex_coords[tb], tex_coords[tc]));
-            } else {
-                triangles.push_back(TrianglePrimitive(A, B, C, normal));
-            }
+    std::vector<ObjFace> faces;
+    if (threads == 1) {
+        vertices.swap(pieces[0].vertices); tex_coords.swap(pieces[0].tex_coords); faces.swap(pieces[0].faces);
+    } else {
+        size_t nv = 0, nt = 0, nf = 0;
+        for (const ObjPiece& pc : pieces) { nv += pc.vertices.size(); nt += pc.tex_coords.size(); nf += pc.faces.size(); }
+        vertices.reserve(nv); tex_coords.reserve(nt); faces.reserve(nf);
+        for (ObjPiece& pc : pieces) {
+            const int bv = (int)vertices.size(), bt = (int)tex_coords.size();
+            for (ObjFace& f : pc.faces) { f.nv += bv; f.nt += bt; }
+            vertices.insert(vertices.end(), pc.vertices.begin(), pc.vertices.end());
+            tex_coords.insert(tex_coords.end(), pc.tex_coords.begin(), pc.tex_coords.end());
+            faces.insert(faces.end(), pc.faces.begin(), pc.faces.end());
         }
     }
+    // pass 2
+    if (threads == 1) {
+        std::string err;
+        obj_pass2(faces, 0, faces.size(), vertices, tex_coords, lenient, triangles, err);
+        return err.empty() ? true : fail(err);
+    }
+    std::vector<std::vector<TrianglePrimitive>> part((size_t)threads);
+    std::vector<std::string> errs((size_t)threads);
+    run_pieces(threads, [&](int k) {
+        obj_pass2(faces, faces.size() * (size_t)k / (size_t)threads, faces.size() * (size_t)(k + 1) / (size_t)threads, vertices, tex_coords,
+                  lenient, part[(size_t)k], errs[(size_t)k]);
+    });
+    for (const std::string& e : errs) if (!e.empty()) return fail(e);
+    size_t total = triangles.size();
+    for (const auto& v : part) total += v.size();
+    triangles.reserve(total);
+    for (const auto& v : part) triangles.insert(triangles.end(), v.begin(), v.end());
     return true;
 }
 

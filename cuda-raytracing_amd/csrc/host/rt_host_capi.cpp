@@ -31,6 +31,23 @@ RthMesh* rth_obj_load(const char* path)
         return new RthMesh(MeshPrimitive(std::move(tris)));
     } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
+int32_t rth_obj_parse(const char* path, int32_t lenient, float* out18, int32_t capacity)
+{
+    try {
+        std::vector<TrianglePrimitive> tris;
+        std::string err;
+        if (!path || !OBJLoader::parse(path, tris, &err, lenient != 0)) { g_err = path ? err : "null path"; return -1; }
+        if (out18 && (size_t)capacity >= tris.size() && !tris.empty()) memcpy(out18, tris.data(), tris.size() * 72);
+        return (int32_t)tris.size();
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int rth_scan_float(const char* token, size_t length, float* out)
+{
+    float f = 0.0f;
+    if (!token || !out || !OBJLoader::scan_float_token(token, token + length, f)) return 0;
+    *out = f;
+    return 1;
+}
 RthMesh* rth_obj_load_lenient(const char* path)
 {
     try {

@@ -21,6 +21,11 @@ typedef struct RthCamera RthCamera;   /* Camera */
 RthMesh *rth_obj_load(const char *path);
 /* OBJLoader::load_lenient: additionally accepts `v//vn` tokens and negative (relative) indices */
 RthMesh *rth_obj_load_lenient(const char *path);
+/* OBJLoader::parse alone (no BVH): the number of triangles, or -1 (rth_last_error()); when out18 is non-NULL and holds
+ * `capacity` >= that many 18-float triangles (TrianglePrimitive layout) they are copied there */
+int32_t rth_obj_parse(const char *path, int32_t lenient, float *out18, int32_t capacity);
+/* the parser's float scanner on token[0..length): 1 and *out = the value std::stof gives, 0 = no conversion */
+int rth_scan_float(const char *token, size_t length, float *out);
 /* MeshPrimitive(std::vector<TrianglePrimitive>) (MeshPrimitive.h:31); tris18 = n x {v0 v1 v2 normal uv0 uv1 uv2} */
 RthMesh *rth_mesh_from_triangles(const float *tris18, int32_t n);
 /* the same meshes with the BVH built on the GPU (rt_bvh_build): identical tree, NULL if no device */

@@ -527,3 +527,108 @@ def test_interaction_handlers_match_oracle(rt, oracle):
         ra = host.rth_on_key(fp(pose_a), ord(key))
         rb = olib.orc_on_key(fp(pose_b), ord(key))
         assert ra == rb == (0 if key == "q" else 1) and pose_a.tobytes() == pose_b.tobytes()
+
+
+def test_obj_float_scanner_matches_strtof(rt):
+    """OBJLoader's own float scanner (the fp32 / double fast paths and the strtof fallback) returns, for every token, the
+    float glibc's strtof returns -- the function std::stof calls in the reference (OBJLoader.hpp:47-49): correctly rounded,
+    prefix rule, inf / nan / hexadecimal forms, no conversion for the same tokens."""
+    import ctypes as C
+    s = rt.libs()[1]
+    s.rth_scan_float.restype = C.c_int
+    s.rth_scan_float.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_float)]
+    libc = C.CDLL("libc.so.6")
+    libc.strtof.restype = C.c_float
+    libc.strtof.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+    rng = np.random.default_rng(5)
+    toks = ["0", "-0", "0.0", "-0.000000", "1", "-1", ".5", "-.5", "5.", "+3.25", "1e5", "1E-5", "1e", "1e+", "1.5abc", "12.5e3x", "1e-40", "1e-46",
+            "3.4028235e38", "3.4028236e38", "3.5e38", "1e39", "-1e39", "16777216", "16777217", "16777218", "16777219", "33554434", "33554435",
+            "0.1", "0.2", "0.3", "123456789", "1234567890123456789", "12345678901234567890123", "0.000000000000000000000000000001",
+            "9007199254740993", "4503599627370497.5", "1.00000005960464477539", "1.0000000596046447753906250", "1.00000005960464477539062500001",
+            "inf", "-inf", "infinity", "nan", "NAN", "0x1.8p1", "0x10", "0x", ".", "-", "+", "e5", "abc", "", "--1", "1..2", "1e5e5", "00012.50", "1e0010", "1e-0010",
+            "8.5070592e37", "1.17549435e-38", "1.17549428e-38", "5.877472e-39", "1.4e-45", "0.7e-45", "0.70064923e-45", "0.8e-45"]
+    for _ in range(4000):
+        kind = rng.integers(7)
+        x = float(rng.normal(0, 1) * 10.0 ** rng.integers(-12, 12))
+        if kind == 0: toks.append("%.6f" % x)
+        elif kind == 1: toks.append("%.9g" % x)
+        elif kind == 2: toks.append("%.17g" % x)
+        elif kind == 3: toks.append("%e" % x)
+        elif kind == 4: toks.append("%d" % int(rng.integers(-2 ** 40, 2 ** 40)))
+        elif kind == 5:                                                  # exactly between two floats, and one double to either side
+            f = np.float32(x)
+            mid = (float(f) + float(np.nextafter(f, np.float32(np.inf)))) / 2.0
+            toks += [repr(mid), repr(float(np.nextafter(mid, np.inf))), repr(float(np.nextafter(mid, -np.inf))), "%.25f" % mid, "%.30e" % mid]
+        else: toks.append("".join(rng.choice(list("0123456789"), int(rng.integers(1, 30)))) + "." + "".join(rng.choice(list("0123456789"), int(rng.integers(0, 30)))))
+    bad = []
+    for t in toks:
+        b = t.encode()
+        e2 = C.c_char_p()
+        buf = C.create_string_buffer(b)
+        want = np.float32(libc.strtof(buf, C.byref(e2)))
+        converted = C.cast(e2, C.c_void_p).value != C.addressof(buf)
+        got = C.c_float(0)
+        ok = s.rth_scan_float(b, len(b), C.byref(got))
+        if bool(ok) != bool(converted):
+            bad.append((t, "conversion", ok, converted))
+        elif ok and not (np.array_equal(np.float32(got.value).view(np.uint32), want.view(np.uint32)) or (np.isnan(want) and np.isnan(got.value))):
+            bad.append((t, float(got.value), float(want)))
+    assert not bad, bad[:10]
+
+
+def test_obj_parse_is_the_same_on_one_thread_and_on_many(rt, tmp_path, blob70k, monkeypatch):
+    """Files above a megabyte are parsed in pieces on several threads: same triangles, in the same order, bit for bit; a face
+    may name vertices defined later in the file, relative indices count the records before the face line across piece
+    boundaries, and the first error of the file is the one reported."""
+    import ctypes as C
+    s = rt.libs()[1]
+    s.rth_obj_parse.restype = C.c_int32
+    s.rth_obj_parse.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_int32]
+    s.rth_last_error.restype = C.c_char_p
+
+    def parse(path, lenient, threads):
+        monkeypatch.setenv("RT_OBJ_THREADS", str(threads))
+        n = s.rth_obj_parse(str(path).encode(), lenient, None, 0)
+        if n < 0:
+            return s.rth_last_error().decode()
+        out = np.zeros((n, 18), np.float32)
+        assert s.rth_obj_parse(str(path).encode(), lenient, out.ctypes.data, n) == n
+        return out
+
+    a = parse(blob70k, 0, 1)
+    assert a.shape[0] == 69936
+    for t in (2, 5, 8):
+        assert np.array_equal(parse(blob70k, 0, t).view(np.uint32), a.view(np.uint32)), t
+    # a file with everything the lenient mode accepts, long enough to be cut into pieces: faces before their vertices,
+    # polygons, v//vn tokens, negative indices, comments, blank and vn lines
+    rng = np.random.default_rng(11)
+    lines = ["# mixed"]
+    nv = 0
+    for k in range(30000):
+        lines.append("v %.6f %.6f %.6f" % tuple(rng.normal(0, 1, 3)))
+        lines.append("vt %.6f %.6f" % tuple(rng.uniform(0, 1, 2)))
+        nv += 1
+        if k % 3 == 0:
+            lines.append("vn 0 0 1")
+        if k >= 4:
+            r = k % 5
+            if r == 0: lines.append("f -1/-1 -2/-2 -3/-3 -4/-4")
+            elif r == 1: lines.append("f %d//1 %d//1 %d//1" % (nv, nv - 1, nv - 2))
+            elif r == 2: lines.append("f %d/%d/1 %d/%d/1 %d/%d/1" % (nv, nv, nv - 2, nv - 2, nv - 3, nv - 3))
+            elif r == 3: lines.append("   f   %d %d %d   " % (1, nv, nv - 1))
+            else: lines.append("")
+    lines.insert(1, "f 30000/30000 29999/29999 29998/29998")                      # names vertices defined at the end of the file
+    path = tmp_path / "mixed.obj"
+    path.write_text("\n".join(lines))
+    assert os.path.getsize(path) > (1 << 20)
+    one = parse(path, 1, 1)
+    assert not isinstance(one, str) and one.shape[0] > 25000
+    for t in (3, 7):
+        assert np.array_equal(parse(path, 1, t).view(np.uint32), one.view(np.uint32)), t
+    assert parse(path, 0, 1) == parse(path, 0, 4) and isinstance(parse(path, 0, 4), str)        # strict mode: the same (first) error
+    # first error in file order, whatever piece finds it
+    broken = lines[:]
+    broken[40001] = "v 1.0 oops 2.0"
+    broken[50000] = "vt x y"
+    (tmp_path / "broken.obj").write_text("\n".join(broken))
+    assert parse(tmp_path / "broken.obj", 1, 1) == parse(tmp_path / "broken.obj", 1, 6) == "malformed v record"
