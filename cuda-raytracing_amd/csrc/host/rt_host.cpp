@@ -14,6 +14,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <atomic>
 #include <stdexcept>
 #include <thread>
 
@@ -874,11 +875,13 @@ void obj_pass2(const std::vector<ObjFace>& faces, size_t f0, size_t f1, const st
 }
 
 template <class F>
-void run_pieces(int n, F&& body)                    // body(k) for k in [0, n), piece 0 on the calling thread
+void run_pieces(int threads, int n, F&& body)       // body(k) for k in [0, n): `threads` workers (the caller is one) take the next k each
 {
+    std::atomic<int> next(0);
+    auto work = [&] { for (int k; (k = next.fetch_add(1)) < n;) body(k); };
     std::vector<std::thread> th;
-    for (int k = 1; k < n; k++) th.emplace_back([&body, k] { body(k); });
-    body(0);
+    for (int t = 1; t < threads && t < n; t++) th.emplace_back(work);
+    work();
     for (auto& t : th) t.join();
 }
 }  // namespace
@@ -895,20 +898,22 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
         threads = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)8, file.size >> 19});
         if (const char* e = getenv("RT_OBJ_THREADS")) threads = std::max(1, std::min(64, atoi(e)));
     }
-    // pieces end at line ends
-    std::vector<ObjPiece> pieces((size_t)threads);
+    // pieces end at line ends; four per thread, handed out as threads finish (the `v` half of a file costs more per byte
+    // than the `f` half in the first pass)
+    const int npieces = threads == 1 ? 1 : threads * 4;
+    std::vector<ObjPiece> pieces((size_t)npieces);
     {
         const char* at = data;
-        for (int k = 0; k < threads; k++) {
+        for (int k = 0; k < npieces; k++) {
             pieces[(size_t)k].begin = at;
-            const char* cut = k + 1 == threads ? fend : data + file.size * (size_t)(k + 1) / (size_t)threads;
+            const char* cut = k + 1 == npieces ? fend : data + file.size * (size_t)(k + 1) / (size_t)npieces;
             if (cut < at) cut = at;
             if (cut < fend) { const char* nl = (const char*)memchr(cut, '\n', (size_t)(fend - cut)); cut = nl ? nl + 1 : fend; }
             pieces[(size_t)k].end = at = cut;
         }
     }
     // pass 1: v / vt records (vn is accepted and unused, OBJLoader.hpp:55-62); remember face lines
-    run_pieces(threads, [&](int k) { obj_pass1(pieces[(size_t)k]); });
+    run_pieces(threads, npieces, [&](int k) { obj_pass1(pieces[(size_t)k]); });
     for (const ObjPiece& pc : pieces) if (!pc.error.empty()) return fail(pc.error);
     std::vector<float3> vertices;
     std::vector<float2> tex_coords;
@@ -933,10 +938,10 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
         obj_pass2(faces, 0, faces.size(), vertices, tex_coords, lenient, triangles, err);
         return err.empty() ? true : fail(err);
     }
-    std::vector<std::vector<TrianglePrimitive>> part((size_t)threads);
-    std::vector<std::string> errs((size_t)threads);
-    run_pieces(threads, [&](int k) {
-        obj_pass2(faces, faces.size() * (size_t)k / (size_t)threads, faces.size() * (size_t)(k + 1) / (size_t)threads, vertices, tex_coords,
+    std::vector<std::vector<TrianglePrimitive>> part((size_t)npieces);
+    std::vector<std::string> errs((size_t)npieces);
+    run_pieces(threads, npieces, [&](int k) {
+        obj_pass2(faces, faces.size() * (size_t)k / (size_t)npieces, faces.size() * (size_t)(k + 1) / (size_t)npieces, vertices, tex_coords,
                   lenient, part[(size_t)k], errs[(size_t)k]);
     });
     for (const std::string& e : errs) if (!e.empty()) return fail(e);
