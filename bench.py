@@ -68,6 +68,52 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class PhaseWatchdog:
+    """Deadlines for the phases of a multi-rank run.  A rank stuck inside a collective (a peer that never joined, a wedged
+    link) would otherwise only show as the driver's time limit.  A daemon thread watches the clock: when the phase the main
+    thread is in outlives its deadline, the rank prints which phase, the communicator's last error text and the phases it
+    had completed, and leaves with a non-zero code through os._exit -- the main thread may be blocked inside RCCL, and a
+    process that has touched the GPU is never re-executed.  torchrun then ends the other ranks."""
+
+    def __init__(self, rank, seconds, enabled):
+        import threading
+        self.rank, self.seconds, self.enabled = rank, seconds, enabled
+        self.phase, self.deadline, self.done = None, None, []
+        self.lock = threading.Lock()
+        if enabled:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def enter(self, name, scale=1.0):
+        with self.lock:
+            if self.phase is not None:
+                self.done.append(self.phase)
+            self.phase, self.deadline = name, time.monotonic() + self.seconds * scale
+        if self.enabled:
+            log("bench.py rank %d: phase '%s' (deadline %.0f s)" % (self.rank, name, self.seconds * scale))
+
+    def finish(self):
+        with self.lock:
+            if self.phase is not None:
+                self.done.append(self.phase)
+            self.phase, self.deadline = None, None
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                late = self.phase is not None and time.monotonic() > self.deadline
+                phase, done = self.phase, list(self.done)
+            if late:
+                try:
+                    err = rt.Comm.last_error()
+                except Exception as e:                                  # (the library may not even be loaded yet)
+                    err = "unavailable (%s)" % e
+                log("bench.py rank %d: phase '%s' exceeded its deadline of %.0f s -- giving up (exit code 3).  rt_comm_last_error(): %r; "
+                    "phases completed: %s; NCCL_DEBUG=%s" % (self.rank, phase, self.seconds, err, ", ".join(done) or "none", os.environ.get("NCCL_DEBUG", "")))
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def camera_path(base, n):
     """n poses on a small closed loop around `base` (a few millimetres of travel and a fraction of a degree of yaw):
     every frame of a group is a different frame, the work per frame stays that of the named camera."""
@@ -177,13 +223,27 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
-    r = subprocess.run(cmd, stdout=subprocess.PIPE)
-    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith('{"metric"')]
-    for ln in r.stdout.decode(errors="replace").splitlines():
+    # the ranks report RCCL's own warnings (stderr is inherited: they arrive as they are printed) and watch their phases
+    # themselves (PhaseWatchdog); the limit here is the backstop for a launcher that never returns
+    env = dict(os.environ)
+    env.setdefault("NCCL_DEBUG", "WARN")
+    limit = args.phase_deadline * 8 + 600
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)                             # (the group this launcher started, by its id)
+        proc.communicate()
+        sys.exit("bench.py: the %d-rank run did not end within %d s and was killed" % (args.gpus, limit))
+    r = proc
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith('{"metric"')]
+    for ln in out.decode(errors="replace").splitlines():
         if not ln.startswith('{"metric"'):
             log(ln)
     if r.returncode != 0 or len(lines) != 1:
-        sys.exit("bench.py: the %d-rank run failed (exit code %d, %d result lines)" % (args.gpus, r.returncode, len(lines)))
+        sys.exit("bench.py: the %d-rank run failed (exit code %d, %d result lines): see the ranks' messages above (phase, rt_comm_last_error, "
+                 "RCCL warnings)" % (args.gpus, r.returncode, len(lines)))
     print(lines[0], flush=True)
     sys.exit(0)
 
@@ -254,6 +314,10 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=0, help="stream workloads: 0 = as many as one launch takes (32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the F = 1 / F = 2 latency figures")
+    ap.add_argument("--phase-deadline", type=float, default=180.0,
+                    help="N > 1: seconds every phase of a rank may take (process group, scene, communicator, first exchange, timed loop x 4, check) "
+                         "before the rank reports the phase and rt_comm_last_error() and exits non-zero")
+    ap.add_argument("--test-stall", default="", help="tests only: 'RANK:PHASE' makes that rank sleep forever on entering that phase")
     ap.add_argument("--debug-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 logic with host-staged exchanges (several ranks may share one GPU); never for numbers")
     ap.add_argument("--gather", default="auto", choices=["auto", "rotate", "root0"],
@@ -290,6 +354,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    wd = PhaseWatchdog(rank, args.phase_deadline, enabled=world > 1)
+
+    def phase(name, scale=1.0):
+        wd.enter(name, scale)
+        if args.test_stall == "%d:%s" % (rank, name):
+            log("bench.py rank %d: --test-stall: sleeping in phase '%s'" % (rank, name))
+            time.sleep(1e9)
     dist_on = world > 1 or args.force_collective                # stripes + exchange + un-stripe instead of whole-frame launches
     rehearsal = dist_on and args.debug_backend == "gloo"
     if rehearsal:
@@ -297,6 +368,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
+        phase("process group")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
@@ -304,6 +376,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    phase("scene")
     rt.build()
     hlib = rt.libs()[0]
     wl = dict(scenes.WORKLOADS[args.workload])
@@ -350,13 +423,16 @@ def main():
     comm = exchange = None
     exchange_note = None
     mock_transport = False
+    ranks_seen = 1
     if dist_on:
+        phase("communicator")
         # rehearsal with RT_RCCL_LIBRARY set (the tests' shared-memory mock of RCCL, tests/mock_rccl): the ranks share one GPU, torch
         # talks gloo, and the DATA path is the product's -- RtComm, rt_all_to_all / rt_gather / rt_render_tiled, the pipeline on
         # its streams -- with only the transport faked.  Rehearsal without it: host-staged exchange through gloo.
         mock_transport = rehearsal and args.exchange == "rccl" and bool(os.environ.get("RT_RCCL_LIBRARY"))
         if rehearsal and not mock_transport:
             exchange = tiling.TorchExchange(rank, world)
+            ranks_seen = dist.get_world_size()
         else:
             # the product path: RtComm (RCCL through the C-ABI).  If it cannot be created on every rank the run goes on with
             # torch.distributed's own RCCL communicator moving the same buffers, and SAYS SO in the result line.
@@ -376,7 +452,9 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
                 exchange = tiling.RcclExchange(comm)
+                ranks_seen = comm.info()[1]                      # the size RCCL itself reports for the communicator
             else:
+                ranks_seen = dist.get_world_size()
                 if comm is not None:
                     comm.close()
                     comm = None
@@ -394,6 +472,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    phase("first exchange")
     if stream_mode:
         res = run_stream(args, locals())
     else:
@@ -401,15 +480,17 @@ def main():
     if rank == 0:
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if dist_on:
+        phase("shutdown")
         dist.barrier()
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
+    wd.finish()
 
 
 def base_line(args, env, value, dt, warmup_done, config, roof, extra):
     world, rehearsal = env["world"], env["rehearsal"]
-    out = {"metric": METRIC, "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world}
+    out = {"metric": METRIC, "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "ranks_seen": env.get("ranks_seen", 1)}
     if rehearsal:
         out["REHEARSAL_NOT_A_MEASUREMENT"] = ("gloo control plane; data path = the C-ABI exchange over the library RT_RCCL_LIBRARY names (the tests' shared-memory mock)"
                                               if env.get("mock_transport") else "gloo backend, host-staged exchanges")
@@ -522,6 +603,7 @@ def run_stream(args, env):
     for i, c in enumerate(warm_groups):
         step_group(i, c)
     sync()
+    g["phase"]("timed loop", 4.0)
     t0 = time.perf_counter()
     for i, c in enumerate(groups):
         step_group(i, c)
@@ -536,6 +618,7 @@ def run_stream(args, env):
         dt = float(tmax.item())
 
     # ---- kernel-only duration with hipEvents on the launch stream (roofline denominator); latency figures ----
+    g["phase"]("check", 4.0)
     kernel_ms, latency = None, None
     if rank == 0:
         n = max(10, min(len(groups), 100))
@@ -699,11 +782,13 @@ def run_frames(args, env):
     for i in range(args.warmup):
         step(i)
     sync()
+    g["phase"]("timed loop", 4.0)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     sync()
     dt = time.perf_counter() - t0
+    g["phase"]("check", 4.0)
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -493,6 +493,18 @@ class Comm:
             out.append(c)
         return out
 
+    def info(self):
+        """(rank, num_ranks, device) as the RCCL communicator itself reports them (rt_comm_info)."""
+        r, n, d = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        check(libs()[0].rt_comm_info(self.h, C.byref(r), C.byref(n), C.byref(d)), "rt_comm_info")
+        return r.value, n.value, d.value
+
+    @staticmethod
+    def last_error():
+        libs()[0].rt_comm_last_error.restype = C.c_char_p
+        e = libs()[0].rt_comm_last_error()
+        return e.decode(errors="replace") if e else ""
+
     @staticmethod
     def group_start():
         check(libs()[0].rt_group_start(), "rt_group_start")

@@ -743,6 +743,9 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
             for (int k = 0; k < ns; k++) {
                 JpegComponent& c = *sc[k];
                 if ((need_dc && !hdc[c.td].present) || (need_ac && !hac[c.ta].present) || !have_qt[c.tq]) return fail(error, "JPEG scan refers to a missing table");
+                // a sequential frame codes every component exactly once: a second scan of one would be decoded on top of the
+                // first one's coefficients (libjpeg refuses such files too)
+                if (!progressive && c.q_latched) return fail(error, "JPEG component scanned twice in a sequential frame");
                 if (!c.q_latched) { memcpy(c.q, qt[c.tq], sizeof c.q); c.q_latched = true; }
                 c.dc_pred = 0;
             }
@@ -779,6 +782,9 @@ bool read_jpeg_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& widt
                                         const int t = jpeg_decode_huff(br, hdc[c.td]);
                                         if (t < 0 || t > 11) return fail(error, "corrupt JPEG data");
                                         if (t) c.dc_pred += jpeg_extend(br.receive(t), t);
+                                        // a DC value is at most 11 bits + sign before the point transform (T.81 F.1.2.1): a running
+                                        // sum outside that range is a corrupt stream, and unchecked it could overflow the int
+                                        if (c.dc_pred < -32768 || c.dc_pred > 32767 || (c.dc_pred * p1) < -32768 || (c.dc_pred * p1) > 32767) return fail(error, "corrupt JPEG data");
                                         blk[0] = (int16_t)(c.dc_pred * p1);
                                     } else if (br.bit()) blk[0] = (int16_t)(blk[0] | p1);   // DC refinement: one more bit
                                 }

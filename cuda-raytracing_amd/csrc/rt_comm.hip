@@ -9,12 +9,12 @@
 // instead of seven of them converging on one root.
 //
 // RCCL is resolved at run time (dlopen of librccl.so.1: the copy a host process already loaded -- PyTorch ships one --
-// or ROCm's), so librt_hip.so has no link-time dependency on it and single-GPU users never load it.  Two ways to form
+// or ROCm's), so librt_hip.so has no link-time dependency on it and single-GPU users never load it; the dozen entry points
+// it uses are declared below, so building this file needs no RCCL headers either.  Two ways to form
 // the group: one process per GPU (rt_comm_unique_id on one rank, broadcast by the host's own means, rt_comm_init_rank
 // on every rank), or one process driving all devices (rt_comm_init_all + the *_all calls, which wrap the per-device
 // calls in ncclGroupStart / ncclGroupEnd).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
 #include <cstdio>
@@ -27,21 +27,32 @@
 
 #include "../../include/rt_hip.h"
 
+// ---- the part of RCCL's C interface this file uses (rccl.h of ROCm 7: the NCCL 2 ABI) ----
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1 } ncclDataType_t;
+
 namespace {
 
 struct Rccl {
     void* lib = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGather) Gather = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclGetVersion) GetVersion = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    // optional (rt_comm_info reports what the library itself says when they exist)
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    std::string load_error;
 };
 
 thread_local std::string g_comm_error;
@@ -51,16 +62,22 @@ Rccl* rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        // RT_RCCL_LIBRARY=<path>: load that library instead (the tests' in-process mock, tests/mock_rccl; an RCCL build elsewhere)
-        if (const char* e = getenv("RT_RCCL_LIBRARY")) r.lib = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+        // RT_RCCL_LIBRARY=<path>: load that library and no other (the tests' in-process mock, tests/mock_rccl; an RCCL build
+        // elsewhere).  If it cannot be loaded the communicator is unavailable -- never a silent switch to the system's library.
+        const char* forced = getenv("RT_RCCL_LIBRARY");
+        if (forced && *forced) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) { const char* de = dlerror(); r.load_error = std::string("RT_RCCL_LIBRARY=") + forced + " could not be loaded: " + (de ? de : "?"); return; }
+        }
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (r.lib) break;
             r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
-        if (!r.lib) return;
+        if (!r.lib) { r.load_error = "librccl.so.1 could not be loaded"; return; }
         bool ok = true;
-        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) ok = false; return p; };
+        std::string missing;
+        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) { ok = false; missing += std::string(missing.empty() ? "" : ", ") + n; } return p; };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
@@ -72,9 +89,15 @@ Rccl* rccl()
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
-        if (!ok) { dlclose(r.lib); r.lib = nullptr; }
+        if (!ok) {
+            dlclose(r.lib); r.lib = nullptr;
+            r.load_error = std::string(forced && *forced ? forced : "librccl.so.1") + " lacks " + missing;
+            return;
+        }
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+        r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
     });
-    if (!r.lib) { g_comm_error = "librccl.so.1 could not be loaded"; return nullptr; }
+    if (!r.lib) { g_comm_error = r.load_error; return nullptr; }
     return &r;
 }
 
@@ -95,6 +118,13 @@ struct RtComm {
     // scratch of rt_render_tiled: this rank's stripe buffer and, on a root, the rank-major gathered buffer (grow-only)
     uint8_t* d_local = nullptr; size_t local_bytes = 0;
     uint8_t* d_gathered = nullptr; size_t gathered_bytes = 0;
+    // One pair of scratch buffers serves every call, so a call must not start before the previous call's last use of them
+    // (its gather, or on the root its un-stripe pass) has finished.  On one stream that is stream order; a call on ANOTHER
+    // stream waits for this event first (frames alternated between two streams would otherwise overwrite d_local under a
+    // gather still reading it).
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
 };
 
 namespace {
@@ -106,6 +136,21 @@ int grow(uint8_t** p, size_t* have, size_t need)
     *p = nullptr; *have = 0;
     RT_HIP(hipMalloc((void**)p, need));
     *have = need;
+    return RT_OK;
+}
+
+// before a call touches the scratch on `stream`: order it behind the previous call if that ran on another stream
+int scratch_acquire(RtComm* c, hipStream_t stream)
+{
+    if (c->scratch_used && c->scratch_stream != stream) RT_HIP(hipStreamWaitEvent(stream, c->scratch_done, 0));
+    return RT_OK;
+}
+// after a call's last use of the scratch has been issued on `stream`
+int scratch_release(RtComm* c, hipStream_t stream)
+{
+    if (!c->scratch_done) RT_HIP(hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming));
+    RT_HIP(hipEventRecord(c->scratch_done, stream));
+    c->scratch_stream = stream; c->scratch_used = true;
     return RT_OK;
 }
 
@@ -132,8 +177,9 @@ int tiling_of(const RtCameraParams* cam, int32_t stripe_rows, int32_t num_ranks,
 int render_local(RtScene* scene, RtComm* c, const RtCameraParams* cam, const RtRenderOptions* opts, const Tiling& t,
                  int32_t stripe_rows, hipStream_t stream)
 {
-    int rc = grow(&c->d_local, &c->local_bytes, std::max<size_t>(t.rank_bytes, 16));
+    int rc = scratch_acquire(c, stream);
     if (rc) return rc;
+    if ((rc = grow(&c->d_local, &c->local_bytes, std::max<size_t>(t.rank_bytes, 16)))) return rc;
     if (opts && (opts->spp != 1 || opts->bounces != 0 || opts->lighting != 0))
         return rt_render_ex_stripes(scene, cam, opts, c->d_local, t.local_pitch, stripe_rows, c->rank, c->num_ranks, stream, 0);
     return rt_render_stripes(scene, cam, c->d_local, t.local_pitch, stripe_rows, c->rank, c->num_ranks, stream, 0);
@@ -207,8 +253,16 @@ int rt_comm_init_all(const int32_t* devices, int32_t num_devices, RtComm** out)
 int rt_comm_info(const RtComm* c, int32_t* rank, int32_t* num_ranks, int32_t* device)
 {
     if (!c) return RT_E_INVALID;
-    if (rank) *rank = c->rank;
-    if (num_ranks) *num_ranks = c->num_ranks;
+    int rk = c->rank, n = c->num_ranks;
+    // what the communicator itself says (ncclCommUserRank / ncclCommCount), when the library has the two queries: a
+    // caller can check that RCCL formed the group it asked for
+    Rccl* r = rccl();
+    if (r && c->comm && r->CommCount && r->CommUserRank) {
+        RT_NCCL(r, r->CommCount(c->comm, &n), "ncclCommCount");
+        RT_NCCL(r, r->CommUserRank(c->comm, &rk), "ncclCommUserRank");
+    }
+    if (rank) *rank = rk;
+    if (num_ranks) *num_ranks = n;
     if (device) *device = c->device;
     return RT_OK;
 }
@@ -219,6 +273,7 @@ int rt_comm_destroy(RtComm* c)
     int prev = 0;
     const bool switched = hipGetDevice(&prev) == hipSuccess && prev != c->device && hipSetDevice(c->device) == hipSuccess;
     (void)hipFree(c->d_local); (void)hipFree(c->d_gathered);
+    if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
     Rccl* r = rccl();
     if (r && c->comm) (void)r->CommDestroy(c->comm);
     if (switched) (void)hipSetDevice(prev);
@@ -284,6 +339,7 @@ int rt_render_tiled(RtScene* scene, RtComm* c, const RtCameraParams* cam, const 
     if ((rc = rt_gather(c, c->d_local, t.rank_bytes, is_root ? c->d_gathered : nullptr, root, stream))) return rc;
     if (is_root && (rc = rt_unstripe(c->d_gathered, t.local_pitch, t.rank_bytes, d_img, pitch, cam->width, cam->height, stripe_rows,
                                      c->num_ranks, stream))) return rc;
+    if ((rc = scratch_release(c, st))) return rc;
     if (synchronize) RT_HIP(hipStreamSynchronize(st));
     return RT_OK;
 }
@@ -327,8 +383,12 @@ int rt_render_tiled_all(RtScene* const* scenes, RtComm* const* comms, int32_t nu
     if (rc == RT_OK && hipSetDevice(comms[root]->device) == hipSuccess) {
         rc = rt_unstripe(comms[root]->d_gathered, t.local_pitch, t.rank_bytes, d_img, pitch, cam->width, cam->height, stripe_rows,
                          num_ranks, stream_of(root));
-        if (rc == RT_OK && synchronize) rc = (int)hipStreamSynchronize((hipStream_t)stream_of(root));
     }
+    for (int r = 0; r < num_ranks && rc == RT_OK; r++) {            // every rank's scratch is busy until its gather (the root: its un-stripe) is done
+        if (hipSetDevice(comms[r]->device) != hipSuccess) { rc = RT_E_INVALID; break; }
+        rc = scratch_release(comms[r], (hipStream_t)stream_of(r));
+    }
+    if (rc == RT_OK && synchronize && hipSetDevice(comms[root]->device) == hipSuccess) rc = (int)hipStreamSynchronize((hipStream_t)stream_of(root));
     (void)hipSetDevice(prev);
     return rc;
 }

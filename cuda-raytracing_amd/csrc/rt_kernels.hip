@@ -1071,18 +1071,26 @@ struct RtScene {
     size_t device_bytes = 0;
     float4* d_ex_scratch = nullptr;              // extension renders: running sums + one chunk of samples (grow-only)
     size_t ex_scratch_bytes = 0;
-    // heavy-first dispatch of single-frame launches (render_kernel<.., ORDERED>, tile_sort_kernel)
+    // heavy-first dispatch of single-frame launches (render_kernel<.., ORDERED>, tile_sort_kernel): one order state per frame
+    // size, a few of them cached -- two cameras of different sizes, or whole frames next to a rank's stripes, alternate on one
+    // scene without ever meeting each other's state (a single state would be torn down and rebuilt, with a device-wide
+    // synchronise in hipFree, on every change of size)
     struct TileOrder {
-        std::mutex m;
         int tiles_x = 0, tiles_y = 0, ntiles = 0;
         int32_t *d_cost = nullptr, *d_keys = nullptr, *d_order[2] = {nullptr, nullptr};
         int cur = -1;                            // order buffer renders read (-1: none sorted yet -> natural order)
         bool pending = false;                    // a sort into d_order[target] is in flight on sort_stream
         int target = 0;
         hipEvent_t sort_done = nullptr;
+        uint64_t last_used = 0;
+        // the last ordered launch on each stream that uses this state (a sort waits for all of them)
+        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; uint64_t tick = 0; } seen[4];
+    };
+    struct TileOrderCache {
+        std::mutex m;
         hipStream_t sort_stream = nullptr;
-        // the last ordered launch on each stream that uses this scene (a sort waits for all of them)
-        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; } seen[4];
+        uint64_t tick = 0;
+        TileOrder entry[4];
     } order;
 };
 
@@ -1182,48 +1190,78 @@ hipError_t trace_end(RenderParams& p, size_t n, const char* path, hipStream_t st
 // Launch with heavy-first tile order.  The order a launch reads was sorted from the costs of an earlier
 // frame by tile_sort_kernel on the scene's own side stream, so sorting never sits between two frames on the caller's
 // stream; the host switches to a new order when it finds its sort finished (an event query, no wait) and keeps at most one
-// sort in flight: a sort writes the buffer no queued or running launch reads (every launch issued before the sort used the
-// other buffer or has finished -- the sort waits for the last ordered launch of every stream that renders this scene, up to
-// four; a fifth stream renders in natural order -- and every launch issued while the sort is pending still reads the
-// other buffer).
+// sort in flight per frame size: a sort writes the buffer no queued or running launch reads (every launch issued before the
+// sort used the other buffer or has finished -- the sort waits for the last ordered launch of every stream that renders this
+// size, up to four at a time; a stream slot whose launch has finished is handed to the next new stream -- and every launch
+// issued while the sort is pending still reads the other buffer).  Nothing here waits on the host or synchronises the
+// device, except when a FIFTH frame size evicts an idle state (its arrays are freed); a launch that finds no state it
+// may use renders in natural order.
+namespace {
+bool order_state_idle(RtScene::TileOrder& o)
+{
+    if (o.pending) { if (hipEventQuery(o.sort_done) != hipSuccess) return false; o.cur = o.target; o.pending = false; }
+    for (auto& e : o.seen) if (e.used && hipEventQuery(e.done) != hipSuccess) return false;
+    return true;
+}
+}  // namespace
+
 int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchronize)
 {
-    RtScene::TileOrder& o = s->order;
-    std::lock_guard<std::mutex> lock(o.m);
+    RtScene::TileOrderCache& cache = s->order;
+    std::lock_guard<std::mutex> lock(cache.m);
     const int ntiles = p.tiles_x * p.tiles_y;
-    if (o.tiles_x != p.tiles_x || o.tiles_y != p.tiles_y) {     // first use, or another frame size: start over
-        if (o.pending) { (void)hipEventSynchronize(o.sort_done); o.pending = false; }
-        (void)hipFree(o.d_cost);                                  // (hipFree waits for launches that still use the old arrays)
-        o.d_cost = o.d_keys = o.d_order[0] = o.d_order[1] = nullptr;
-        o.tiles_x = o.tiles_y = o.ntiles = 0; o.cur = -1;
-        if (!o.sort_stream) {
-            RT_HIP(hipStreamCreateWithFlags(&o.sort_stream, hipStreamNonBlocking));
-            RT_HIP(hipEventCreateWithFlags(&o.sort_done, hipEventDisableTiming));
-            for (auto& e : o.seen) RT_HIP(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+    if (!cache.sort_stream) RT_HIP(hipStreamCreateWithFlags(&cache.sort_stream, hipStreamNonBlocking));
+    RtScene::TileOrder* o = nullptr;
+    for (auto& e : cache.entry) if (e.ntiles && e.tiles_x == p.tiles_x && e.tiles_y == p.tiles_y) o = &e;
+    if (!o) {                                                   // a size not seen before: a free state, else the least recently used idle one
+        for (auto& e : cache.entry) if (!e.ntiles && !o) o = &e;
+        if (!o) {
+            RtScene::TileOrder* lru = nullptr;
+            for (auto& e : cache.entry) if (!lru || e.last_used < lru->last_used) lru = &e;
+            if (order_state_idle(*lru)) {
+                (void)hipFree(lru->d_cost);
+                lru->d_cost = lru->d_keys = lru->d_order[0] = lru->d_order[1] = nullptr;
+                lru->tiles_x = lru->tiles_y = lru->ntiles = 0; lru->cur = -1; lru->pending = false;
+                for (auto& e : lru->seen) e.used = false;
+                o = lru;
+            }
         }
-        for (auto& e : o.seen) e.used = false;                   // (hipFree above waited for every launch in flight)
-        RT_HIP(hipMalloc((void**)&o.d_cost, (size_t)ntiles * 4 * sizeof(int32_t)));
-        RT_HIP(hipMemsetAsync(o.d_cost, 0, (size_t)ntiles * sizeof(int32_t), stream));
-        o.d_keys = o.d_cost + ntiles; o.d_order[0] = o.d_keys + ntiles; o.d_order[1] = o.d_order[0] + ntiles;
-        o.tiles_x = p.tiles_x; o.tiles_y = p.tiles_y; o.ntiles = ntiles;
+        if (o) {
+            if (!o->sort_done) {
+                RT_HIP(hipEventCreateWithFlags(&o->sort_done, hipEventDisableTiming));
+                for (auto& e : o->seen) RT_HIP(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+            }
+            RT_HIP(hipMalloc((void**)&o->d_cost, (size_t)ntiles * 4 * sizeof(int32_t)));
+            RT_HIP(hipMemsetAsync(o->d_cost, 0, (size_t)ntiles * sizeof(int32_t), stream));
+            o->d_keys = o->d_cost + ntiles; o->d_order[0] = o->d_keys + ntiles; o->d_order[1] = o->d_order[0] + ntiles;
+            o->tiles_x = p.tiles_x; o->tiles_y = p.tiles_y; o->ntiles = ntiles;
+        }
     }
-    if (o.pending && hipEventQuery(o.sort_done) == hipSuccess) { o.cur = o.target; o.pending = false; }
     RtScene::TileOrder::Seen* mine = nullptr;
-    for (auto& e : o.seen) if (e.used && e.stream == stream) mine = &e;
-    if (!mine) for (auto& e : o.seen) if (!e.used) { mine = &e; e.used = true; e.stream = stream; break; }
-    p.tile_order = (mine && o.cur >= 0) ? o.d_order[o.cur] : nullptr;
-    p.tile_cost = mine ? o.d_cost : nullptr;
+    if (o) {
+        o->last_used = ++cache.tick;
+        if (o->pending && hipEventQuery(o->sort_done) == hipSuccess) { o->cur = o->target; o->pending = false; }
+        for (auto& e : o->seen) if (e.used && e.stream == stream) mine = &e;
+        if (!mine) for (auto& e : o->seen) if (!e.used) { mine = &e; break; }
+        if (!mine) {                                            // all four slots taken: the one whose launch finished longest ago
+            for (auto& e : o->seen)
+                if (hipEventQuery(e.done) == hipSuccess && (!mine || e.tick < mine->tick)) mine = &e;
+        }
+        if (mine) { mine->used = true; mine->stream = stream; mine->tick = cache.tick; }
+    }
+    p.tile_order = (mine && o->cur >= 0) ? o->d_order[o->cur] : nullptr;
+    p.tile_cost = mine ? o->d_cost : nullptr;
     const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int) + 2 * sizeof(int);
     hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     RT_HIP(hipGetLastError());
     if (mine) RT_HIP(hipEventRecord(mine->done, stream));
-    if (mine && !o.pending) {
-        o.target = o.cur < 0 ? 0 : o.cur ^ 1;
-        for (auto& e : o.seen) if (e.used) RT_HIP(hipStreamWaitEvent(o.sort_stream, e.done, 0));
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, o.sort_stream, o.d_cost, ntiles, o.d_keys, o.d_order[o.target]);
+    if (mine && !o->pending) {
+        o->target = o->cur < 0 ? 0 : o->cur ^ 1;
+        for (auto& e : o->seen) if (e.used) RT_HIP(hipStreamWaitEvent(cache.sort_stream, e.done, 0));
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, cache.sort_stream, o->d_cost, ntiles, o->d_keys, o->d_order[o->target]);
         RT_HIP(hipGetLastError());
-        RT_HIP(hipEventRecord(o.sort_done, o.sort_stream));
-        o.pending = true;
+        RT_HIP(hipEventRecord(o->sort_done, cache.sort_stream));
+        o->pending = true;
     }
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
@@ -1568,13 +1606,12 @@ int rt_scene_refit_mesh_device(RtScene* s, int32_t mesh_index, const float* d_ve
 int rt_scene_destroy(RtScene* s)
 {
     if (!s) return RT_OK;
-    if (s->order.sort_stream) {
-        (void)hipStreamSynchronize(s->order.sort_stream);
-        (void)hipEventDestroy(s->order.sort_done);
-        for (auto& e : s->order.seen) (void)hipEventDestroy(e.done);
-        (void)hipStreamDestroy(s->order.sort_stream);
+    if (s->order.sort_stream) (void)hipStreamSynchronize(s->order.sort_stream);
+    for (auto& o : s->order.entry) {
+        if (o.sort_done) { (void)hipEventDestroy(o.sort_done); for (auto& e : o.seen) (void)hipEventDestroy(e.done); }
+        (void)hipFree(o.d_cost);
     }
-    (void)hipFree(s->order.d_cost);
+    if (s->order.sort_stream) (void)hipStreamDestroy(s->order.sort_stream);
     for (auto& rf : s->mesh_refit) (void)hipFree(rf.d_sched);
     (void)hipFree(s->d_refit_scratch);
     (void)hipFree(s->d_ex_scratch);

@@ -17,7 +17,8 @@
  * RT_TILE_ORDER=0 turns the heavy-first dispatch order of single-frame launches off; RT_BVH_LIBRARY_SCAN=1 makes
  * rt_bvh_build use the partition path of meshes above 1 M triangles; RT_BVH_DEBUG=1 prints its phase timings;
  * RT_BVH_SMALL=k (0..64) lowers the size of the subtrees one wave finishes on its own (0: level loop only; tests);
- * RT_RCCL_LIBRARY=<path> makes rt_comm_* load that library instead of librccl.so.1 (tests: an in-process mock).
+ * RT_RCCL_LIBRARY=<path> makes rt_comm_* load that library instead of librccl.so.1 (tests: an in-process mock); if it cannot
+ * be loaded or lacks an entry point, rt_comm_* fail with RT_E_COMM (rt_comm_last_error() has the loader's message).
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -228,6 +229,8 @@ const char *rt_comm_last_error(void);                    /* text of the calling 
 int rt_comm_unique_id(uint8_t *id /* [RT_COMM_ID_BYTES] */);
 int rt_comm_init_rank(const uint8_t *id, int32_t rank, int32_t num_ranks, RtComm **out);   /* on the current device */
 int rt_comm_init_all(const int32_t *devices, int32_t num_devices, RtComm **comms);
+/* rank and size as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount; the values given at creation
+ * if the library lacks the two queries), and the device it lives on */
 int rt_comm_info(const RtComm *comm, int32_t *rank, int32_t *num_ranks, int32_t *device);
 int rt_comm_destroy(RtComm *comm);
 int rt_group_start(void);                                /* ncclGroupStart / ncclGroupEnd for single-process callers */
@@ -242,8 +245,10 @@ int rt_all_to_all(RtComm *comm, const void *d_send, const size_t *send_bytes, co
                   void *d_recv, const size_t *recv_bytes, const size_t *recv_offsets, void *stream);
 /* One tiled frame, the whole of SURVEY.md 8(e) in one call made by every rank: render this rank's stripes (rt_render_stripes,
  * or rt_render_ex_stripes when opts is non-NULL and not the default 1 / 0 / 0), gather them to `root`, and on the root
- * put the rows back into frame order in d_img (may be NULL on other ranks).  Scratch buffers live in the communicator.
- * With one rank this is rt_render / rt_render_ex. */
+ * put the rows back into frame order in d_img (may be NULL on other ranks).  Scratch buffers live in the communicator:
+ * consecutive calls on one RtComm may use different streams (frames alternated between two streams) -- each call waits, on its
+ * stream, for the previous call's last use of the scratch (an event, no host synchronisation); calls on one RtComm from
+ * several host threads at once are not supported.  With one rank this is rt_render / rt_render_ex. */
 int rt_render_tiled(RtScene *scene, RtComm *comm, const RtCameraParams *cam, const RtRenderOptions *opts, uint8_t *d_img,
                     size_t pitch, int32_t stripe_rows, int32_t root, void *stream, int synchronize);
 /* the same from ONE process that holds a scene replica and a communicator per device (rt_comm_init_all):

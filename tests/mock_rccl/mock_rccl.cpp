@@ -141,6 +141,8 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int n, ncclUniqueId id, int rank)
     return ncclSuccess;
 }
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int*) { for (int i = 0; i < n; i++) comms[i] = new MockComm{i, n, nullptr, nullptr, {0}}; return ncclSuccess; }
+ncclResult_t ncclCommCount(const ncclComm_t c, int* n) { *n = c->nranks; return ncclSuccess; }
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* r) { *r = c->rank; return ncclSuccess; }
 ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
     if (c && c->shm) munmap((void*)c->shm, sizeof(ShmHeader) + (size_t)c->shm->n * c->shm->region_bytes);

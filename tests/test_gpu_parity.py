@@ -517,6 +517,75 @@ def test_c4_atrium_4k(rt, orc, scenes, atrium):
     so.close()
 
 
+def test_heavy_first_order_with_alternating_frame_sizes_and_many_streams(rt, scenes, blob70k):
+    """Single-frame launches of two sizes alternate on one scene (two cameras), each issued while a long batch is still
+    running on another stream: every size has its own order state, so no call tears anything down or synchronises the device
+    -- the calls return while the long batch is still in flight -- and all frames equal the natural-order kernel's.  Then more
+    than four streams take turns on one size (a stream slot whose launch has finished is recycled), then a fifth and sixth
+    size arrive (an idle state is evicted, or the launch falls back to natural order): same frames throughout."""
+    import time
+    import torch
+    sp = sd.blob_scene(scenes, blob70k).build_product(rt)
+    sp.upload_to_device()
+    h = rt.libs()[0]
+    sizes = [(1920, 1080), (1920, 544)]
+    pose = scenes.C2_CAMERAS["mid"]
+    cams, imgs, want = [], [], []
+    for W, H in sizes:
+        K = scenes.scaled_K(W)
+        c = rt.Camera(W, H, K, scenes.D_REF)
+        c.set_pose(pose)
+        cams.append(c)
+        imgs.append(rt.DeviceBuffer(width_bytes=W * 3, height=H))
+        want.append(rt.render_ids(sp, c)["img"])
+    # warm both states up (first use allocates)
+    for c, im in zip(cams, imgs):
+        c.render_scene(sp, im.ptr, im.pitch, synchronize=True)
+    long_stream, side = torch.cuda.Stream(), torch.cuda.Stream()
+    big = rt.Camera(1920, 1080, scenes.scaled_K(1920), scenes.D_REF)
+    big.set_stream(long_stream.cuda_stream)
+    F = 32
+    bufs = rt.DeviceBuffer(nbytes=F * 1080 * 1920 * 3)
+    ptrs = [bufs.ptr.value + k * 1080 * 1920 * 3 for k in range(F)]
+    done = torch.cuda.Event()
+    for _ in range(12):                                              # ~12 x 4.2 ms of work queued on long_stream
+        big.render_scene_batch(sp, [pose] * F, ptrs, 1920 * 3)
+    done.record(long_stream)
+    for c in cams:
+        c.set_stream(side.cuda_stream)
+    t0 = time.perf_counter()
+    for k in range(10):
+        cams[k & 1].render_scene(sp, imgs[k & 1].ptr, imgs[k & 1].pitch)
+    host_ms = (time.perf_counter() - t0) * 1e3
+    still_running = not done.query()
+    torch.cuda.synchronize()
+    assert still_running and host_ms < 25.0, (still_running, host_ms)        # a device-wide synchronise would have waited ~50 ms for the batch
+    for k in range(2):
+        assert np.array_equal(imgs[k].to_host().reshape(sizes[k][1], sizes[k][0], 3), want[k])
+    # six streams on one size
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    outs = [rt.DeviceBuffer(width_bytes=1920 * 3, height=1080) for _ in streams]
+    for rep in range(3):
+        for st, o in zip(streams, outs):
+            cams[0].set_stream(st.cuda_stream)
+            cams[0].render_scene(sp, o.ptr, o.pitch)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert np.array_equal(o.to_host().reshape(1080, 1920, 3), want[0])
+    # six sizes in rotation: more than the four cached states
+    more = [(1920, 1080), (1920, 544), (1600, 912), (1280, 1024), (2048, 640), (1760, 800)]
+    for rep in range(2):
+        for W, H in more:
+            c = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+            c.set_pose(pose)
+            ref = rt.render_ids(sp, c)["img"]
+            im = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+            c.render_scene(sp, im.ptr, im.pitch)
+            c.render_scene(sp, im.ptr, im.pitch, synchronize=True)
+            assert np.array_equal(im.to_host().reshape(H, W, 3), ref), (W, H)
+    rt.check(h.rt_device_synchronize())
+
+
 def test_deep_traversal_stack_spills(rt, orc, scenes):
     """Stack entries beyond the 16 kept in LDS go to the private spill array; counts and hits must not change."""
     desc = sd.deep_stack_scene(28)

@@ -187,8 +187,26 @@ def test_bench_ranks_as_processes_over_mock_transport(mock_rccl, extra):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == int(extra[1]) and "RT_RCCL_LIBRARY" in line["REHEARSAL_NOT_A_MEASUREMENT"] and "EXCHANGE_FALLBACK" not in line
+    assert line["ranks_seen"] == int(extra[1])                       # the size the (mock) communicator itself reports
     assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
     assert "rt_" in line["config"]["parallelism"]
+
+
+def test_bench_rank_that_never_joins_ends_the_run_inside_the_deadline(mock_rccl):
+    """A peer that never reaches the communicator: rank 0 is then stuck inside rt_comm_init_rank (the mock, like RCCL, returns
+    when every rank has joined).  bench.py's phase watchdog must end the run -- non-zero exit, no result line, the phase and
+    rt_comm_last_error() on stderr -- within its deadline instead of leaving it to whoever started the run to time out."""
+    import time
+    env = dict(os.environ, RT_RCCL_LIBRARY=mock_rccl)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--debug-backend", "gloo", "--no-cpu-baseline", "--gpus", "2", "--workload", "c2",
+                        "--width", "320", "--height", "192", "--steps", "8", "--warmup", "2", "--phase-deadline", "12", "--test-stall", "1:communicator"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0 and r.stdout.strip() == "", (r.returncode, r.stdout)
+    assert "phase 'communicator' exceeded its deadline of 12 s" in r.stderr and "rt_comm_last_error()" in r.stderr, r.stderr[-3000:]
+    assert "phases completed: process group, scene" in r.stderr
+    assert took < 150, took                                          # start-up + the 12 s deadline + torchrun's tear-down; not the mock's own 120 s
 
 
 def test_cpp_tiled_application(rt, orc, scenes, blob5k, tmp_path):

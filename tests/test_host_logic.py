@@ -459,6 +459,32 @@ def test_hostile_image_files_are_refused(rt, tmp_path):
     with pytest.raises(rt.RtError):
         rt.read_image(p)
 
+    # a sequential file that codes its components twice: the second scan would be decoded on top of the first one's coefficients
+    eoi = jpg.rindex(b"\xff\xd9")
+    p = str(tmp_path / "scan_twice.jpg")
+    open(p, "wb").write(jpg[:eoi] + jpg[j:eoi] + jpg[eoi:])
+    with pytest.raises(rt.RtError, match="scanned twice"):
+        rt.read_image(p)
+
+    # DC differences that run the predictor out of the 16-bit coefficient range (32 blocks of +2047 each): corrupt data, not an
+    # integer overflow.  The same file with alternating signs is a valid image and decodes.
+    def grey_jpeg(diff_bits):
+        seg = lambda m, body: b"\xff" + bytes([m]) + struct.pack(">H", len(body) + 2) + body
+        bits = "".join("0" + b + "0" for b in diff_bits)            # DC code '0' = category 11, the 11 value bits, AC code '0' = end of block
+        bits += "1" * (-len(bits) % 8)
+        data = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)).replace(b"\xff", b"\xff\x00")
+        return (b"\xff\xd8" + seg(0xDB, b"\x00" + bytes([1] * 64)) + seg(0xC0, struct.pack(">BHHB", 8, 8, 8 * len(diff_bits), 1) + b"\x01\x11\x00")
+                + seg(0xC4, b"\x00" + bytes([1] + [0] * 15) + b"\x0b") + seg(0xC4, b"\x10" + bytes([1] + [0] * 15) + b"\x00")
+                + seg(0xDA, b"\x01\x01\x00\x00\x3f\x00") + data + b"\xff\xd9")
+    up, down = "1" * 11, "0" * 11                                       # +2047, -2047
+    p = str(tmp_path / "dc_ok.jpg")
+    open(p, "wb").write(grey_jpeg([up, down] * 16))
+    assert rt.read_image(p).shape == (8, 256, 3)
+    p = str(tmp_path / "dc_runaway.jpg")
+    open(p, "wb").write(grey_jpeg([up] * 32))
+    with pytest.raises(rt.RtError, match="corrupt JPEG data"):
+        rt.read_image(p)
+
     def chunk(t, body):
         return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
     ihdr = struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)                # 4 x 4 RGB: 52 bytes of image data
@@ -632,3 +658,19 @@ def test_obj_parse_is_the_same_on_one_thread_and_on_many(rt, tmp_path, blob70k, 
     broken[50000] = "vt x y"
     (tmp_path / "broken.obj").write_text("\n".join(broken))
     assert parse(tmp_path / "broken.obj", 1, 1) == parse(tmp_path / "broken.obj", 1, 6) == "malformed v record"
+
+
+def test_forced_rccl_library_that_cannot_be_loaded_is_an_error(rt, tmp_path):
+    """RT_RCCL_LIBRARY names the library to use: if it cannot be loaded, or lacks an entry point, rt_comm_* fail with RT_E_COMM and
+    the loader's message -- never a silent switch to the system's RCCL (no GPU involved: loading is all that happens)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, sys; rt = importlib.import_module('cuda-raytracing_amd'); import ctypes as C\n"
+            "h = rt.libs()[0]; v = C.c_int32(0); rc = h.rt_comm_available(C.byref(v)); print(rc, rt.Comm.last_error())")
+    bad = str(tmp_path / "not_a_library.so")
+    open(bad, "w").write("this is not an ELF file")
+    for path, needle in ((str(tmp_path / "missing.so"), "could not be loaded"), (bad, "could not be loaded"), ("libm.so.6", "lacks ncclGetUniqueId")):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, RT_RCCL_LIBRARY=path))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split()[0] == "-5" and needle in r.stdout, r.stdout
