@@ -62,7 +62,7 @@ class RtSceneDesc(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
+    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_render", "rt_render_batch",
     "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch",
     "rt_comm_available", "rt_comm_last_error", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_info", "rt_comm_destroy",
     "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
@@ -71,7 +71,7 @@ RT_HOST_SYMBOLS = [
     "rth_obj_load", "rth_obj_parse", "rth_scan_float", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
     "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
     "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
-    "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance", "rth_scene_update_mesh_instance_async", "rth_scene_refit_mesh",
+    "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance", "rth_scene_update_mesh_instance_async", "rth_scene_refit_mesh", "rth_scene_rebuild_mesh",
     "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
     "rth_camera_render_scene_tiled", "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
@@ -127,6 +127,8 @@ def _declare(h, s):
     h.rt_scene_update_instance_async.argtypes = [_vp, C.c_int32, _vp, _vp]
     h.rt_scene_refit_mesh.argtypes = [_vp, C.c_int32, _f, _f, C.c_int32, _vp]
     h.rt_scene_refit_mesh_device.argtypes = [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]
+    h.rt_scene_rebuild_mesh_device.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp]
+    h.rt_scene_debug_read.argtypes = [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
     h.rt_scene_destroy.argtypes = [_vp]
     h.rt_render.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, C.c_int]
     h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
@@ -182,6 +184,7 @@ def _declare(h, s):
     s.rth_scene_update_mesh_instance.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _f, _f]
     s.rth_scene_update_mesh_instance_async.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, _f, _f, _vp]
     s.rth_scene_refit_mesh.argtypes = [_vp, C.c_int32, _f, C.c_int32, _vp]
+    s.rth_scene_rebuild_mesh.argtypes = [_vp, C.c_int32, _f, C.c_int32, _vp]
     s.rth_instance_build.argtypes = [_f, _f, _f]
     s.rth_camera_create.argtypes = [C.c_int32, C.c_int32, _f, _f]
     s.rth_camera_set_pose.argtypes = [_vp, _f]
@@ -350,6 +353,19 @@ class Scene:
         """Scene::refit_mesh: the mesh deformed (same triangle count and order): new records, refitted bounds, no rebuild."""
         t = _fa(tris18).reshape(-1, 18)
         check(libs()[1].rth_scene_refit_mesh(self.h, mesh_index, _fp(t), t.shape[0], stream), "Scene::refit_mesh")
+
+    def rebuild_mesh(self, mesh_index, tris18, stream=None):
+        """Scene::rebuild_mesh: new triangles (at most as many as at upload): a new tree, built on the GPU in place."""
+        t = _fa(tris18).reshape(-1, 18)
+        check(libs()[1].rth_scene_rebuild_mesh(self.h, mesh_index, _fp(t), t.shape[0], stream), "Scene::rebuild_mesh")
+
+    def debug_read(self, which, dtype):
+        """tests: one of the device arrays of the uploaded scene (rt_scene_debug_read) as a numpy array of `dtype`."""
+        n = C.c_size_t(0)
+        check(libs()[0].rt_scene_debug_read(self.device_handle, which, None, 0, C.byref(n)), "rt_scene_debug_read")
+        out = np.zeros(n.value, np.uint8)
+        check(libs()[0].rt_scene_debug_read(self.device_handle, which, out.ctypes.data, n.value, C.byref(n)), "rt_scene_debug_read")
+        return out.view(dtype)
 
     @property
     def device_handle(self):

@@ -19,10 +19,13 @@ public:
     // scene, whose device copy is refitted by the GPU at once: walking the host tree costs twenty times the device refit
     // and is only needed if the mesh is uploaded again or bvh_top is read (call sync_tree() first).
     bool refit(std::vector<TrianglePrimitive> moved, bool defer_tree = false);
+    // new triangles altogether (any count): the tree is rebuilt, at once or (defer_tree) when sync_tree() is next called --
+    // Scene::rebuild_mesh defers, because the device copy gets its new tree from the GPU build
+    void replace(std::vector<TrianglePrimitive> triangles, bool defer_tree = false);
     void sync_tree();
     bool tree_is_stale() const { return tree_stale; }
 
 private:
     std::vector<TrianglePrimitive> triangles;
-    bool tree_stale = false;
+    bool tree_stale = false, tree_needs_rebuild = false;
 };

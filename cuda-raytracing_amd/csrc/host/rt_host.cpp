@@ -409,11 +409,46 @@ bool MeshPrimitive::refit(std::vector<TrianglePrimitive> moved, bool defer_tree)
     return true;
 }
 
+void MeshPrimitive::replace(std::vector<TrianglePrimitive> tris, bool defer_tree)
+{
+    triangles = std::move(tris);
+    num_triangles = (int)triangles.size();
+    tree_stale = tree_needs_rebuild = true;
+    if (!defer_tree) sync_tree();
+}
+
 void MeshPrimitive::sync_tree()
 {
     if (!tree_stale) return;
-    bvh_top.refit(triangles.data(), num_triangles);
-    tree_stale = false;
+    if (tree_needs_rebuild) bvh_top.build(triangles.data(), num_triangles);       // MeshPrimitive.cpp:38-56
+    else bvh_top.refit(triangles.data(), num_triangles);
+    tree_stale = tree_needs_rebuild = false;
+}
+
+void Scene::rebuild_mesh(int mesh_index, std::vector<TrianglePrimitive> tris, void* stream)
+{
+    if (mesh_index < 0 || mesh_index >= (int)meshes.size()) { last_error = RT_E_INVALID; return; }
+    MeshPrimitive& m = meshes[(size_t)mesh_index];
+    m.replace(std::move(tris), d_scene != nullptr);
+    if (!d_scene) { last_error = RT_OK; return; }               // not uploaded yet: upload_to_device() will send the new mesh
+    const size_t n = (size_t)m.num_triangles;
+    std::vector<float> host(n * 18);                            // vertices [n][9], normals [n][3], uvs [n][6]
+    float *v = host.data(), *nn = v + n * 9, *uv = nn + n * 3;
+    for (size_t t = 0; t < n; t++) {
+        const TrianglePrimitive& tr = m.triangle_array()[t];
+        for (int k = 0; k < 3; k++) {
+            v[9 * t + 3 * k] = tr.vertices[k].x; v[9 * t + 3 * k + 1] = tr.vertices[k].y; v[9 * t + 3 * k + 2] = tr.vertices[k].z;
+            uv[6 * t + 2 * k] = tr.uv_coords[k].x; uv[6 * t + 2 * k + 1] = tr.uv_coords[k].y;
+        }
+        nn[3 * t] = tr.normal.x; nn[3 * t + 1] = tr.normal.y; nn[3 * t + 2] = tr.normal.z;
+    }
+    void* d = nullptr;
+    last_error = rt_malloc(&d, host.size() * sizeof(float));
+    if (last_error) return;
+    last_error = rt_memcpy_h2d(d, host.data(), host.size() * sizeof(float), stream);
+    const float* dv = (const float*)d;
+    if (last_error == RT_OK) last_error = rt_scene_rebuild_mesh_device(d_scene, mesh_index, dv, dv + n * 9, dv + n * 12, (int32_t)n, stream);
+    (void)rt_free(d);
 }
 
 void Scene::refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream)

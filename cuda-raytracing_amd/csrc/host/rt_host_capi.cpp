@@ -165,6 +165,15 @@ int rth_scene_refit_mesh(RthScene* s, int32_t mesh_index, const float* tris18, i
         return s->scene.last_error;
     } catch (const std::exception& e) { g_err = e.what(); return RT_E_NOMEM; }
 }
+int rth_scene_rebuild_mesh(RthScene* s, int32_t mesh_index, const float* tris18, int32_t n, void* stream)
+{
+    try {
+        std::vector<TrianglePrimitive> tris((size_t)(n > 0 ? n : 0));
+        if (n > 0) memcpy((void*)tris.data(), tris18, (size_t)n * 72);
+        s->scene.rebuild_mesh(mesh_index, std::move(tris), stream);
+        return s->scene.last_error;
+    } catch (const std::exception& e) { g_err = e.what(); return RT_E_NOMEM; }
+}
 int32_t rth_scene_num_mesh_instances(const RthScene* s) { return s->scene.num_mesh_instances; }
 void* rth_scene_device_handle(RthScene* s) { return s->scene.d_scene; }
 void rth_instance_build(const float* pose6, const float* scale3, float* out24)

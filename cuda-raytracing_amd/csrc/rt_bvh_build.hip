@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "rt_scene_internal.h"
 
 #define RT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
 
@@ -721,21 +722,33 @@ char* g_arena = nullptr;
 size_t g_arena_bytes = 0;
 int g_arena_device = -1;
 
-}  // namespace
+constexpr size_t kExtraBytes = 2048;
 
-extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth, float* node_bounds, int32_t* node_children,
-                            int32_t* node_leaf_first, int32_t* node_leaf_count, int32_t* leaf_indices, int32_t* num_nodes,
-                            int32_t* num_levels)
+// What a finished build leaves on the device (in the cached arena: valid until the next build of the process; the arena
+// mutex is held by whoever uses it).
+struct DeviceBuild {
+    BuildNode* nodes = nullptr;         // breadth-first
+    BuildState* state = nullptr;
+    int32_t* ends_before = nullptr;     // exclusive scan of the range-end histogram (pre-order numbering, see preorder_of)
+    int32_t* order = nullptr;           // triangle indices in leaf order
+    int32_t *hist = nullptr, *hist_scan = nullptr;      // n + 2 ints each: free for the caller after the build
+    char* extra = nullptr;                              // kExtraBytes of scratch for the caller
+    void* tmp = nullptr; size_t tmp_bytes = 0;          // scan scratch (n + 2 items)
+    float *bounds = nullptr; int32_t *children = nullptr, *leaf_first = nullptr, *leaf_count = nullptr;   // emit_kernel's outputs
+    BuildState st;                      // host copy after the last kernel
+    int cap = 0;
+};
+
+// The build itself: `vertices` is a host array (copied into the arena) or, with on_device, a device array used where it lies.
+// Kernels run on `stream`; the few state read-backs wait for it.  Caller holds g_arena_mutex.
+int build_core(const float* vertices, bool on_device, int32_t n, int32_t max_depth, hipStream_t stream, bool emit_host_layout, DeviceBuild& out)
 {
-    if (n < 0 || max_depth < 1 || (n > 0 && !vertices) || !node_bounds || !node_children || !node_leaf_first ||
-        !node_leaf_count || !num_nodes || (n > 0 && !leaf_indices)) return RT_E_INVALID;
     if (max_depth > kMaxLevels) max_depth = kMaxLevels;          // (levels beyond the table cannot be represented; the reference uses 32)
     int rc = RT_OK;
     const int cap = n > 0 ? 2 * n : 1;                           // <= 2n - 1 nodes
     const int T = 256;
     const int gridN = (n + T - 1) / T;
     const int bins_per_level = n / 2 + 1;                        // nodes that evaluate a split hold >= 2 triangles each
-    std::lock_guard<std::mutex> lock(g_arena_mutex);
     float *d_v, *d_centroid, *d_tbox, *d_bounds;
     int32_t *d_order[2], *d_nodeof[2], *d_flags, *d_scan, *d_btot, *d_hist, *d_hscan, *d_children, *d_lfirst, *d_lcount, *d_small;
     BuildNode* d_nodes;
@@ -743,8 +756,8 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
     BuildState* d_state;
     void* d_tmp;
     size_t tmp_bytes = 0, tmp2 = 0;
-    int cur = 0, total = 0;
-    BuildState st;
+    int cur = 0;
+    BuildState& st = out.st;
 
     {
         hipError_t e1 = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n > 0 ? n : 1);
@@ -754,12 +767,13 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
         const size_t n1 = n > 0 ? (size_t)n : 1;
         size_t off = 0;
         auto take = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-        const size_t o_v = take(n1 * 9 * 4), o_cen = take(n1 * 3 * 4), o_tbox = take(n1 * 6 * 4), o_ord0 = take(n1 * 4), o_ord1 = take(n1 * 4),
+        const size_t o_v = take(on_device ? 4 : n1 * 9 * 4), o_cen = take(n1 * 3 * 4), o_tbox = take(n1 * 6 * 4), o_ord0 = take(n1 * 4), o_ord1 = take(n1 * 4),
                      o_nof0 = take(n1 * 4), o_nof1 = take(n1 * 4), o_flags = take(n1 * 4), o_scan = take(n1 * 4), o_btot = take(((n1 + 255) / 256 + 1) * 4), o_hist = take((n1 + 2) * 4), o_hscan = take((n1 + 2) * 4),
                      o_state = take(sizeof(BuildState)), o_nodes = take(((size_t)cap + 2) * sizeof(BuildNode)),
                      o_bins = take(2 * (size_t)bins_per_level * sizeof(Bins)), o_tmp = take(tmp_bytes ? tmp_bytes : 1),
                      o_bounds = take((size_t)cap * 6 * 4), o_children = take((size_t)cap * 2 * 4), o_lfirst = take((size_t)cap * 4),
-                     o_lcount = take((size_t)cap * 4), o_small = take((n1 / 2 + 2) * 4);
+                     o_lcount = take((size_t)cap * 4), o_small = take((n1 / 2 + 2) * 4),
+                     o_hscan2 = take((n1 + 2) * 4), o_extra = take(kExtraBytes);      // (used by the device-resident rebuild)
         int device = 0;
         hipError_t he = hipGetDevice(&device);
         if (he != hipSuccess) return he == hipErrorNoDevice ? RT_E_NODEVICE : (int)he;
@@ -771,7 +785,8 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
             g_arena_bytes = off + off / 4; g_arena_device = device;
         }
         char* arena = g_arena;
-        d_v = (float*)(arena + o_v); d_centroid = (float*)(arena + o_cen); d_tbox = (float*)(arena + o_tbox);
+        d_v = on_device ? const_cast<float*>(vertices) : (float*)(arena + o_v);
+        d_centroid = (float*)(arena + o_cen); d_tbox = (float*)(arena + o_tbox);
         d_order[0] = (int32_t*)(arena + o_ord0); d_order[1] = (int32_t*)(arena + o_ord1);
         d_nodeof[0] = (int32_t*)(arena + o_nof0); d_nodeof[1] = (int32_t*)(arena + o_nof1);
         d_flags = (int32_t*)(arena + o_flags); d_scan = (int32_t*)(arena + o_scan); d_btot = (int32_t*)(arena + o_btot); d_hist = (int32_t*)(arena + o_hist); d_hscan = (int32_t*)(arena + o_hscan);
@@ -779,6 +794,7 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
         d_nodes = (BuildNode*)(arena + o_nodes); d_bins = (Bins*)(arena + o_bins); d_tmp = arena + o_tmp;
         d_bounds = (float*)(arena + o_bounds); d_children = (int32_t*)(arena + o_children);
         d_lfirst = (int32_t*)(arena + o_lfirst); d_lcount = (int32_t*)(arena + o_lcount); d_small = (int32_t*)(arena + o_small);
+        out.hist_scan = (int32_t*)(arena + o_hscan2); out.extra = arena + o_extra;
     }
     // subtrees of at most this many triangles leave the level loop and are finished by one wave each (RT_BVH_SMALL=0: everything
     // goes through the level loop, the tests' way of keeping that path covered)
@@ -787,12 +803,16 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
 
     const bool debug = getenv("RT_BVH_DEBUG") != nullptr;           // diagnostics: phase timings (with extra synchronisation) and a state dump
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto read_state = [&]() -> hipError_t {                         // the level loop's question to the device: one small read-back
+        hipError_t e = hipMemcpyAsync(&st, d_state, sizeof st, hipMemcpyDeviceToHost, stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(stream);
+    };
     double t_start = now(), t_in = 0, t_kernels = 0;
-    if (n > 0) RT_HIP(hipMemcpyAsync(d_v, vertices, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, 0));
+    if (n > 0 && !on_device) RT_HIP(hipMemcpyAsync(d_v, vertices, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, stream));
     if (debug) { (void)hipDeviceSynchronize(); t_in = now(); }
-    hipLaunchKernelGGL(prep_kernel, dim3((n + 1 + T - 1) / T), dim3(T), 0, 0, d_v, n, max_depth, d_centroid, d_tbox, d_order[0], d_nodeof[0],
+    hipLaunchKernelGGL(prep_kernel, dim3((n + 1 + T - 1) / T), dim3(T), 0, stream, d_v, n, max_depth, d_centroid, d_tbox, d_order[0], d_nodeof[0],
                        d_nodes, d_bins, d_state, d_hist, d_small, small_limit);
-    if (n > 0) hipLaunchKernelGGL(root_bounds_kernel, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, 0, n, d_tbox, d_nodes);
+    if (n > 0) hipLaunchKernelGGL(root_bounds_kernel, dim3(std::min(64, (n + 1023) / 1024)), dim3(1024), 0, stream, n, d_tbox, d_nodes);
 
     // ---- the level loop: four launches per level.  Where a level starts and ends is device state, so the host enqueues
     //      levels without waiting; it only has to learn when to stop.  Nodes of more than small_limit triangles are gone
@@ -810,24 +830,24 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
             for (int l = 0; l < levels_to_run; l++) {
                 const long long width = l < 30 ? (1ll << l) : (1ll << 30);
                 const int gridL = (int)(((width < n ? width : (long long)n) + T - 1) / T);
-                hipLaunchKernelGGL(bins_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_tbox, d_nodes, d_bins, d_state, l);
-                hipLaunchKernelGGL(decide_kernel, dim3(gridL), dim3(T), 0, 0, d_nodes, d_bins, bins_per_level, d_state, l, max_depth, cap,
+                hipLaunchKernelGGL(bins_kernel, dim3(gridN), dim3(T), 0, stream, d_order[cur], d_nodeof[cur], n, d_centroid, d_tbox, d_nodes, d_bins, d_state, l);
+                hipLaunchKernelGGL(decide_kernel, dim3(gridL), dim3(T), 0, stream, d_nodes, d_bins, bins_per_level, d_state, l, max_depth, cap,
                                    d_order[cur], d_centroid, d_tbox, d_small, small_limit);
                 if (gridN <= kScanBlocks && !library_scan) {
-                    hipLaunchKernelGGL(flags_scan_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l,
+                    hipLaunchKernelGGL(flags_scan_kernel, dim3(gridN), dim3(T), 0, stream, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l,
                                        d_flags, d_scan, d_btot);
-                    hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
+                    hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, stream, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
                                        d_btot, gridN, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
                 } else {                                         // very large meshes: library scan over the whole array
-                    hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l, d_flags);
-                    RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n));
-                    hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, 0, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
+                    hipLaunchKernelGGL(flags_kernel, dim3(gridN), dim3(T), 0, stream, d_order[cur], d_nodeof[cur], n, d_centroid, d_nodes, d_state, l, d_flags);
+                    RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_flags, d_scan, n, stream));
+                    hipLaunchKernelGGL(scatter_kernel, dim3(gridN), dim3(T), 0, stream, d_order[cur], d_nodeof[cur], n, d_nodes, d_state, l, d_flags, d_scan,
                                        (const int32_t*)nullptr, 0, d_order[cur ^ 1], d_nodeof[cur ^ 1]);
                 }
                 cur ^= 1;
                 have_state = false;
                 if (l + 1 >= check_at && l + 1 < levels_to_run) {
-                    RT_HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
+                    RT_HIP(read_state());
                     have_state = true;
                     if (st.bins_used[(l + 1) & 1] == 0) break;   // no node of the next level evaluates a split
                     check_at = l + 3;
@@ -835,21 +855,22 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
             }
         }
         if (small_limit > 0 && n > 1) {
-            if (!have_state) RT_HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
+            if (!have_state) RT_HIP(read_state());
             if (st.num_small > 0)
-                hipLaunchKernelGGL(small_subtree_kernel, dim3(st.num_small), dim3(64), 0, 0, d_nodes, d_state, d_small, d_order[cur], d_centroid, d_tbox,
+                hipLaunchKernelGGL(small_subtree_kernel, dim3(st.num_small), dim3(64), 0, stream, d_nodes, d_state, d_small, d_order[cur], d_centroid, d_tbox,
                                    max_depth, cap);
         }
     }
     // ---- breadth-first -> the reference's depth-first numbering ----
-    hipLaunchKernelGGL(ends_kernel, dim3((cap + T - 1) / T), dim3(T), 0, 0, d_nodes, d_state, d_hist);
-    RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_hist, d_hscan, n + 2));
-    hipLaunchKernelGGL(emit_kernel, dim3((cap + T - 1) / T), dim3(T), 0, 0, d_nodes, d_state, d_hscan, d_bounds, d_children, d_lfirst, d_lcount);
+    hipLaunchKernelGGL(ends_kernel, dim3((cap + T - 1) / T), dim3(T), 0, stream, d_nodes, d_state, d_hist);
+    RT_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_hist, d_hscan, n + 2, stream));
+    if (emit_host_layout)
+        hipLaunchKernelGGL(emit_kernel, dim3((cap + T - 1) / T), dim3(T), 0, stream, d_nodes, d_state, d_hscan, d_bounds, d_children, d_lfirst, d_lcount);
     RT_HIP(hipGetLastError());
     if (debug) { (void)hipDeviceSynchronize(); t_kernels = now(); }
-    RT_HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
-    total = st.total;
+    RT_HIP(read_state());
     if (debug) {
+        const int total = st.total;
         fprintf(stderr, "bvh: n %d total %d levels %d overflow %d bins_used %d %d small subtrees %d (limit %d) begin", n, st.total, st.levels, st.overflow,
                 st.bins_used[0], st.bins_used[1], st.num_small, small_limit);
         for (int l = 0; l < 8; l++) fprintf(stderr, " %d", st.begin[l]);
@@ -867,17 +888,249 @@ extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth,
             for (int a = 0; a < 3; a++) { fprintf(stderr, " |"); for (int q = 0; q < 6; q++) fprintf(stderr, " %d", hb.cnt[a][q]); }
             fprintf(stderr, "\n");
         }
+        fprintf(stderr, "bvh timing: copy in %.3f ms, kernels %.3f ms\n", t_in - t_start, t_kernels - t_in);
     }
-    if (st.overflow || total < 1 || total > cap) { rc = RT_E_INVALID; goto done; }
-    RT_HIP(hipMemcpy(node_bounds, d_bounds, (size_t)total * 6 * sizeof(float), hipMemcpyDeviceToHost));
-    RT_HIP(hipMemcpy(node_children, d_children, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    RT_HIP(hipMemcpy(node_leaf_first, d_lfirst, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
-    RT_HIP(hipMemcpy(node_leaf_count, d_lcount, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (n > 0) RT_HIP(hipMemcpy(leaf_indices, d_order[cur], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    *num_nodes = total;
-    if (num_levels) *num_levels = st.levels;
-    if (debug) fprintf(stderr, "bvh timing: copy in %.3f ms, kernels %.3f ms, copy out (+ dump) %.3f ms\n", t_in - t_start, t_kernels - t_in, now() - t_kernels);
+    if (st.overflow || st.total < 1 || st.total > cap) { rc = RT_E_INVALID; goto done; }
+    out.nodes = d_nodes; out.state = d_state; out.ends_before = d_hscan; out.order = d_order[cur]; out.hist = d_hist;
+    out.tmp = d_tmp; out.tmp_bytes = tmp_bytes;
+    out.bounds = d_bounds; out.children = d_children; out.leaf_first = d_lfirst; out.leaf_count = d_lcount; out.cap = cap;
+done:
+    return rc;
+}
 
+}  // namespace
+
+extern "C" int rt_bvh_build(const float* vertices, int32_t n, int32_t max_depth, float* node_bounds, int32_t* node_children,
+                            int32_t* node_leaf_first, int32_t* node_leaf_count, int32_t* leaf_indices, int32_t* num_nodes,
+                            int32_t* num_levels)
+{
+    if (n < 0 || max_depth < 1 || (n > 0 && !vertices) || !node_bounds || !node_children || !node_leaf_first ||
+        !node_leaf_count || !num_nodes || (n > 0 && !leaf_indices)) return RT_E_INVALID;
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    DeviceBuild b;
+    int rc = build_core(vertices, false, n, max_depth, nullptr, true, b);
+    if (rc) return rc;
+    const int total = b.st.total;
+    RT_HIP(hipMemcpy(node_bounds, b.bounds, (size_t)total * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(node_children, b.children, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(node_leaf_first, b.leaf_first, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(node_leaf_count, b.leaf_count, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n > 0) RT_HIP(hipMemcpy(leaf_indices, b.order, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    *num_nodes = total;
+    if (num_levels) *num_levels = b.st.levels;
+done:
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Device-resident rebuild: a new tree over a mesh whose triangles have moved (or been replaced by at most as many), written
+// straight into the scene's record arrays -- no host copy of the vertices, of the tree, or of the records.  The host path for
+// the same job is rt_bvh_build (9 MB in, 12 MB out for 70 k triangles), MeshPrimitive / Scene::upload_to_device (flatten
+// again) and rt_scene_upload (re-lay out on the host, copy 13 MB in): 7 ms around 0.6 ms of kernels.  Reference hooks:
+// MeshPrimitive::build_bvh (MeshPrimitive.cpp:38-56) and Scene::upload_to_device (Scene.cpp:25-65).
+//
+// The records a mesh owns are laid out by rt_scene_upload as [int_cap interior records][slot_cap triangle records], the
+// interior nodes in pre-order; an interior node's record index is node_base + (its pre-order number - the leaves before it),
+// and both counts come from range-end histograms (a node is preceded, in pre-order, by its ancestors and by every node whose
+// triangle range ends at or before its own first triangle -- see preorder_of).  Triangle slot = slot_base + position in leaf
+// order.  The kernels below write exactly what rt_scene_upload writes for the same tree.
+namespace {
+
+// hist[e] += 1 for every LEAF whose range ends at e; depth_hist[d] += 1 for every interior node of depth d (counted per
+// block in LDS first: tens of thousands of nodes share a dozen depths, and a returning atomic on one word is slow)
+__global__ __launch_bounds__(256) void leaf_ends_kernel(const BuildNode* __restrict__ nodes, const BuildState* __restrict__ st,
+                                                        int32_t* __restrict__ leaf_hist, int32_t* __restrict__ depth_hist)
+{
+    __shared__ int local[kMaxLevels + 2];
+    for (int d = threadIdx.x; d < kMaxLevels + 2; d += blockDim.x) local[d] = 0;
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < st->total) {
+        const BuildNode& nd = nodes[k];
+        if (nd.child_a < 0) atomicAdd(&leaf_hist[nd.first + nd.count], 1);
+        else atomicAdd(&local[nd.depth], 1);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kMaxLevels + 2; d += blockDim.x) if (local[d]) atomicAdd(&depth_hist[d], local[d]);
+}
+
+// several small clears in one launch (each hipMemsetAsync is a launch of its own): range r = words[r] 32-bit words of value[r]
+struct ClearRanges { uint32_t* ptr[6]; unsigned long long words[6]; uint32_t value[6]; int count; };
+__global__ void clear_kernel(const ClearRanges c)
+{
+    for (int r = 0; r < c.count; r++)
+        for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < c.words[r]; i += (unsigned long long)gridDim.x * blockDim.x)
+            c.ptr[r][i] = c.value[r];
+}
+
+// traversal entry of a node (rt_device_types.h): interior -> its record index, leaf -> flag | count | first slot
+__device__ __forceinline__ int32_t entry_of(const BuildNode& nd, const int32_t* ends_before, const int32_t* leaf_ends_before, int32_t node_base,
+                                            int32_t slot_base)
+{
+    if (nd.child_a < 0) return rt::kLeafFlag | ((nd.count <= 30 ? nd.count : 31) << rt::kSlotBits) | (slot_base + nd.first);
+    const int pre = nd.count > 0 ? preorder_of(nd, ends_before) : 0;
+    return node_base + (pre - leaf_ends_before[nd.first + 1]);
+}
+
+// interior records (both children's boxes + both child entries), leaf counts, the refit schedule (interior records grouped
+// by level, deepest first: level_start[d] = first schedule position of depth d), and the root entry
+__global__ __launch_bounds__(256) void emit_nodes_kernel(const BuildNode* __restrict__ nodes, const BuildState* __restrict__ st,
+                                  const int32_t* __restrict__ ends_before, const int32_t* __restrict__ leaf_ends_before, int32_t node_base,
+                                  int32_t slot_base, float4* __restrict__ records, int32_t* __restrict__ leaf_count,
+                                  int32_t* __restrict__ level_cursor, int32_t* __restrict__ sched, int32_t* __restrict__ root_entry)
+{
+    __shared__ int local[kMaxLevels + 2], base[kMaxLevels + 2];  // this block's interior nodes per depth -> one cursor bump per depth
+    for (int d = threadIdx.x; d < kMaxLevels + 2; d += blockDim.x) local[d] = 0;
+    __syncthreads();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t entry = 0, depth = -1, rank = 0;
+    if (k < st->total) {
+        const BuildNode& nd = nodes[k];
+        entry = entry_of(nd, ends_before, leaf_ends_before, node_base, slot_base);
+        if (k == 0) *root_entry = entry;
+        if (nd.child_a < 0) {
+            if (nd.count > 0) leaf_count[slot_base + nd.first] = nd.count;
+        } else {
+            const BuildNode &a = nodes[nd.child_a], &b = nodes[nd.child_b];
+            float4* q = records + (size_t)entry * 4;
+            q[0] = make_float4(a.mn[0], a.mn[1], a.mn[2], a.mx[0]);
+            q[1] = make_float4(a.mx[1], a.mx[2], b.mn[0], b.mn[1]);
+            q[2] = make_float4(b.mn[2], b.mx[0], b.mx[1], b.mx[2]);
+            q[3] = make_float4(__int_as_float(entry_of(a, ends_before, leaf_ends_before, node_base, slot_base)),
+                               __int_as_float(entry_of(b, ends_before, leaf_ends_before, node_base, slot_base)), 0.0f, 0.0f);
+            depth = nd.depth;
+            rank = atomicAdd(&local[depth], 1);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < kMaxLevels + 2; d += blockDim.x) if (local[d]) base[d] = atomicAdd(&level_cursor[d], local[d]);
+    __syncthreads();
+    if (depth >= 0) sched[base[depth] + rank] = entry;
+}
+
+// every instance of the rebuilt mesh gets the new root entry and uv mode (what rt_scene_upload puts into its record)
+__global__ void patch_instances_kernel(rt::DevInstance* instances, int count, int32_t mesh_index, const int32_t* __restrict__ root_entry,
+                                       const int32_t* __restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count || instances[i].mesh_index != mesh_index) return;
+    instances[i].root_ref = *root_entry;
+    instances[i].exact_uv = *flags & 1;
+}
+
+// triangle records, uvs and ids in leaf order (the arithmetic of rt_scene_upload / refit_triangles_kernel); flags[0] |= 1 when a
+// uv value is not an ordinary number (the mesh then interpolates uv per candidate, raycast.cu:96)
+__global__ void emit_triangles_kernel(const int32_t* __restrict__ order, int n, int32_t slot_base, const float* __restrict__ vertices,
+                                      const float* __restrict__ normals, const float* __restrict__ uvs, float4* __restrict__ records,
+                                      float* __restrict__ tri_uv, int32_t* __restrict__ tri_id, int32_t* __restrict__ flags)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int t = order[p];
+    const size_t slot = (size_t)slot_base + (size_t)p;
+    const float* v = vertices + 9 * (size_t)t;
+    const float* nn = normals + 3 * (size_t)t;
+    const rt::V3 v0 = rt::v3(v[0], v[1], v[2]), v1 = rt::v3(v[3], v[4], v[5]), v2 = rt::v3(v[6], v[7], v[8]);
+    const rt::V3 e0 = v2 - v0, e1 = v1 - v0;                    // TrianglePrimitive.hpp:154-155
+    const float d00 = rt::dot(e0, e0), d01 = rt::dot(e0, e1), d11 = rt::dot(e1, e1);
+    const float inv = 1.0f / (d00 * d11 - d01 * d01);          // TrianglePrimitive.hpp:164
+    float4* q = records + slot * 4;
+    q[0] = make_float4(v0.x, v0.y, v0.z, nn[0]);
+    q[1] = make_float4(nn[1], nn[2], e0.x, e0.y);
+    q[2] = make_float4(e0.z, e1.x, e1.y, e1.z);
+    q[3] = make_float4(d00, d01, d11, inv);
+    bool odd = false;
+    for (int c = 0; c < 6; c++) {
+        const float u = uvs ? uvs[6 * (size_t)t + c] : 0.0f;
+        tri_uv[slot * 6 + c] = u;
+        if (!(fabsf(u) < 1e37f)) odd = true;
+    }
+    tri_id[slot] = t;
+    if (odd) atomicOr(&flags[0], 1);
+}
+
+// level_cursor[d] <- first schedule position of depth d (deepest level first), from the per-depth counts; one thread
+__global__ void level_starts_kernel(const int32_t* __restrict__ depth_hist, int32_t* __restrict__ level_cursor, int32_t* __restrict__ level_count_out)
+{
+    int at = 0;
+    for (int d = kMaxLevels + 1; d >= 0; d--) { level_cursor[d] = at; at += depth_hist[d]; level_count_out[d] = depth_hist[d]; }
+}
+
+struct RebuildResult {              // what the host needs to know afterwards: one small read-back
+    int32_t root_entry, flags;
+    int32_t level_count[kMaxLevels + 2];
+};
+
+}  // namespace
+
+extern "C" int rt_scene_rebuild_mesh_device(RtScene* s, int32_t mesh_index, const float* d_vertices, const float* d_normals, const float* d_uvs,
+                                            int32_t n, void* stream_)
+{
+    if (!s || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size() || n < 0 || (n > 0 && (!d_vertices || !d_normals))) return RT_E_INVALID;
+    RtScene::MeshRefit& rf = s->mesh_refit[(size_t)mesh_index];
+    if (n > rf.slot_cap || (n > 0 && n - 1 > rf.int_cap)) return RT_E_INVALID;     // more triangles than the mesh was uploaded with
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = RT_OK;
+    const int T = 256;
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    const bool debug = getenv("RT_BVH_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    DeviceBuild b;
+    if ((rc = build_core(d_vertices, true, n, 32, stream, false, b))) return rc;    // fill(1, 32), MeshPrimitive.cpp:54
+    const double t1 = now();
+    const int cap = b.cap;
+    // scratch inside the arena: the range-end histogram (n + 2 ints, consumed by its scan) becomes the LEAF-end histogram, its
+    // scan goes to hist_scan; the per-depth counters and the result record live in `extra`
+    int32_t* leaf_hist = b.hist;
+    int32_t* leaf_before = b.hist_scan;
+    int32_t* depth_hist = (int32_t*)b.extra;                        // kMaxLevels + 2 ints
+    int32_t* level_cursor = depth_hist + (kMaxLevels + 2);
+    RebuildResult* d_result = (RebuildResult*)(level_cursor + (kMaxLevels + 2));
+    static_assert(sizeof(RebuildResult) + 2 * (kMaxLevels + 2) * sizeof(int32_t) <= kExtraBytes, "scratch of the rebuild");
+    RebuildResult res;
+    {
+        // the mesh's part of the scene arrays starts from zero (what rt_scene_upload leaves in unused records), tri_id from -1
+        ClearRanges c;
+        c.count = 6;
+        c.ptr[0] = (uint32_t*)leaf_hist; c.words[0] = (unsigned long long)n + 2; c.value[0] = 0;
+        c.ptr[1] = (uint32_t*)depth_hist; c.words[1] = (2 * (kMaxLevels + 2) * sizeof(int32_t) + sizeof(RebuildResult)) / 4; c.value[1] = 0;
+        c.ptr[2] = (uint32_t*)(s->d_records + (size_t)rf.node_base * 4); c.words[2] = ((unsigned long long)rf.int_cap + rf.slot_cap) * 16; c.value[2] = 0;
+        c.ptr[3] = (uint32_t*)(s->d_tri_uv + (size_t)rf.slot_base * 6); c.words[3] = (unsigned long long)rf.slot_cap * 6; c.value[3] = 0;
+        c.ptr[4] = (uint32_t*)(s->d_tri_id + rf.slot_base); c.words[4] = (unsigned long long)rf.slot_cap; c.value[4] = 0xffffffffu;
+        c.ptr[5] = (uint32_t*)(s->d_leaf_count + rf.slot_base); c.words[5] = (unsigned long long)rf.slot_cap; c.value[5] = 0;
+        hipLaunchKernelGGL(clear_kernel, dim3(2048), dim3(T), 0, stream, c);
+    }
+    hipLaunchKernelGGL(leaf_ends_kernel, dim3((cap + T - 1) / T), dim3(T), 0, stream, b.nodes, b.state, leaf_hist, depth_hist);
+    RT_HIP(hipcub::DeviceScan::ExclusiveSum(b.tmp, b.tmp_bytes, leaf_hist, leaf_before, n + 2, stream));
+    hipLaunchKernelGGL(level_starts_kernel, dim3(1), dim3(1), 0, stream, depth_hist, level_cursor, d_result->level_count);
+    hipLaunchKernelGGL(emit_nodes_kernel, dim3((cap + T - 1) / T), dim3(T), 0, stream, b.nodes, b.state, b.ends_before, leaf_before, rf.node_base, rf.slot_base,
+                       s->d_records, s->d_leaf_count, level_cursor, rf.d_sched, &d_result->root_entry);
+    if (n > 0)
+        hipLaunchKernelGGL(emit_triangles_kernel, dim3((n + T - 1) / T), dim3(T), 0, stream, b.order, n, rf.slot_base, d_vertices, d_normals, d_uvs,
+                           s->d_records, s->d_tri_uv, s->d_tri_id, &d_result->flags);
+    if (!s->instances.empty())
+        hipLaunchKernelGGL(patch_instances_kernel, dim3((unsigned)((s->instances.size() + T - 1) / T)), dim3(T), 0, stream, s->d_instances,
+                           (int)s->instances.size(), mesh_index, &d_result->root_entry, &d_result->flags);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemcpyAsync(&res, d_result, sizeof res, hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    if (debug) fprintf(stderr, "rebuild timing: build %.3f ms, emit into the scene %.3f ms\n", t1 - t0, now() - t1);
+    // ---- host bookkeeping: what rt_scene_upload records for a mesh ----
+    rf.num_triangles = n; rf.num_slots = n; rf.levels = b.st.levels;
+    rf.level_end.clear();
+    {
+        int32_t at = 0;
+        for (int d = kMaxLevels + 1; d >= 0; d--) if (res.level_count[d] > 0) { at += res.level_count[d]; rf.level_end.push_back(at); }
+        rf.sched.clear();                                           // (the schedule now lives on the device only)
+    }
+    s->mesh_exact_uv[(size_t)mesh_index] = res.flags & 1;
+    s->mesh_root_ref[(size_t)mesh_index] = res.root_entry;
+    s->max_stack = 1;
+    for (const auto& m : s->mesh_refit) s->max_stack = std::max(s->max_stack, m.levels);
+    if (s->max_stack > rt::kMaxStack) { rc = RT_E_DEPTH; goto done; }
+    for (DevInstance& in : s->instances)                            // the host mirror of what patch_instances_kernel wrote
+        if (in.mesh_index == mesh_index) { in.root_ref = res.root_entry; in.exact_uv = res.flags & 1; }
 done:
     return rc;
 }

@@ -19,6 +19,7 @@
 #include "../../include/rt_hip.h"
 #include "rt_device_types.h"
 #include "rt_math.h"
+#include "rt_scene_internal.h"
 
 using namespace rt;
 
@@ -1044,56 +1045,6 @@ __global__ void set_instance_kernel(DevInstance* dst, const DevInstance value) {
 //                                  host side of the C-ABI
 // =====================================================================================
 
-struct RtScene {
-    int device = 0;
-    float4* d_records = nullptr;                 // interior-node and triangle records, one index space
-    float* d_tri_uv = nullptr;
-    int32_t* d_tri_id = nullptr;
-    int32_t* d_leaf_count = nullptr;
-    DevInstance* d_instances = nullptr;
-    DevMaterial* d_materials = nullptr;
-    std::vector<uint8_t*> d_textures;
-    std::vector<DevInstance> instances;          // host mirror (for update_instance)
-    std::vector<int32_t> mesh_root_ref;          // per mesh
-    std::vector<int32_t> mesh_exact_uv;
-    // per mesh, for rt_scene_refit_mesh: its slot range, triangle count, and its interior records grouped by tree level
-    struct MeshRefit {
-        int32_t slot_base = 0, num_slots = 0, num_triangles = 0;
-        std::vector<int32_t> sched;              // interior record indices, deepest level first
-        std::vector<int32_t> level_end;          // sched[level_end[k-1] .. level_end[k]) is one level
-        int32_t* d_sched = nullptr;
-    };
-    std::vector<MeshRefit> mesh_refit;
-    float* d_refit_scratch = nullptr;            // vertices + normals of the mesh being refitted (grow-only)
-    size_t refit_scratch_bytes = 0;
-    int32_t num_materials = 0;
-    int32_t max_stack = 1;
-    size_t device_bytes = 0;
-    float4* d_ex_scratch = nullptr;              // extension renders: running sums + one chunk of samples (grow-only)
-    size_t ex_scratch_bytes = 0;
-    // heavy-first dispatch of single-frame launches (render_kernel<.., ORDERED>, tile_sort_kernel): one order state per frame
-    // size, a few of them cached -- two cameras of different sizes, or whole frames next to a rank's stripes, alternate on one
-    // scene without ever meeting each other's state (a single state would be torn down and rebuilt, with a device-wide
-    // synchronise in hipFree, on every change of size)
-    struct TileOrder {
-        int tiles_x = 0, tiles_y = 0, ntiles = 0;
-        int32_t *d_cost = nullptr, *d_keys = nullptr, *d_order[2] = {nullptr, nullptr};
-        int cur = -1;                            // order buffer renders read (-1: none sorted yet -> natural order)
-        bool pending = false;                    // a sort into d_order[target] is in flight on sort_stream
-        int target = 0;
-        hipEvent_t sort_done = nullptr;
-        uint64_t last_used = 0;
-        // the last ordered launch on each stream that uses this state (a sort waits for all of them)
-        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; uint64_t tick = 0; } seen[4];
-    };
-    struct TileOrderCache {
-        std::mutex m;
-        hipStream_t sort_stream = nullptr;
-        uint64_t tick = 0;
-        TileOrder entry[4];
-    } order;
-};
-
 struct RtTimer { hipEvent_t start, stop; };
 
 #define RT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -1376,8 +1327,10 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             }
             int64_t mesh_interior = 0;
             for (int i = 0; i < m.num_nodes; i++) mesh_interior += m.node_children[2 * i] > 0 ? 1 : 0;
-            const int64_t node_base = (int64_t)records.size() / 4, slot_base = node_base + mesh_interior;
-            if (slot_base + m.num_leaf_indices + 1 > kSlotMask) { rc = RT_E_INVALID; break; }
+            // (room for any tree over these triangles: rt_scene_rebuild_mesh_device writes a new one in place)
+            const int64_t int_cap = std::max<int64_t>(mesh_interior, (int64_t)m.num_triangles - 1);
+            const int64_t node_base = (int64_t)records.size() / 4, slot_base = node_base + int_cap;
+            if (slot_base + std::max<int64_t>(m.num_leaf_indices, m.num_triangles) + 1 > kSlotMask) { rc = RT_E_INVALID; break; }
             // pass 1: entry of every node (interior -> running interior index, leaf -> slot range), levels
             std::vector<int32_t> entry((size_t)m.num_nodes), level((size_t)m.num_nodes, 0);
             int64_t n_int = 0, n_slot = 0;
@@ -1406,14 +1359,15 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             s->max_stack = std::max(s->max_stack, max_level);
             // pass 2: emit records
             bool exact_uv = false;
-            records.reserve(records.size() + (size_t)(n_int + n_slot) * 4 + 4);
-            tri_uv.reserve(tri_uv.size() + (size_t)(n_int + n_slot) * 6);
-            tri_id.reserve(tri_id.size() + (size_t)(n_int + n_slot));
-            leaf_count.reserve(leaf_count.size() + (size_t)(n_int + n_slot));
-            records.resize(records.size() + (size_t)n_int * 4);
-            tri_uv.resize(tri_uv.size() + (size_t)n_int * 6, 0.0f);
-            tri_id.resize(tri_id.size() + (size_t)n_int, -1);
-            leaf_count.resize(leaf_count.size() + (size_t)n_int, 0);
+            const int64_t slot_cap = std::max<int64_t>(n_slot, m.num_triangles);
+            records.reserve(records.size() + (size_t)(int_cap + slot_cap) * 4 + 4);
+            tri_uv.reserve(tri_uv.size() + (size_t)(int_cap + slot_cap) * 6);
+            tri_id.reserve(tri_id.size() + (size_t)(int_cap + slot_cap));
+            leaf_count.reserve(leaf_count.size() + (size_t)(int_cap + slot_cap));
+            records.resize(records.size() + (size_t)int_cap * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            tri_uv.resize(tri_uv.size() + (size_t)int_cap * 6, 0.0f);
+            tri_id.resize(tri_id.size() + (size_t)int_cap, -1);
+            leaf_count.resize(leaf_count.size() + (size_t)int_cap, 0);
             for (int i = 0; i < m.num_nodes && rc == RT_OK; i++) {
                 const int a = m.node_children[2 * i], b = m.node_children[2 * i + 1];
                 if (a > 0) {
@@ -1449,10 +1403,17 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                     }
                 }
             }
+            if (rc != RT_OK) break;
+            // unused slots of the mesh's part
+            records.resize(((size_t)slot_base + (size_t)slot_cap) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            tri_uv.resize(((size_t)slot_base + (size_t)slot_cap) * 6, 0.0f);
+            tri_id.resize((size_t)slot_base + (size_t)slot_cap, -1);
+            leaf_count.resize((size_t)slot_base + (size_t)slot_cap, 0);
             s->mesh_root_ref.push_back(entry[0]);
             s->mesh_exact_uv.push_back(exact_uv ? 1 : 0);
             {
                 RtScene::MeshRefit rf;
+                rf.node_base = (int32_t)node_base; rf.int_cap = (int32_t)int_cap; rf.slot_cap = (int32_t)slot_cap; rf.levels = max_level;
                 rf.slot_base = (int32_t)slot_base; rf.num_slots = (int32_t)n_slot; rf.num_triangles = m.num_triangles;
                 std::vector<std::vector<int32_t>> by_level((size_t)max_level + 1);
                 for (int i = 0; i < m.num_nodes; i++)
@@ -1488,8 +1449,11 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     if ((rc = upload(&s->d_tri_uv, tri_uv, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_tri_id, tri_id, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_leaf_count, leaf_count, s->device_bytes))) return fail(rc);
-    for (auto& rf : s->mesh_refit)
-        if ((rc = upload(&rf.d_sched, rf.sched, s->device_bytes))) return fail(rc);
+    for (auto& rf : s->mesh_refit) {
+        std::vector<int32_t> sched(rf.sched);
+        sched.resize((size_t)std::max(rf.int_cap, 1), 0);            // (capacity for the schedule of any tree over the mesh)
+        if ((rc = upload(&rf.d_sched, sched, s->device_bytes))) return fail(rc);
+    }
     std::vector<DevMaterial> mats((size_t)desc->num_materials);
     for (int i = 0; i < desc->num_materials; i++) {
         const RtMaterialDesc& m = desc->materials[i];
@@ -1601,6 +1565,28 @@ int rt_scene_refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, c
 int rt_scene_refit_mesh_device(RtScene* s, int32_t mesh_index, const float* d_vertices, const float* d_normals, int32_t num_triangles, void* stream)
 {
     return refit_mesh(s, mesh_index, d_vertices, d_normals, num_triangles, stream, true);
+}
+
+int rt_scene_debug_read(RtScene* s, int32_t which, void* host_dst, size_t capacity, size_t* bytes)
+{
+    if (!s || !bytes || which < 0 || which > 4) return RT_E_INVALID;
+    size_t recs = 4;                                            // the padding records at the end
+    for (const auto& rf : s->mesh_refit) recs = std::max(recs, (size_t)rf.slot_base + (size_t)rf.slot_cap + 4);
+    recs -= 4;
+    const void* src = nullptr;
+    size_t n = 0;
+    switch (which) {
+    case 0: src = s->d_records; n = (recs + 1) * 4 * sizeof(float4); break;       // (+ the four padding float4 = one record)
+    case 1: src = s->d_tri_uv; n = recs * 6 * sizeof(float); break;
+    case 2: src = s->d_tri_id; n = recs * sizeof(int32_t); break;
+    case 3: src = s->d_leaf_count; n = recs * sizeof(int32_t); break;
+    default: src = s->d_instances; n = s->instances.size() * sizeof(DevInstance); break;
+    }
+    *bytes = n;
+    if (!host_dst || capacity < n) return RT_OK;
+    RT_HIP(hipDeviceSynchronize());
+    if (n) RT_HIP(hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 int rt_scene_destroy(RtScene* s)

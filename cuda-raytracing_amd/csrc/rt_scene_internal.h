@@ -1,0 +1,68 @@
+// rt_scene_internal.h -- the scene handle of the C-ABI (RtScene of include/rt_hip.h) as the library's own translation units see it:
+// rt_kernels.hip (upload, render, refit) and rt_bvh_build.hip (device-resident rebuild).  Not part of the interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+#include "rt_device_types.h"
+
+using rt::DevInstance;
+using rt::DevMaterial;
+
+struct RtScene {
+    int device = 0;
+    float4* d_records = nullptr;                 // interior-node and triangle records, one index space
+    float* d_tri_uv = nullptr;
+    int32_t* d_tri_id = nullptr;
+    int32_t* d_leaf_count = nullptr;
+    DevInstance* d_instances = nullptr;
+    DevMaterial* d_materials = nullptr;
+    std::vector<uint8_t*> d_textures;
+    std::vector<DevInstance> instances;          // host mirror (for update_instance)
+    std::vector<int32_t> mesh_root_ref;          // per mesh
+    std::vector<int32_t> mesh_exact_uv;
+    // per mesh, for rt_scene_refit_mesh: its slot range, triangle count, and its interior records grouped by tree level
+    // Layout of a mesh's part of the record array: int_cap interior records from node_base (the tree's interior nodes in
+    // pre-order, then unused ones), slot_cap triangle records from slot_base = node_base + int_cap.  The capacities leave room
+    // for ANY tree over the mesh's triangles (at most n - 1 interior nodes, n slots), so that rt_scene_rebuild_mesh_device can
+    // write a new tree in place.
+    struct MeshRefit {
+        int32_t node_base = 0, int_cap = 0, slot_cap = 0, levels = 1;
+        int32_t slot_base = 0, num_slots = 0, num_triangles = 0;
+        std::vector<int32_t> sched;              // interior record indices, deepest level first
+        std::vector<int32_t> level_end;          // sched[level_end[k-1] .. level_end[k]) is one level
+        int32_t* d_sched = nullptr;              // int_cap entries
+    };
+    std::vector<MeshRefit> mesh_refit;
+    float* d_refit_scratch = nullptr;            // vertices + normals of the mesh being refitted (grow-only)
+    size_t refit_scratch_bytes = 0;
+    int32_t num_materials = 0;
+    int32_t max_stack = 1;
+    size_t device_bytes = 0;
+    float4* d_ex_scratch = nullptr;              // extension renders: running sums + one chunk of samples (grow-only)
+    size_t ex_scratch_bytes = 0;
+    // heavy-first dispatch of single-frame launches (render_kernel<.., ORDERED>, tile_sort_kernel): one order state per frame
+    // size, a few of them cached -- two cameras of different sizes, or whole frames next to a rank's stripes, alternate on one
+    // scene without ever meeting each other's state (a single state would be torn down and rebuilt, with a device-wide
+    // synchronise in hipFree, on every change of size)
+    struct TileOrder {
+        int tiles_x = 0, tiles_y = 0, ntiles = 0;
+        int32_t *d_cost = nullptr, *d_keys = nullptr, *d_order[2] = {nullptr, nullptr};
+        int cur = -1;                            // order buffer renders read (-1: none sorted yet -> natural order)
+        bool pending = false;                    // a sort into d_order[target] is in flight on sort_stream
+        int target = 0;
+        hipEvent_t sort_done = nullptr;
+        uint64_t last_used = 0;
+        // the last ordered launch on each stream that uses this state (a sort waits for all of them)
+        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; uint64_t tick = 0; } seen[4];
+    };
+    struct TileOrderCache {
+        std::mutex m;
+        hipStream_t sort_stream = nullptr;
+        uint64_t tick = 0;
+        TileOrder entry[4];
+    } order;
+};
+

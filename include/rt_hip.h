@@ -147,6 +147,20 @@ int rt_scene_destroy(RtScene *scene);
 /* bytes of device memory the scene holds, and the traversal-stack depth it needs */
 int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);
 
+/* Device-resident rebuild of one mesh of an uploaded scene: a NEW tree (the reference's, node for node, as rt_bvh_build gives
+ * it) over the n triangles in DEVICE arrays d_vertices [n][3][3], d_normals [n][3] and d_uvs [n][3][2] (NULL = all zero), n at
+ * most the triangle count the mesh was uploaded with.  The build kernels and an emit pass write straight into the scene's
+ * record arrays -- what rt_bvh_build + Scene::upload_to_device + rt_scene_upload produce for the same triangles, bit for bit,
+ * without a host copy of vertices, tree or records: for a mesh whose motion has outgrown refitting, or whose triangles change.
+ * Ordered on `stream` like rt_scene_refit_mesh_device; the call returns when the new tree is in place (it reads a few words
+ * of build state back while it runs).  Replaces MeshPrimitive::build_bvh + Scene::upload_to_device (MeshPrimitive.cpp:38-56,
+ * Scene.cpp:25-65) for that mesh. */
+int rt_scene_rebuild_mesh_device(RtScene *scene, int32_t mesh_index, const float *d_vertices, const float *d_normals,
+                                 const float *d_uvs, int32_t num_triangles, void *stream);
+/* tests: copies one of the scene's device arrays to the host (which: 0 records [float4], 1 tri_uv, 2 tri_id, 3 leaf_count,
+ * 4 instances); *bytes receives its size, nothing is copied when capacity is smaller */
+int rt_scene_debug_read(RtScene *scene, int32_t which, void *host_dst, size_t capacity, size_t *bytes);
+
 /* ---- GPU build of the reference's BVH (replaces MeshPrimitive::build_bvh -> BVHTree::fill(1, 32), MeshPrimitive.cpp:38-56,
  *      BVHTree.hpp:203-292): identical topology, bounds and pre-order node numbering, built level by level on the device.
  *      vertices: HOST [n][3][3].  Outputs are HOST arrays sized for 2n nodes (n leaf indices) in the RtMeshDesc layout;

@@ -64,6 +64,8 @@ int rth_scene_update_mesh_instance_async(RthScene *s, int32_t index, int32_t mes
 /* Scene::refit_mesh: the mesh's triangles moved (tris18 = n TrianglePrimitives of 18 floats, same count and order as when
  * the mesh was built): new triangle records and refitted BVH bounds on host and device, no rebuild (rt_scene_refit_mesh) */
 int rth_scene_refit_mesh(RthScene *s, int32_t mesh_index, const float *tris18, int32_t n, void *stream);
+/* Scene::rebuild_mesh: new triangles for a mesh (at most as many as at upload), a new tree built on the GPU in place */
+int rth_scene_rebuild_mesh(RthScene *s, int32_t mesh_index, const float *tris18, int32_t n, void *stream);
 int32_t rth_scene_num_mesh_instances(const RthScene *s);
 /* the RtScene* behind the Scene (for rt_render_debug etc.), NULL before upload */
 void *rth_scene_device_handle(RthScene *s);

@@ -375,6 +375,102 @@ def test_batched_frames_equal_single_frames(rt, orc, scenes, blob5k):
         b.free()
 
 
+def test_device_resident_rebuild_of_a_mesh(rt, orc, scenes, blob5k):
+    """Scene::rebuild_mesh / rt_scene_rebuild_mesh_device: the triangles of an uploaded mesh are replaced and the device copy
+    gets a NEW tree, built by the GPU build kernels and emitted straight into the scene's record arrays.  (a) the arrays are,
+    byte for byte, what the host route produces for the same triangles (GPU build -> host arrays -> Scene::upload_to_device
+    -> rt_scene_upload); (b) all planes equal the oracle's, whose builder is the reference's; (c) a refit, an instance update
+    and a re-upload after the rebuild behave; (d) fewer triangles than at upload, a single leaf, one triangle, none."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    W, H = 320, 180
+    K, pose = scenes.scaled_K(W), scenes.C2_CAMERAS["mid"]
+    tex = sd.checker_texture(32, 32, seed=5)
+    inst = ((0.1, 0.0, 0.0, 0.2, 0.0, 0.0), (1.0, 0.9, 1.1))
+    rest = rt.Mesh.load_obj(blob5k).dump()["tris"].copy()
+
+    def with_normals(t):
+        t = t.copy()
+        for i in range(len(t)):
+            t[i, :12] = o.tri_from_vertices(t[i, :9])[:12]
+        return t
+
+    def scrambled(step):                                        # far more than a refit can follow: the blob folded and stretched
+        m = rest.copy()
+        v = m[:, :9].reshape(-1, 3, 3)
+        v[..., 2] += np.float32(0.6 * step) * np.sin(5.0 * v[..., 0] + step)
+        v[..., 0] = np.where(v[..., 1] > 0, v[..., 0], -v[..., 0] * np.float32(1.3))
+        return with_normals(m)
+
+    def oracle_scene(tris):
+        so = orc_mod.OracleScene(o)
+        so.add_material((1.0, 1.0, 1.0), tex)
+        om = o.mesh_from_triangles(tris)
+        so.add_mesh(om)
+        so.add_instance(0, 0, *inst)
+        return so, om
+
+    def product_scene(tris):
+        sp = rt.Scene()
+        sp.add_material((1.0, 1.0, 1.0), texture_bgr=tex)
+        sp.add_mesh(rt.Mesh.from_triangles(tris, gpu_build=True))
+        sp.add_mesh_instance(0, 0, *inst)
+        sp.upload_to_device()
+        return sp
+
+    def check(sp, so, what):
+        cam = rt.Camera(W, H, K, scenes.D_REF)
+        cam.set_pose(pose)
+        ref = so.render(W, H, K, scenes.D_REF, pose, threads=8)
+        dbg = rt.render_debug(sp, cam)
+        for n in ("img",) + PLANES:
+            assert np.array_equal(dbg[n], ref[n]), (what, n)
+        assert np.array_equal(rt.render_ids(sp, cam)["hit_tri"], ref["hit_tri"]), what
+        return ref["img"]
+
+    sp = product_scene(rest)
+    first = None
+    for step in (1, 2):
+        moved = scrambled(step)
+        sp.rebuild_mesh(0, moved)
+        fresh = product_scene(moved)                            # the host route for the same triangles
+        for which, dt in ((0, np.uint32), (1, np.uint32), (2, np.int32), (3, np.int32), (4, np.uint32)):
+            a, b = sp.debug_read(which, dt), fresh.debug_read(which, dt)
+            assert a.shape == b.shape and np.array_equal(a, b), ("array", which, step)
+        so, om = oracle_scene(moved)
+        img = check(sp, so, "rebuilt %d" % step)
+        first = img if first is None else first
+        # a small deformation afterwards is a refit of the NEW tree
+        m2 = moved.copy()
+        m2[:, :9].reshape(-1, 3, 3)[..., 2] += np.float32(0.02) * np.cos(4.0 * m2[:, :9].reshape(-1, 3, 3)[..., 1])
+        m2 = with_normals(m2)
+        sp.refit_mesh(0, m2)
+        o.mesh_refit(om, m2)
+        check(sp, so, "refit after rebuild %d" % step)
+        sp.update_mesh_instance(0, 0, 0, (0.0, 0.1, 0.0, 0.1, 0.0, 0.0), (1.0, 1.0, 1.0))
+        so.update_instance(0, 0, 0, (0.0, 0.1, 0.0, 0.1, 0.0, 0.0), (1.0, 1.0, 1.0))
+        check(sp, so, "instance update after rebuild %d" % step)
+        sp.update_mesh_instance(0, 0, 0, *inst)
+        so.close()
+    # a re-upload sends the host copy, whose tree is rebuilt on the host when it is needed
+    so, om = oracle_scene(m2)
+    sp.upload_to_device()
+    check(sp, so, "re-upload")
+    so.close()
+    # fewer triangles; one leaf that cannot be split (duplicates); one triangle; none
+    for name, tris in (("a third", scrambled(1)[::3]), ("duplicates", np.repeat(rest[:1], 40, 0)), ("one", rest[7:8]), ("none", rest[:0])):
+        sp.rebuild_mesh(0, tris)
+        so, om = oracle_scene(tris)
+        check(sp, so, name)
+        so.close()
+    with pytest.raises(rt.RtError):
+        sp.rebuild_mesh(0, np.concatenate([rest, rest[:10]]))   # more triangles than the mesh was uploaded with
+    sp.rebuild_mesh(0, rest)                                    # and back: the first frame again
+    so, om = oracle_scene(rest)
+    check(sp, so, "back to rest")
+    so.close()
+
+
 def test_heavy_first_tile_order_keeps_frames_identical(rt, scenes, blob70k):
     """Single-frame launches dispatch their tiles heaviest-first, in an order sorted from an earlier frame's per-tile costs
     on a side stream (rt_kernels.hip, launch_ordered).  Whatever order a launch happens to read -- none yet, one frame
