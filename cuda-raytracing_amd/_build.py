@@ -71,7 +71,8 @@ def build(force=False, verbose=False):
 
 def _build_locked(force, verbose):
     if force or _stale(HIP_SO, HIP_DEPS):
-        cmd = [HIPCC] + HIP_FLAGS + ["-o", HIP_SO] + HIP_SRCS
+        # RT_HIPCC_EXTRA: extra compiler flags for A/B experiments on the kernels (e.g. -DRT_PRED_STACK=1); never set in a normal build
+        cmd = [HIPCC] + HIP_FLAGS + os.environ.get("RT_HIPCC_EXTRA", "").split() + ["-o", HIP_SO] + HIP_SRCS
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
