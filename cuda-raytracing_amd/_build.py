@@ -37,7 +37,7 @@ def kernel_code_hash(sources=None, flags=None):
     for path in (sources if sources is not None else [os.path.join(CSRC, n) for n in ("rt_kernels.hip", "rt_math.h", "rt_device_types.h")]):
         h.update(os.path.basename(path).encode() + b"\0")
         h.update(open(path, "rb").read())
-    h.update(" ".join(flags if flags is not None else HIP_FLAGS).encode())
+    h.update(" ".join(flags if flags is not None else HIP_FLAGS + os.environ.get("RT_HIPCC_EXTRA", "").split()).encode())
     return h.hexdigest()[:16]
 
 
