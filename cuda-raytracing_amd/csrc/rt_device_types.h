@@ -96,6 +96,10 @@ struct RenderParams {
     float4* ex_samples;         // [chunk][local_rows * width] radiance xyz + node pops (int bits) of one sample
     float4* ex_acc;             // [local_rows * width] running sums between chunks
     int32_t* total_pops;
+    // render_ex_kernel<.., PX>: the samples of a pixel share a wave (64 lanes = px_pw x px_ph pixels x px_n sample slots)
+    int32_t px_n, px_count;     // sample slots per pixel in a wave (4..64, a power of two), samples of this launch (<= px_n)
+    int32_t px_pw, px_ph;       // pixels of a wave; a workgroup is 2 x 2 waves
+    int32_t px_first, px_last;  // first / last chunk of the frame's samples (running sums wait in ex_acc in between)
     // wavefront form of the extension renderer (ex_wave_kernel): path queues between casts, see rt_kernels.hip
     float4* exq_s;              // shadow-ray items: kExPlanesS planes of exq_nseg * 64 float4
     float4* exq_a[3];           // bounce-ray items: kExPlanesA planes each; three arrays in rotation (exq_in1 / in2 / out)

@@ -530,7 +530,15 @@ __device__ __forceinline__ V3 hit_normal(const RenderParams& p, const Hit& hit)
 // (8 waves per SIMD at 32 spilled registers beats 7 / 6 / 5 waves with 18 / 4 / 0 spills: +2 % / +8 % / +21 % time.)
 // SIMPLE = no bounces and no lighting (samples per pixel only, BASELINE configs[3]): the path is one primary ray, so
 // nothing but the hit has to survive the cast -- no path state spilled around the traversal loop, no hit location.
-template <bool SIMPLE>
+// PX = the samples of a pixel share a wave (the default for 4 and more samples per pixel): a wave is px_pw x px_ph pixels
+// times px_n sample slots -- 2 x 2 pixels x 16 samples, or 1 pixel x 64 samples -- instead of 8 x 8 pixels of one sample
+// index.  The jittered rays of one pixel visit almost the same nodes in almost the same order, so the lanes of a wave stay
+// together through the loop (most iterations find every lane holding the same entry and take the scalar fetch) and finish
+// together; and because a pixel's samples now sit in one wave, they are added up -- in sample order, by one lane per channel,
+// through the wave's own LDS columns -- right here: no sample planes in HBM, no resolve pass.  Frames of more than 64 samples
+// take several launches, the running sums wait in ex_acc in between.  What a (pixel, sample) pair computes does not depend on
+// the lane it runs in, so the frame is the same bit for bit (tests/test_gpu_parity.py compares the two mappings).
+template <bool SIMPLE, bool PX = false>
 __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];
@@ -538,11 +546,22 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     const int tile = blockIdx.x;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int x = tx * kTile + (wave & 1) * 8 + (lane & 7);
-    const int ly = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
-    if (x >= p.width || ly >= p.local_rows) return;
+    int x, ly, s;
+    bool valid;
+    if constexpr (PX) {
+        const int pix = lane / p.px_n, sl = lane % p.px_n;
+        x = tx * 2 * p.px_pw + (wave & 1) * p.px_pw + pix % p.px_pw;
+        ly = ty * 2 * p.px_ph + (wave >> 1) * p.px_ph + pix / p.px_pw;
+        s = p.sample_base + sl;
+        valid = x < p.width && ly < p.local_rows && sl < p.px_count;
+    } else {
+        x = tx * kTile + (wave & 1) * 8 + (lane & 7);
+        ly = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+        s = p.sample_base + (int)blockIdx.y;
+        valid = x < p.width && ly < p.local_rows;
+        if (!valid) return;
+    }
     const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;   // stripes: local -> frame row
-    const int s = p.sample_base + (int)blockIdx.y;
     unsigned long long t_start = 0;
     if (p.trace) t_start = wall_clock64();
 
@@ -550,6 +569,8 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     Stack stack;
     stack.lds = (lds_int*)lds_stack + tid; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
     int pops = 0;
+    V3 sample = v3(0.0f, 0.0f, 0.0f);
+    if (valid) {
 
     // stream of (pixel, sample): the reference's per-pixel seed (raycast.cu:190: int idx * 1000) plus the sample index
     Xorwow rng;
@@ -559,7 +580,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     if (s > 0) { px = px + (xorwow_uniform(rng) - 0.5f); py = py + (xorwow_uniform(rng) - 0.5f); }
     V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     V3 dir = camera_direction(f, px, py);
-    V3 weight = v3(1.0f, 1.0f, 1.0f), sample = v3(0.0f, 0.0f, 0.0f);
+    V3 weight = v3(1.0f, 1.0f, 1.0f);
     if constexpr (SIMPLE) {                                     // the loop below for bounces = 0, lighting = 0, written out
         const Hit hit = cast_ray_ex<false>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) sample = sample + weight * v3(1.0f, 0.8f, 0.6f);
@@ -604,6 +625,37 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
         org = hit.loc + r * (float)1e-4;
         dir = r;
     }
+    }
+    if constexpr (PX) {
+        // the wave's samples -> its own LDS columns (the traversal stacks are idle now), four rows of 64 words: r g b pops
+        lds_int* mine = (lds_int*)lds_stack + wave * 64;
+        mine[0 * kBlock + lane] = __float_as_int(sample.x);
+        mine[1 * kBlock + lane] = __float_as_int(sample.y);
+        mine[2 * kBlock + lane] = __float_as_int(sample.z);
+        mine[3 * kBlock + lane] = pops;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the first four lanes of a pixel add up one channel each, in sample order (what resolve_ex_kernel does per pixel)
+        const int c = lane % p.px_n;
+        if (c < 4 && x < p.width && ly < p.local_rows) {
+            const lds_int* col = mine + c * kBlock + (lane - c);
+            const size_t pixel = (size_t)ly * p.width + x;
+            if (c < 3) {
+                float acc = 0.0f;
+                if (!p.px_first) acc = ((const float*)&p.ex_acc[pixel])[c];
+                for (int k = 0; k < p.px_count; k++) acc = acc + __int_as_float(col[k]);
+                if (!p.px_last) ((float*)&p.ex_acc[pixel])[c] = acc;
+                else (f.img + (size_t)ly * p.pitch + 3 * (size_t)x)[c] = to_u8(acc / (float)p.spp * 255.0f);
+            } else {
+                int acc = 0;
+                if (!p.px_first) acc = __float_as_int(p.ex_acc[pixel].w);
+                for (int k = 0; k < p.px_count; k++) acc += col[k];
+                if (!p.px_last) ((int*)&p.ex_acc[pixel])[3] = acc;
+                else if (p.total_pops) p.total_pops[(size_t)y * p.width + x] = acc;
+            }
+        }
+    } else
     p.ex_samples[(size_t)blockIdx.y * ((size_t)p.local_rows * p.width) + (size_t)ly * p.width + x] =
         make_float4(sample.x, sample.y, sample.z, __int_as_float(pops));
     if (p.trace) {                                              // diagnostic: per-wave lifetime (RT_TRACE_FILE)
@@ -1679,6 +1731,41 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
     // The wavefront form is opt-in (RT_EX_WAVEFRONT=1): measured 37-52 ms against 32.8 ms on the blob with sun + 8 bounces, see
     // the comment above ex_wave_kernel and profiles/r03_experiments/ex_wavefront.md
     const bool wavefront = !simple && !trace_file && ex_env_int("RT_EX_WAVEFRONT", 0) != 0;
+    // The samples of a pixel in one wave (render_ex_kernel<.., PX>): the default from four samples per pixel on.
+    // RT_EX_PIXEL_WAVES=0 selects the older mapping (one sample index per launch row, sample planes + resolve pass).
+    const bool pixel_waves = !wavefront && !trace_file && p.spp >= 4 && ex_env_int("RT_EX_PIXEL_WAVES", 1) != 0;
+    if (pixel_waves) {
+        const bool many = p.spp > 64;                                               // several launches: running sums in ex_acc
+        const size_t need = many ? npix * sizeof(float4) : 0;
+        if (s->ex_scratch_bytes < need) {
+            (void)hipFree(s->d_ex_scratch);                                         // (synchronises with renders in flight)
+            s->d_ex_scratch = nullptr; s->ex_scratch_bytes = 0;
+            RT_HIP(hipMalloc((void**)&s->d_ex_scratch, need));
+            s->ex_scratch_bytes = need;
+        }
+        p.ex_acc = s->d_ex_scratch;
+        // (four LDS rows per lane hold a wave's samples for the in-wave sum, whatever the depth of the stack)
+        const size_t lds = (size_t)std::max(std::min(p.stack_depth, kLdsStack), 4) * kBlock * sizeof(int);
+        for (int base = 0; base < p.spp; base += 64) {
+            const int n = std::min(64, p.spp - base);
+            int slots = 4;
+            while (slots < n) slots <<= 1;
+            const int ppw = 64 / slots;                                             // pixels of a wave: 16, 8, 4, 2 or 1
+            p.px_n = slots; p.px_count = n;
+            p.px_pw = ppw >= 16 ? 4 : (ppw >= 4 ? 2 : (ppw >= 2 ? 2 : 1));
+            p.px_ph = ppw / p.px_pw;
+            p.px_first = base == 0 ? 1 : 0; p.px_last = base + n == p.spp ? 1 : 0;
+            p.sample_base = base;
+            p.tiles_x = (p.width + 2 * p.px_pw - 1) / (2 * p.px_pw);
+            p.tiles_y = (p.local_rows + 2 * p.px_ph - 1) / (2 * p.px_ph);
+            const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y));
+            if (simple) hipLaunchKernelGGL((render_ex_kernel<true, true>), grid, dim3(kBlock), lds, stream, p);
+            else hipLaunchKernelGGL((render_ex_kernel<false, true>), grid, dim3(kBlock), lds, stream, p);
+            RT_HIP(hipGetLastError());
+        }
+        if (synchronize) RT_HIP(hipStreamSynchronize(stream));
+        return RT_OK;
+    }
     size_t budget = wavefront ? kExWaveScratchBudget : kExScratchBudget;
     if (const char* e = getenv("RT_EX_SCRATCH_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);   // tests: force several chunks
     // bytes per sample index: its plane of samples, and for the wavefront form a slot for every path of the plane (tiles

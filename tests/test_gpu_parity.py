@@ -748,10 +748,13 @@ def test_ex_samples_in_chunks(rt, orc, scenes, blob5k, monkeypatch):
     _compare_ex(rt, orc, sd.shiny_scene(scenes, blob5k), m["width"], m["height"], scenes.scaled_K(m["width"]), m["pose"], 4, 2, 1)
 
 
-@pytest.mark.parametrize("spp,bounces,lighting,size", [(3, 2, 1, (200, 120)), (2, 5, 0, (203, 117)), (5, 0, 1, (64, 48)), (6, 4, 1, (333, 190))])
-def test_ex_wavefront_equals_per_lane_form(rt, orc, scenes, blob5k, monkeypatch, spp, bounces, lighting, size):
-    """The wavefront form (RT_EX_WAVEFRONT=1: one cast per launch, live paths compacted between launches) and the per-lane form
-    (the default: a lane keeps its path from the camera to the last bounce) give the same frame and the same
+@pytest.mark.parametrize("spp,bounces,lighting,size", [(3, 2, 1, (200, 120)), (2, 5, 0, (203, 117)), (5, 0, 1, (64, 48)), (6, 4, 1, (333, 190)),
+                                                       (16, 0, 0, (131, 77)), (33, 1, 1, (97, 61)), (70, 2, 1, (64, 48)), (130, 0, 0, (45, 31))])
+def test_ex_forms_are_bit_identical(rt, orc, scenes, blob5k, monkeypatch, spp, bounces, lighting, size):
+    """The three ways the extension renderer maps (pixel, sample) pairs to lanes -- a pixel's samples in one wave with the sum
+    taken there (the default from 4 samples on; more than 64 samples take several launches), one sample index per launch row with
+    sample planes and a resolve pass (RT_EX_PIXEL_WAVES=0), and the wavefront form (RT_EX_WAVEFRONT=1: one cast per launch, live
+    paths compacted between launches) -- give the same frame and the same
     node-pop totals, and both equal the oracle -- also with small queue groups (4 segments), with the samples in chunks
     of 2 and of 1 (the primary launch's workgroup then covers 2 or 4 pixel quads), and for a rank's stripes."""
     W, H = size
@@ -763,7 +766,9 @@ def test_ex_wavefront_equals_per_lane_form(rt, orc, scenes, blob5k, monkeypatch,
     cam = rt.Camera(W, H, K, sd_D)
     cam.set_pose(pose)
     cam.set_options(spp, bounces, lighting)
-    variants = [{"RT_EX_WAVEFRONT": "1"}, {"RT_EX_WAVEFRONT": "1", "RT_EX_GROUP": "4"},
+    # (the default from 4 samples on: a pixel's samples share a wave and are summed there; RT_EX_PIXEL_WAVES=0: one sample index per
+    # launch row, sample planes and a resolve pass)
+    variants = [{"RT_EX_PIXEL_WAVES": "0"}, {"RT_EX_WAVEFRONT": "1"}, {"RT_EX_WAVEFRONT": "1", "RT_EX_GROUP": "4"},
                 {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": str(2 * (W + 16) * (H + 16) * 380)},
                 {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": "1"}]
     for env in variants:
