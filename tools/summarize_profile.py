@@ -28,6 +28,9 @@ if kernel == "render_kernel<false, false>":                 # (lines printed bef
     kernel = "render_kernel<false, false, false>"
 tiles = ((W + 15) // 16) * ((H + 15) // 16)
 per_frame_items = tiles * 256 * (cfg["spp"] if "render_ex" in kernel else 1)
+# render_ex_kernel<.., PX> (4 and more samples per pixel): a launch covers up to 64 samples of every pixel, a frame is
+# ceil(spp / 64) launches of ceil(W / 2pw) x ceil(H / 2ph) workgroups -- count frames by dispatches, not by work-items
+ex_launches_per_frame = (cfg["spp"] + 63) // 64 if ("render_ex" in kernel and cfg["spp"] >= 4) else 0
 tot, meta, frames_by_pass = collections.defaultdict(float), {}, {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) if os.path.isdir(d) else []
@@ -39,7 +42,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             seen[r["Dispatch_Id"]] = int(r["Grid_Size"])
             meta = {k: r[k] for k in ("Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size") if k in r}
-    frames = sum(seen.values()) / per_frame_items
+    frames = len(seen) / ex_launches_per_frame if ex_launches_per_frame else sum(seen.values()) / per_frame_items
     for r in csv.DictReader(open(fs[0])):
         if kernel in r["Kernel_Name"]:
             frames_by_pass[r["Counter_Name"]] = frames
@@ -68,7 +71,7 @@ if kt:
         if kernel in r["Kernel_Name"]:
             grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
             groups[grid].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    entry["kernel_trace"] = [{"grid_work_items": g, "frames_per_launch": round(g / per_frame_items, 3), "launches": len(v),
+    entry["kernel_trace"] = [{"grid_work_items": g, "frames_per_launch": round(1.0 / ex_launches_per_frame if ex_launches_per_frame else g / per_frame_items, 3), "launches": len(v),
                               "avg_ms": round(sum(v) / len(v), 4), "min_ms": round(min(v), 4), "max_ms": round(max(v), 4)}
                              for g, v in sorted(groups.items(), key=lambda kv: -len(kv[1]))]
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
