@@ -700,9 +700,12 @@ def measure_latency(g, poses, f32_ms_per_frame):
     singles = [cam.prepared_batch(scene, [poses[k % len(poses)]], [bufs[k & 1].data_ptr()], pitch) for k in range(n)]
     pairs = [cam.prepared_batch(scene, [poses[(2 * k) % len(poses)], poses[(2 * k + 1) % len(poses)]], [bufs[0].data_ptr(), bufs[1].data_ptr()], pitch)
              for k in range(n // 2)]
-    for c in singles[:4]:
+    # warm-up: single-frame launches dispatch their tiles in the order sorted from an earlier frame's costs (heavy-first), and a
+    # new order is picked up by the first launch issued after its sort has finished -- synchronise between the first launches so
+    # that the timed ones run with a settled order, as any frame of a running application does
+    for c in singles[:8]:
         c()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     timer.start(stream)
     for c in singles:
         c()
