@@ -948,7 +948,10 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
         }
     }
     // pass 1: v / vt records (vn is accepted and unused, OBJLoader.hpp:55-62); remember face lines
-    run_pieces(threads, npieces, [&](int k) { obj_pass1(pieces[(size_t)k]); });
+    // (an exception must not leave a worker thread: out of memory becomes this piece's error)
+    run_pieces(threads, npieces, [&](int k) {
+        try { obj_pass1(pieces[(size_t)k]); } catch (const std::exception&) { pieces[(size_t)k].error = "out of memory while reading the file"; }
+    });
     for (const ObjPiece& pc : pieces) if (!pc.error.empty()) return fail(pc.error);
     std::vector<float3> vertices;
     std::vector<float2> tex_coords;
@@ -976,8 +979,10 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
     std::vector<std::vector<TrianglePrimitive>> part((size_t)npieces);
     std::vector<std::string> errs((size_t)npieces);
     run_pieces(threads, npieces, [&](int k) {
-        obj_pass2(faces, faces.size() * (size_t)k / (size_t)npieces, faces.size() * (size_t)(k + 1) / (size_t)npieces, vertices, tex_coords,
-                  lenient, part[(size_t)k], errs[(size_t)k]);
+        try {
+            obj_pass2(faces, faces.size() * (size_t)k / (size_t)npieces, faces.size() * (size_t)(k + 1) / (size_t)npieces, vertices, tex_coords,
+                      lenient, part[(size_t)k], errs[(size_t)k]);
+        } catch (const std::exception&) { errs[(size_t)k] = "out of memory while building the triangles"; }
     });
     for (const std::string& e : errs) if (!e.empty()) return fail(e);
     size_t total = triangles.size();
