@@ -68,7 +68,7 @@ RT_HIP_SYMBOLS = [
     "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
 RT_HOST_SYMBOLS = [
-    "rth_obj_load", "rth_obj_parse", "rth_scan_float", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
+    "rth_obj_load", "rth_obj_parse", "rth_scan_float", "rth_obj_load_for_device", "rth_mesh_from_triangles_for_device", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_mesh_free", "rth_mesh_num_triangles",
     "rth_mesh_num_nodes", "rth_mesh_max_level", "rth_mesh_get_triangles", "rth_mesh_get_nodes", "rth_mesh_get_leaf_indices",
     "rth_mesh_print_stats", "rth_scene_create", "rth_scene_free", "rth_scene_add_material", "rth_scene_add_material_ppm",
     "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance", "rth_scene_update_mesh_instance_async", "rth_scene_refit_mesh", "rth_scene_rebuild_mesh",
@@ -158,12 +158,18 @@ def _declare(h, s):
     h.rt_timer_destroy.argtypes = [_vp]
 
     s.rth_last_error.restype = C.c_char_p
-    for n in ("rth_obj_load", "rth_obj_parse", "rth_scan_float", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
+    for n in ("rth_obj_load", "rth_obj_load_for_device", "rth_mesh_from_triangles_for_device", "rth_obj_load_lenient", "rth_obj_load_gpu", "rth_mesh_from_triangles", "rth_mesh_from_triangles_gpu", "rth_mesh_single_triangle", "rth_scene_create", "rth_camera_create",
               "rth_scene_device_handle"):
         getattr(s, n).restype = _vp
     s.rth_obj_load.argtypes = [C.c_char_p]
     s.rth_obj_load_lenient.argtypes = [C.c_char_p]
     s.rth_obj_load_gpu.argtypes = [C.c_char_p]
+    s.rth_obj_load_for_device.argtypes = [C.c_char_p]
+    s.rth_mesh_from_triangles_for_device.argtypes = [_f, C.c_int32]
+    s.rth_obj_parse.restype = C.c_int32
+    s.rth_obj_parse.argtypes = [C.c_char_p, C.c_int32, _vp, C.c_int32]
+    s.rth_scan_float.restype = C.c_int
+    s.rth_scan_float.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_float)]
     s.rth_mesh_from_triangles_gpu.argtypes = [_f, C.c_int32]
     s.rth_mesh_from_triangles.argtypes = [_f, C.c_int32]
     s.rth_mesh_single_triangle.argtypes = [_f]
@@ -257,14 +263,17 @@ class Mesh:
         self.h = handle
 
     @classmethod
-    def load_obj(cls, path, lenient=False, gpu_build=False):    # OBJLoader::load / load_lenient; BVH on host or GPU
+    def load_obj(cls, path, lenient=False, gpu_build=False, for_device=False):    # OBJLoader::load / load_lenient; BVH on host or GPU
+        """for_device: OBJLoader::load_for_device -- no host tree, the GPU builds it inside the scene at Scene.upload_to_device."""
+        if for_device:
+            return cls(libs()[1].rth_obj_load_for_device(os.fsencode(path)))
         fn = libs()[1].rth_obj_load_gpu if gpu_build else (libs()[1].rth_obj_load_lenient if lenient else libs()[1].rth_obj_load)
         return cls(fn(os.fsencode(path)))
 
     @classmethod
-    def from_triangles(cls, tris18, gpu_build=False):  # MeshPrimitive(std::vector<TrianglePrimitive>[, build_on_device])
+    def from_triangles(cls, tris18, gpu_build=False, for_device=False):  # MeshPrimitive(std::vector<TrianglePrimitive>[, build_on_device])
         t = _fa(tris18).reshape(-1, 18)
-        fn = libs()[1].rth_mesh_from_triangles_gpu if gpu_build else libs()[1].rth_mesh_from_triangles
+        fn = libs()[1].rth_mesh_from_triangles_for_device if for_device else (libs()[1].rth_mesh_from_triangles_gpu if gpu_build else libs()[1].rth_mesh_from_triangles)
         return cls(fn(_fp(t), t.shape[0]))
 
     @classmethod

@@ -11,6 +11,11 @@ public:
     // build_on_device = true builds the BVH with rt_bvh_build (GPU) instead of the host builder; same tree.
     // Throws std::runtime_error if the device build fails.
     MeshPrimitive(std::vector<TrianglePrimitive> triangles, bool build_on_device);
+    // No tree yet: Scene::upload_to_device hands the triangles over and the GPU builds the tree inside the scene's arrays
+    // (rt_scene_upload with num_nodes = 0) -- the shortest way from an OBJ file to a renderable scene.  bvh_top stays empty
+    // until sync_tree() builds it on the host (print_stats, or anything else that reads the host tree, needs that first).
+    static MeshPrimitive for_device_build(std::vector<TrianglePrimitive> triangles);
+    bool builds_at_upload() const { return tree_needs_rebuild; }
     int num_triangles;
     BVHTree bvh_top;
     const std::vector<TrianglePrimitive>& triangle_array() const { return triangles; }
@@ -26,6 +31,7 @@ public:
     bool tree_is_stale() const { return tree_stale; }
 
 private:
+    MeshPrimitive() : num_triangles(0) {}
     std::vector<TrianglePrimitive> triangles;
     bool tree_stale = false, tree_needs_rebuild = false;
 };

@@ -16,6 +16,8 @@ namespace OBJLoader {
 bool parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error, bool lenient = false);
 // The float scanner of parse() on one token (std::stof semantics, correctly rounded like strtof; exposed for tests)
 bool scan_float_token(const char* begin, const char* end, float& out);
+// parse + MeshPrimitive::for_device_build: no host tree, the GPU builds it at Scene::upload_to_device; throws like load_lenient
+MeshPrimitive load_for_device(std::string fp, bool lenient = false);
 // parse(lenient = true) + MeshPrimitive; throws std::runtime_error on failure
 MeshPrimitive load_lenient(std::string fp);
 // Reference behaviour: prints the progress lines, and on an unreadable file prints

@@ -310,6 +310,15 @@ MeshPrimitive::MeshPrimitive(std::vector<TrianglePrimitive> tris, bool build_on_
     if (rc) throw std::runtime_error(std::string("MeshPrimitive: GPU BVH build failed: ") + rt_error_string(rc));
 }
 
+MeshPrimitive MeshPrimitive::for_device_build(std::vector<TrianglePrimitive> tris)
+{
+    MeshPrimitive m;
+    m.triangles = std::move(tris);
+    m.num_triangles = (int)m.triangles.size();
+    m.tree_stale = m.tree_needs_rebuild = true;
+    return m;
+}
+
 // ------------------------------------------------------------------------------ Material
 
 void Material::set_texture_bgr(const uint8_t* bgr, int width, int height, size_t pitch)
@@ -353,7 +362,8 @@ void Scene::upload_to_device()
     std::vector<Flat> flat(meshes.size());
     std::vector<RtMeshDesc> md(meshes.size());
     for (size_t i = 0; i < meshes.size(); i++) {
-        meshes[i].sync_tree();                                   // (a mesh refitted on the device only: its host tree catches up now)
+        const bool device_build = meshes[i].builds_at_upload();  // no host tree wanted: the GPU builds it inside the scene's arrays
+        if (!device_build) meshes[i].sync_tree();                // (a mesh refitted on the device only: its host tree catches up now)
         const MeshPrimitive& m = meshes[i];
         Flat& f = flat[i];
         const auto& tris = m.triangle_array();
@@ -365,10 +375,12 @@ void Scene::upload_to_device()
             }
             f.n[3 * t] = tris[t].normal.x; f.n[3 * t + 1] = tris[t].normal.y; f.n[3 * t + 2] = tris[t].normal.z;
         }
-        f.tree = m.bvh_top.to_device_compatible();                // BVHTree.hpp:364-383
         RtMeshDesc& d = md[i];
+        memset(&d, 0, sizeof d);
         d.num_triangles = m.num_triangles;
         d.vertices = f.v.data(); d.normals = f.n.data(); d.uvs = f.uv.data();
+        if (device_build) continue;                              // num_nodes = 0
+        f.tree = m.bvh_top.to_device_compatible();                // BVHTree.hpp:364-383
         d.num_nodes = (int32_t)m.bvh_top.nodes.size();
         d.node_bounds = f.tree.node_bounds.data(); d.node_children = f.tree.node_children.data();
         d.node_leaf_first = f.tree.node_leaf_first.data(); d.node_leaf_count = f.tree.node_leaf_count.data();
@@ -990,6 +1002,14 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
     triangles.reserve(total);
     for (const auto& v : part) triangles.insert(triangles.end(), v.begin(), v.end());
     return true;
+}
+
+MeshPrimitive OBJLoader::load_for_device(std::string fp, bool lenient)
+{
+    std::vector<TrianglePrimitive> triangles;
+    std::string err;
+    if (!parse(fp, triangles, &err, lenient)) throw std::runtime_error("OBJLoader: " + err);
+    return MeshPrimitive::for_device_build(std::move(triangles));
 }
 
 MeshPrimitive OBJLoader::load_lenient(std::string fp)

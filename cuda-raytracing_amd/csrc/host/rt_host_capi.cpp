@@ -48,6 +48,21 @@ int rth_scan_float(const char* token, size_t length, float* out)
     *out = f;
     return 1;
 }
+RthMesh* rth_obj_load_for_device(const char* path)
+{
+    try {
+        if (!path) { g_err = "null path"; return nullptr; }
+        return new RthMesh(OBJLoader::load_for_device(path));
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+RthMesh* rth_mesh_from_triangles_for_device(const float* tris18, int32_t n)
+{
+    try {
+        std::vector<TrianglePrimitive> tris((size_t)(n > 0 ? n : 0));
+        if (n > 0) memcpy((void*)tris.data(), tris18, (size_t)n * 72);
+        return new RthMesh(MeshPrimitive::for_device_build(std::move(tris)));
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
 RthMesh* rth_obj_load_lenient(const char* path)
 {
     try {

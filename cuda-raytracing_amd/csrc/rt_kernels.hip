@@ -1370,12 +1370,32 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     std::vector<float4> records;
     std::vector<float> tri_uv;
     std::vector<int32_t> tri_id, leaf_count;
+    std::vector<int> build_on_device;               // meshes that arrive without a tree (num_nodes == 0)
     try {
         for (int mi = 0; mi < desc->num_meshes && rc == RT_OK; mi++) {
             const RtMeshDesc& m = desc->meshes[mi];
-            if (m.num_triangles < 0 || m.num_nodes < 1 || m.num_leaf_indices < 0 || !m.node_bounds || !m.node_children ||
-                !m.node_leaf_first || !m.node_leaf_count ||
-                (m.num_triangles && (!m.vertices || !m.normals || !m.uvs)) || (m.num_leaf_indices && !m.leaf_indices)) {
+            if (m.num_triangles < 0 || (m.num_triangles && (!m.vertices || !m.normals || !m.uvs))) { rc = RT_E_INVALID; break; }
+            if (m.num_nodes == 0) {
+                // no tree given: the mesh's part of the arrays is reserved here and the tree is built on the device, in place,
+                // once the arrays are uploaded (the kernels of rt_scene_rebuild_mesh_device) -- no host tree, no host re-layout
+                const int64_t n = m.num_triangles, int_cap = std::max<int64_t>(n - 1, 0);
+                const int64_t node_base = (int64_t)records.size() / 4, slot_base = node_base + int_cap;
+                if (slot_base + n + 1 > kSlotMask) { rc = RT_E_INVALID; break; }
+                records.resize(records.size() + (size_t)(int_cap + n) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                tri_uv.resize(tri_uv.size() + (size_t)(int_cap + n) * 6, 0.0f);
+                tri_id.resize(tri_id.size() + (size_t)(int_cap + n), -1);
+                leaf_count.resize(leaf_count.size() + (size_t)(int_cap + n), 0);
+                s->mesh_root_ref.push_back(leaf_ref(slot_base, 0));
+                s->mesh_exact_uv.push_back(0);
+                RtScene::MeshRefit rf;
+                rf.node_base = (int32_t)node_base; rf.int_cap = (int32_t)int_cap; rf.slot_cap = (int32_t)n; rf.levels = 1;
+                rf.slot_base = (int32_t)slot_base; rf.num_slots = 0; rf.num_triangles = 0;
+                s->mesh_refit.push_back(std::move(rf));
+                build_on_device.push_back(mi);
+                continue;
+            }
+            if (m.num_nodes < 1 || m.num_leaf_indices < 0 || !m.node_bounds || !m.node_children || !m.node_leaf_first || !m.node_leaf_count ||
+                (m.num_leaf_indices && !m.leaf_indices)) {
                 rc = RT_E_INVALID; break;
             }
             int64_t mesh_interior = 0;
@@ -1506,6 +1526,21 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
         std::vector<int32_t> sched(rf.sched);
         sched.resize((size_t)std::max(rf.int_cap, 1), 0);            // (capacity for the schedule of any tree over the mesh)
         if ((rc = upload(&rf.d_sched, sched, s->device_bytes))) return fail(rc);
+    }
+    for (int mi : build_on_device) {                             // trees the device builds in place (before the instances take their root entries)
+        const RtMeshDesc& m = desc->meshes[mi];
+        const size_t n = (size_t)m.num_triangles;
+        float* d = nullptr;
+        he = hipMalloc((void**)&d, std::max<size_t>(n, 1) * 18 * sizeof(float));
+        if (he != hipSuccess) return fail((int)he);
+        if (n) {
+            he = hipMemcpy(d, m.vertices, n * 9 * sizeof(float), hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(d + n * 9, m.normals, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(d + n * 12, m.uvs, n * 6 * sizeof(float), hipMemcpyHostToDevice);
+        }
+        rc = he != hipSuccess ? (int)he : rt_scene_rebuild_mesh_device(s, mi, d, d + n * 9, d + n * 12, (int32_t)n, nullptr);
+        (void)hipFree(d);
+        if (rc) return fail(rc);
     }
     std::vector<DevMaterial> mats((size_t)desc->num_materials);
     for (int i = 0; i < desc->num_materials; i++) {

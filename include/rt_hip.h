@@ -50,7 +50,9 @@ typedef struct RtMeshDesc {
     const float *vertices;          /* [num_triangles][3][3]  TrianglePrimitive::vertices      */
     const float *normals;           /* [num_triangles][3]     TrianglePrimitive::normal        */
     const float *uvs;               /* [num_triangles][3][2]  TrianglePrimitive::uv_coords     */
-    int32_t num_nodes;              /* node 0 is the root (MeshPrimitive.cpp:51)               */
+    int32_t num_nodes;              /* node 0 is the root (MeshPrimitive.cpp:51).  0 = no tree given (the node and leaf
+                                     * arrays are ignored): rt_scene_upload builds the reference's tree on the device,
+                                     * in place -- the shortest way from triangles to a renderable scene            */
     const float *node_bounds;       /* [num_nodes][6]  min.xyz, max.xyz (d_BVHTree::min/max)   */
     const int32_t *node_children;   /* [num_nodes][2]  child_index_a/b; -1,-1 for a leaf       */
     const int32_t *node_leaf_first; /* [num_nodes]     offset of the leaf's list in leaf_indices */

@@ -21,6 +21,9 @@ typedef struct RthCamera RthCamera;   /* Camera */
 RthMesh *rth_obj_load(const char *path);
 /* OBJLoader::load_lenient: additionally accepts `v//vn` tokens and negative (relative) indices */
 RthMesh *rth_obj_load_lenient(const char *path);
+/* OBJLoader::load_for_device / MeshPrimitive::for_device_build: no host tree, the GPU builds it at Scene::upload_to_device */
+RthMesh *rth_obj_load_for_device(const char *path);
+RthMesh *rth_mesh_from_triangles_for_device(const float *tris18, int32_t n);
 /* OBJLoader::parse alone (no BVH): the number of triangles, or -1 (rth_last_error()); when out18 is non-NULL and holds
  * `capacity` >= that many 18-float triangles (TrianglePrimitive layout) they are copied there */
 int32_t rth_obj_parse(const char *path, int32_t lenient, float *out18, int32_t capacity);

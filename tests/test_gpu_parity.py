@@ -375,6 +375,79 @@ def test_batched_frames_equal_single_frames(rt, orc, scenes, blob5k):
         b.free()
 
 
+def test_scene_upload_builds_the_tree_on_the_device(rt, orc, scenes, blob5k, tmp_path):
+    """A mesh that arrives without a tree (MeshPrimitive::for_device_build / OBJLoader::load_for_device; RtMeshDesc.num_nodes = 0):
+    rt_scene_upload reserves its part of the arrays and the GPU builds the reference's tree in place.  The device arrays are byte
+    for byte those of a scene whose mesh was built first (GPU build -> host arrays -> upload), all planes equal the oracle's, a
+    second mesh with a host-built tree lives next to it, and refit / rebuild / re-upload work afterwards."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    W, H = 320, 180
+    K, pose = scenes.scaled_K(W), scenes.C2_CAMERAS["mid"]
+    soup = sd.random_triangles(300, seed=8, spread=0.6, size=0.3)
+    inst0, inst1 = ((0.1, 0.0, 0.0, 0.2, 0.0, 0.0), (1.0, 0.9, 1.1)), ((1.2, 0.5, 0.3, 0.0, 0.4, 0.0), (0.8, 0.8, 0.8))
+
+    def build(deferred):
+        sp = rt.Scene()
+        sp.add_material((0.9, 0.5, 0.2))
+        sp.add_mesh(rt.Mesh.load_obj(blob5k, for_device=True) if deferred else rt.Mesh.load_obj(blob5k, gpu_build=True))
+        sp.add_mesh(rt.Mesh.from_triangles(soup))                # a host-built tree in the same scene
+        sp.add_mesh(rt.Mesh.from_triangles(soup[:1], for_device=deferred, gpu_build=not deferred))      # one triangle
+        sp.add_mesh_instance(0, 0, *inst0)
+        sp.add_mesh_instance(1, 0, *inst1)
+        sp.add_mesh_instance(2, 0, (0, 0, 1.5, 0, 0, 0), (1, 1, 1))
+        sp.upload_to_device()
+        return sp
+
+    a, b = build(True), build(False)
+    for which, dt in ((0, np.uint32), (1, np.uint32), (2, np.int32), (3, np.int32), (4, np.uint32)):
+        x, y = a.debug_read(which, dt), b.debug_read(which, dt)
+        assert x.shape == y.shape and np.array_equal(x, y), ("array", which)
+    assert a.info() == b.info()
+    so = orc_mod.OracleScene(o)
+    so.add_material((0.9, 0.5, 0.2))
+    blob = o.obj_load(blob5k)
+    so.add_mesh(blob)
+    so.add_mesh(o.mesh_from_triangles(soup))
+    so.add_mesh(o.mesh_from_triangles(soup[:1]))
+    so.add_instance(0, 0, *inst0)
+    so.add_instance(1, 0, *inst1)
+    so.add_instance(2, 0, (0, 0, 1.5, 0, 0, 0), (1, 1, 1))
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose(pose)
+    ref = so.render(W, H, K, scenes.D_REF, pose, threads=8)
+    for sp in (a, b):
+        dbg = rt.render_debug(sp, cam)
+        for n in ("img",) + PLANES:
+            assert np.array_equal(dbg[n], ref[n]), n
+    # the deferred mesh deforms (refit), then changes (rebuild), then the scene is uploaded again
+    tris = o.mesh_dump(blob)["tris"].copy()
+    tris[:, :9].reshape(-1, 3, 3)[..., 2] *= np.float32(1.1)
+    for i in range(len(tris)):
+        tris[i, :12] = o.tri_from_vertices(tris[i, :9])[:12]
+    a.refit_mesh(0, tris)
+    o.mesh_refit(blob, tris)
+    ref = so.render(W, H, K, scenes.D_REF, pose, threads=8)
+    dbg = rt.render_debug(a, cam)
+    for n in ("img",) + PLANES:
+        assert np.array_equal(dbg[n], ref[n]), ("refit", n)
+    a.upload_to_device()                                        # (the deferred mesh is built on the device again, from the moved triangles)
+    so2 = orc_mod.OracleScene(o)
+    so2.add_material((0.9, 0.5, 0.2))
+    so2.add_mesh(o.mesh_from_triangles(tris))
+    so2.add_mesh(o.mesh_from_triangles(soup))
+    so2.add_mesh(o.mesh_from_triangles(soup[:1]))
+    so2.add_instance(0, 0, *inst0)
+    so2.add_instance(1, 0, *inst1)
+    so2.add_instance(2, 0, (0, 0, 1.5, 0, 0, 0), (1, 1, 1))
+    ref = so2.render(W, H, K, scenes.D_REF, pose, threads=8)
+    dbg = rt.render_debug(a, cam)
+    for n in ("img",) + PLANES:
+        assert np.array_equal(dbg[n], ref[n]), ("re-upload", n)
+    so.close()
+    so2.close()
+
+
 def test_device_resident_rebuild_of_a_mesh(rt, orc, scenes, blob5k):
     """Scene::rebuild_mesh / rt_scene_rebuild_mesh_device: the triangles of an uploaded mesh are replaced and the device copy
     gets a NEW tree, built by the GPU build kernels and emitted straight into the scene's record arrays.  (a) the arrays are,

@@ -339,7 +339,8 @@ def test_scene_upload_validates_its_input(rt, blob5k):
     assert broken(lambda d2, k: k["c"].__setitem__((interior, 1), k["c"][interior, 0])) == -1   # both children the same node
     assert broken(lambda d2, k: k["lc"].__setitem__(leaf, 10 ** 6)) == -1                       # leaf range past the list
     assert broken(lambda d2, k: k["li"].__setitem__(0, 10 ** 6)) == -1                          # triangle index out of range
-    assert broken(lambda d2, k: setattr(d2, "num_nodes", 0)) == -1
+    assert broken(lambda d2, k: setattr(d2, "num_nodes", -1)) == -1
+    assert broken(lambda d2, k: setattr(d2, "num_nodes", 0)) != -1                                 # 0 = "build the tree on the device": valid
     bad_inst = rt.RtInstanceDesc(3, 0, (C.c_float * 6)(), (C.c_float * 6)(), (C.c_float * 3)(), (C.c_float * 3)(),
                                  (C.c_float * 3)(1, 1, 1), (C.c_float * 3)(1, 1, 1))
     assert upload(d, instance=bad_inst) == -1                                                   # mesh_index out of range
