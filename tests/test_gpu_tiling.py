@@ -170,8 +170,9 @@ def mock_rccl(tmp_path_factory):
 @pytest.mark.parametrize("extra", [["--gpus", "2", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "40", "--warmup", "8"],
                                    ["--gpus", "4", "--workload", "c2", "--width", "322", "--height", "203", "--steps", "21", "--warmup", "5", "--frames-per-launch", "7"],
                                    ["--gpus", "3", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "12", "--warmup", "3", "--gather", "root0"],
-                                   ["--gpus", "2", "--workload", "c5", "--width", "480", "--height", "272", "--spp", "2", "--bounces", "1", "--steps", "2", "--warmup", "1"],
-                                   ["--gpus", "4", "--workload", "c3", "--width", "322", "--height", "203", "--spp", "3", "--bounces", "2", "--steps", "3", "--warmup", "1"]])
+                                   ["--gpus", "2", "--workload", "c5", "--width", "480", "--height", "272", "--spp", "6", "--bounces", "1", "--steps", "2", "--warmup", "1"],
+                                   ["--gpus", "4", "--workload", "c3", "--width", "322", "--height", "203", "--spp", "3", "--bounces", "2", "--steps", "3", "--warmup", "1"],
+                                   ["--gpus", "3", "--workload", "c3", "--width", "322", "--height", "203", "--spp", "70", "--bounces", "1", "--steps", "2", "--warmup", "1"]])
 def test_bench_ranks_as_processes_over_mock_transport(mock_rccl, extra):
     """bench.py --gpus N with one process per rank, the ranks sharing the box's GPU: torch.distributed talks gloo, and the data
     path is the product's own N-rank code -- RtComm from a broadcast id, rt_all_to_all with the rotating plan or rt_gather,
