@@ -703,6 +703,14 @@ def measure_latency(g, poses, f32_ms_per_frame):
     # warm-up: single-frame launches dispatch their tiles in the order sorted from an earlier frame's costs (heavy-first), and a
     # new order is picked up by the first launch issued after its sort has finished -- synchronise between the first launches so
     # that the timed ones run with a settled order, as any frame of a running application does
+    def hold_clock():
+        # (building the launch descriptors above left the GPU idle for a while: ~45 ms of load before a timed section, for the
+        # same reason as the warm-up floor of the main loop -- the chip needs tens of milliseconds of load to hold its clock)
+        for _ in range(7):
+            for c in pairs:
+                c()
+        torch.cuda.synchronize()
+    hold_clock()
     for c in singles[:8]:
         c()
         torch.cuda.synchronize()
@@ -716,7 +724,7 @@ def measure_latency(g, poses, f32_ms_per_frame):
         c()
     timer.stop(stream)
     f2 = timer.elapsed_ms() / n
-    torch.cuda.synchronize()
+    hold_clock()
     t0 = time.perf_counter()
     for k in range(0, n, 2):
         singles[k]()
@@ -743,10 +751,58 @@ def measure_latency(g, poses, f32_ms_per_frame):
         c()
     torch.cuda.synchronize()
     f1_two = (time.perf_counter() - t0) * 1e3 / m
+    pcie = measure_download(g, poses)
     return {"f1_kernel_ms": round(f1, 4), "f1_launch_plus_sync_wall_ms": round(f1_sync, 4), "f2_batch_ms_per_frame": round(f2, 4),
+            "pcie_inclusive": pcie,
             "f1_two_alternating_streams_wall_ms_per_frame": round(f1_two, 4),
             "reference_loop_2_renders_per_sync_wall_ms_per_frame": round(ref_loop, 4), "f32_batch_kernel_ms_per_frame": round(f32_ms_per_frame, 4),
             "note": "kernel ms = hipEvents around back-to-back launches on one stream; wall ms include launch and hipDeviceSynchronize"}
+
+
+def measure_download(g, poses, F=32, groups=12):
+    """The PCIe-inclusive rate (never `value`): every frame also travels to the host, as display_image does (kernel.cu:33-37).
+    Batches of F frames into two device frame sets; each set is copied to pinned host memory on a copy stream while the next
+    batch renders (events order render -> copy -> re-use of the set); and, for comparison, the same with render and copy in turn
+    on one stream."""
+    W, H, scene, dev, pitch, make_camera = g["W"], g["H"], g["scene"], g["dev"], g["pitch"], g["make_camera"]
+    F = min(F, len(poses))
+    try:
+        host = [torch.empty((F, H, pitch), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    except RuntimeError as e:
+        return {"note": "pinned host memory unavailable: %s" % e}
+    sets = [torch.empty((F, H, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+    rs, cs = torch.cuda.Stream(), torch.cuda.Stream()
+    cam = make_camera(rs)
+    calls = [cam.prepared_batch(scene, poses[:F], [sets[b][f].data_ptr() for f in range(F)], pitch) for b in range(2)]
+    rendered = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+
+    def run(overlap):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(groups):
+            b = i & 1
+            if overlap:
+                if i >= 2:
+                    rs.wait_event(copied[b])                    # the set is free again once its previous content has left
+                calls[b]()
+                rendered[b].record(rs)
+                cs.wait_event(rendered[b])
+                with torch.cuda.stream(cs):
+                    host[b].copy_(sets[b], non_blocking=True)
+                copied[b].record(cs)
+            else:
+                calls[b]()
+                with torch.cuda.stream(rs):
+                    host[b].copy_(sets[b], non_blocking=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / (groups * F)
+    run(True)                                                    # warm-up (first touch of the pinned pages)
+    over, serial = run(True), run(False)
+    mb = F * H * W * 3 / 1e6
+    return {"frames_per_launch": F, "overlapped_copy_stream_ms_per_frame": round(over, 4), "render_then_copy_one_stream_ms_per_frame": round(serial, 4),
+            "overlapped_Mrays_per_s": round(W * H / over / 1e3, 1), "frame_MB": round(W * H * 3 / 1e6, 2),
+            "note": "every frame copied to pinned host memory (tight rows, %.0f MB per batch); not the headline value" % mb}
 
 
 def run_frames(args, env):
