@@ -51,6 +51,26 @@ def main(blob):
             got = img.to_host().reshape(H, W, 3)
             assert np.array_equal(got, want), (n, opts, stripe, root, int((got != want).any(axis=2).sum()))
             cases += 1
+        # frames alternated between two streams on the same communicators, no host wait in between: every call orders itself
+        # behind the previous call's use of the communicator's scratch (an event), so all frames must come out right
+        if n == 3:
+            import torch
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            cam.set_options(1, 0, 0)
+            outs, wants = [], []
+            for k in range(6):
+                pose = list(sd.SHINY_CAMERA["pose"])
+                pose[1] += 0.07 * k
+                cam.set_pose(pose)
+                wants.append(rt.render(replicas[0], cam))
+                outs.append(rt.DeviceBuffer(width_bytes=W * 3, height=H))
+                pk = cam.params()
+                sarr = (C.c_void_p * n)(*([streams[k & 1].cuda_stream] * n))
+                rt.check(h.rt_render_tiled_all(scn, comms, n, C.byref(pk), None, outs[k].ptr, outs[k].pitch, 16, k % n, sarr, 0), "rt_render_tiled_all (two streams)")
+            torch.cuda.synchronize()
+            for k in range(6):
+                assert np.array_equal(outs[k].to_host().reshape(H, W, 3), wants[k]), ("two streams", k)
+            cases += 1
         # argument checks of the N-rank form
         assert h.rt_render_tiled_all(scn, comms, n, C.byref(p), None, img.ptr, img.pitch, 16, n, None, 1) == -1       # no such root
         assert h.rt_render_tiled_all(scn, comms, n - 1, C.byref(p), None, img.ptr, img.pitch, 16, 0, None, 1) == -1   # not the whole communicator

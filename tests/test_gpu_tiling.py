@@ -246,4 +246,4 @@ def test_tiled_all_with_several_ranks_over_mock_rccl(blob5k, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "tiled_all_ranks.py"), blob5k], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.strip().splitlines()[-1] == "OK 20"
+    assert r.stdout.strip().splitlines()[-1] == "OK 21"
