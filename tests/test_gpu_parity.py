@@ -841,7 +841,7 @@ def test_ex_forms_are_bit_identical(rt, orc, scenes, blob5k, monkeypatch, spp, b
     cam.set_options(spp, bounces, lighting)
     # (the default from 4 samples on: a pixel's samples share a wave and are summed there; RT_EX_PIXEL_WAVES=0: one sample index per
     # launch row, sample planes and a resolve pass)
-    variants = [{"RT_EX_PIXEL_WAVES": "0"}, {"RT_EX_WAVEFRONT": "1"}, {"RT_EX_WAVEFRONT": "1", "RT_EX_GROUP": "4"},
+    variants = [{"RT_EX_PIXEL_WAVES": "0"}, {"RT_EX_PIXEL_WAVES": "0", "RT_EX_SCRATCH_BYTES": str(3 * W * H * 16)}, {"RT_EX_WAVEFRONT": "1"}, {"RT_EX_WAVEFRONT": "1", "RT_EX_GROUP": "4"},
                 {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": str(2 * (W + 16) * (H + 16) * 380)},
                 {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": "1"}]
     for env in variants:
