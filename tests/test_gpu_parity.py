@@ -444,8 +444,26 @@ def test_scene_upload_builds_the_tree_on_the_device(rt, orc, scenes, blob5k, tmp
     dbg = rt.render_debug(a, cam)
     for n in ("img",) + PLANES:
         assert np.array_equal(dbg[n], ref[n]), ("re-upload", n)
+    # a mesh in the middle of the record array (index 1, host-built at upload) is rebuilt in place; its new triangles carry a uv
+    # value that is not an ordinary number, which switches the mesh to per-candidate uv interpolation (raycast.cu:96)
+    soup2 = sd.random_triangles(300, seed=9, spread=0.7, size=0.35)
+    soup2[5, 12] = np.inf
+    a.rebuild_mesh(1, soup2)
+    so3 = orc_mod.OracleScene(o)
+    so3.add_material((0.9, 0.5, 0.2))
+    so3.add_mesh(o.mesh_from_triangles(tris))
+    so3.add_mesh(o.mesh_from_triangles(soup2))
+    so3.add_mesh(o.mesh_from_triangles(soup[:1]))
+    so3.add_instance(0, 0, *inst0)
+    so3.add_instance(1, 0, *inst1)
+    so3.add_instance(2, 0, (0, 0, 1.5, 0, 0, 0), (1, 1, 1))
+    ref = so3.render(W, H, K, scenes.D_REF, pose, threads=8)
+    dbg = rt.render_debug(a, cam)
+    for n in ("img",) + PLANES:
+        assert np.array_equal(dbg[n], ref[n]), ("rebuild of mesh 1", n)
     so.close()
     so2.close()
+    so3.close()
 
 
 def test_device_resident_rebuild_of_a_mesh(rt, orc, scenes, blob5k):
