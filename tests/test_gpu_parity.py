@@ -1068,8 +1068,10 @@ def test_8k_frame_bands(rt, orc, scenes, blob70k):
     assert np.array_equal(out.to_host().reshape(H, W, 3), dbg["img"])
 
 
-# RT_FUZZ_SEEDS=n widens the two differential fuzz tests below (a one-off campaign on the GPU box; the suite runs 12 and 4)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_SEEDS", 12))))
+# RT_FUZZ_SEEDS=n widens the two differential fuzz tests below (a one-off campaign on the GPU box; the suite runs 12 and 4);
+# RT_FUZZ_FIRST=k starts at seed k (a second campaign over seeds the first did not see)
+_FUZZ_FIRST = int(os.environ.get("RT_FUZZ_FIRST", 0))
+@pytest.mark.parametrize("seed", range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("RT_FUZZ_SEEDS", 12))))
 def test_fuzz_random_scenes(rt, orc, scenes, blob5k, seed):
     """Differential fuzzing: random soups / blob instances with random poses, non-uniform scales, random materials
     (albedo or texture), random cameras and odd frame sizes; all six parity planes and RGB against the oracle."""
@@ -1095,7 +1097,7 @@ def test_fuzz_random_scenes(rt, orc, scenes, blob5k, seed):
     _compare(rt, orc, sd.SceneDesc(materials, meshes, instances), W, H, scenes.scaled_K(W), scenes.D_REF, cam_pose, gpu_build=seed % 3 == 2)
 
 
-@pytest.mark.parametrize("seed", range(max(4, int(os.environ.get("RT_FUZZ_SEEDS", 4)) // 3)))
+@pytest.mark.parametrize("seed", range(_FUZZ_FIRST, _FUZZ_FIRST + max(4, int(os.environ.get("RT_FUZZ_SEEDS", 4)) // 3)))
 def test_fuzz_extension_modes(rt, orc, scenes, blob5k, seed, monkeypatch):
     """Random spp / bounces / lighting, random metallic / roughness, rotated and scaled instances: extension kernel vs oracle,
     and its wavefront form (RT_EX_WAVEFRONT=1) vs both."""

@@ -3,14 +3,15 @@
 `seed` is numpy default_rng(1000 + seed)) and ::test_fuzz_extension_modes with N // 3 seeds (default_rng(7000 + seed), per-lane and
 wavefront form), every case against the CPU oracle on all parity planes.  Writes the seeds and the result as JSON so that a
 campaign is a reproducible artifact (profiles/rNN_experiments/fuzz_campaign.json), not a line in a log.
-   python tools/fuzz_campaign.py <n_seeds> <out.json>"""
+   python tools/fuzz_campaign.py <n_seeds> <out.json> [first_seed]"""
 import importlib, json, os, subprocess, sys, time
 import xml.etree.ElementTree as ET
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 n, out = int(sys.argv[1]), sys.argv[2]
 xml = out + ".junit.xml"
-env = dict(os.environ, RT_FUZZ_SEEDS=str(n))
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+env = dict(os.environ, RT_FUZZ_SEEDS=str(n), RT_FUZZ_FIRST=str(first))
 t0 = time.time()
 r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-k", "fuzz",
                     "--junitxml", xml, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True)
@@ -19,8 +20,8 @@ bad = [c.get("name") for c in cases if any(ch.tag in ("failure", "error") for ch
 skipped = [c.get("name") for c in cases if any(ch.tag == "skipped" for ch in c)]
 res = {"campaign": "differential fuzz, HIP path vs CPU oracle, all parity planes", "date": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
        "kernel_code_hash": importlib.import_module("cuda-raytracing_amd._build").kernel_code_hash(),
-       "test_fuzz_random_scenes": {"seeds": [0, n], "rng": "numpy.random.default_rng(1000 + seed)", "gpu_built_tree": "seed % 3 == 2"},
-       "test_fuzz_extension_modes": {"seeds": [0, max(4, n // 3)], "rng": "numpy.random.default_rng(7000 + seed)", "forms": ["per-lane", "wavefront"]},
+       "test_fuzz_random_scenes": {"seeds": [first, first + n], "rng": "numpy.random.default_rng(1000 + seed)", "gpu_built_tree": "seed % 3 == 2"},
+       "test_fuzz_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(7000 + seed)", "forms": ["per-lane", "wavefront"]},
        "cases": len(cases), "passed": len(cases) - len(bad) - len(skipped), "failed": bad, "skipped": skipped,
        "pytest_exit_code": r.returncode, "pytest_summary": r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "", "seconds": round(time.time() - t0, 1)}
 json.dump(res, open(out, "w"), indent=1)
