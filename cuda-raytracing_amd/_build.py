@@ -20,7 +20,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 HIP_SRCS = [os.path.join(CSRC, "rt_kernels.hip"), os.path.join(CSRC, "rt_bvh_build.hip"), os.path.join(CSRC, "rt_comm.hip")]
-HIP_DEPS = HIP_SRCS + [os.path.join(CSRC, n) for n in ("rt_math.h", "rt_device_types.h")] + \
+HIP_DEPS = HIP_SRCS + [os.path.join(CSRC, n) for n in ("rt_math.h", "rt_device_types.h", "rt_scene_internal.h")] + \
     [os.path.join(ROOT, "include", "rt_hip.h")]
 HOST_SRCS = [os.path.join(CSRC, "host", n) for n in ("rt_host.cpp", "rt_host_capi.cpp", "rt_image_io.cpp")]
 

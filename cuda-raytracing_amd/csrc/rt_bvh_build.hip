@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void leaf_ends_kernel(const BuildNode* __restr
 }
 
 // several small clears in one launch (each hipMemsetAsync is a launch of its own): range r = words[r] 32-bit words of value[r]
-struct ClearRanges { uint32_t* ptr[6]; unsigned long long words[6]; uint32_t value[6]; int count; };
+struct ClearRanges { uint32_t* ptr[7]; unsigned long long words[7]; uint32_t value[7]; int count; };
 __global__ void clear_kernel(const ClearRanges c)
 {
     for (int r = 0; r < c.count; r++)
@@ -977,7 +977,8 @@ __device__ __forceinline__ int32_t entry_of(const BuildNode& nd, const int32_t* 
 __global__ __launch_bounds__(256) void emit_nodes_kernel(const BuildNode* __restrict__ nodes, const BuildState* __restrict__ st,
                                   const int32_t* __restrict__ ends_before, const int32_t* __restrict__ leaf_ends_before, int32_t node_base,
                                   int32_t slot_base, float4* __restrict__ records, int32_t* __restrict__ leaf_count,
-                                  int32_t* __restrict__ level_cursor, int32_t* __restrict__ sched, int32_t* __restrict__ root_entry)
+                                  int32_t* __restrict__ level_cursor, int32_t* __restrict__ sched, int32_t* __restrict__ root_entry,
+                                  int32_t* __restrict__ mesh_flag)
 {
     __shared__ int local[kMaxLevels + 2], base[kMaxLevels + 2];  // this block's interior nodes per depth -> one cursor bump per depth
     for (int d = threadIdx.x; d < kMaxLevels + 2; d += blockDim.x) local[d] = 0;
@@ -998,6 +999,8 @@ __global__ __launch_bounds__(256) void emit_nodes_kernel(const BuildNode* __rest
             q[2] = make_float4(b.mn[2], b.mx[0], b.mx[1], b.mx[2]);
             q[3] = make_float4(__int_as_float(entry_of(a, ends_before, leaf_ends_before, node_base, slot_base)),
                                __int_as_float(entry_of(b, ends_before, leaf_ends_before, node_base, slot_base)), 0.0f, 0.0f);
+            const float w[12] = {a.mn[0], a.mn[1], a.mn[2], a.mx[0], a.mx[1], a.mx[2], b.mn[0], b.mn[1], b.mn[2], b.mx[0], b.mx[1], b.mx[2]};
+            if (!rt::boxes_ordered(w)) *mesh_flag = rt::kBoxUnordered;     // (the octant-specialised slab test is not for this mesh)
             depth = nd.depth;
             rank = atomicAdd(&local[depth], 1);
         }
@@ -1092,20 +1095,21 @@ extern "C" int rt_scene_rebuild_mesh_device(RtScene* s, int32_t mesh_index, cons
     {
         // the mesh's part of the scene arrays starts from zero (what rt_scene_upload leaves in unused records), tri_id from -1
         ClearRanges c;
-        c.count = 6;
+        c.count = 7;
         c.ptr[0] = (uint32_t*)leaf_hist; c.words[0] = (unsigned long long)n + 2; c.value[0] = 0;
         c.ptr[1] = (uint32_t*)depth_hist; c.words[1] = (2 * (kMaxLevels + 2) * sizeof(int32_t) + sizeof(RebuildResult)) / 4; c.value[1] = 0;
         c.ptr[2] = (uint32_t*)(s->d_records + (size_t)rf.node_base * 4); c.words[2] = ((unsigned long long)rf.int_cap + rf.slot_cap) * 16; c.value[2] = 0;
         c.ptr[3] = (uint32_t*)(s->d_tri_uv + (size_t)rf.slot_base * 6); c.words[3] = (unsigned long long)rf.slot_cap * 6; c.value[3] = 0;
         c.ptr[4] = (uint32_t*)(s->d_tri_id + rf.slot_base); c.words[4] = (unsigned long long)rf.slot_cap; c.value[4] = 0xffffffffu;
         c.ptr[5] = (uint32_t*)(s->d_leaf_count + rf.slot_base); c.words[5] = (unsigned long long)rf.slot_cap; c.value[5] = 0;
+        c.ptr[6] = (uint32_t*)(s->d_mesh_flags + mesh_index); c.words[6] = 1; c.value[6] = 0;
         hipLaunchKernelGGL(clear_kernel, dim3(2048), dim3(T), 0, stream, c);
     }
     hipLaunchKernelGGL(leaf_ends_kernel, dim3((cap + T - 1) / T), dim3(T), 0, stream, b.nodes, b.state, leaf_hist, depth_hist);
     RT_HIP(hipcub::DeviceScan::ExclusiveSum(b.tmp, b.tmp_bytes, leaf_hist, leaf_before, n + 2, stream));
     hipLaunchKernelGGL(level_starts_kernel, dim3(1), dim3(1), 0, stream, depth_hist, level_cursor, d_result->level_count);
     hipLaunchKernelGGL(emit_nodes_kernel, dim3((cap + T - 1) / T), dim3(T), 0, stream, b.nodes, b.state, b.ends_before, leaf_before, rf.node_base, rf.slot_base,
-                       s->d_records, s->d_leaf_count, level_cursor, rf.d_sched, &d_result->root_entry);
+                       s->d_records, s->d_leaf_count, level_cursor, rf.d_sched, &d_result->root_entry, s->d_mesh_flags + mesh_index);
     if (n > 0)
         hipLaunchKernelGGL(emit_triangles_kernel, dim3((n + T - 1) / T), dim3(T), 0, stream, b.order, n, rf.slot_base, d_vertices, d_normals, d_uvs,
                            s->d_records, s->d_tri_uv, s->d_tri_id, &d_result->flags);

@@ -13,6 +13,13 @@ constexpr int32_t kLeafFlag = (int32_t)0x80000000u;
 constexpr int kSlotBits = 26;
 constexpr int32_t kSlotMask = (1 << kSlotBits) - 1;
 constexpr int kMaxStack = 64;
+constexpr int32_t kBoxUnordered = 1;    // mesh_flags bit 0: the octant-specialised slab test must not be used on this mesh
+
+// the twelve box words of an interior record: true when both boxes have min <= max on every axis (false for any NaN)
+RT_HD bool boxes_ordered(const float* w)
+{
+    return w[0] <= w[3] && w[1] <= w[4] && w[2] <= w[5] && w[6] <= w[9] && w[7] <= w[10] && w[8] <= w[11];
+}
 
 // Interior node: 64 B = 4 x float4, holds BOTH children's boxes so one pop costs one 64-B
 // record instead of the reference's three 48-B d_BVHTree loads (raycast.cu:62,69,70).
@@ -78,6 +85,7 @@ struct RenderParams {
     const float* tri_uv;        // [slot][3][2]
     const int32_t* tri_id;      // [slot] -> caller's triangle index within its mesh
     const int32_t* leaf_count;  // [slot] count of the leaf that starts at slot (only read for count > 30)
+    const int32_t* mesh_flags;  // [mesh] bit 0: some interior record of the mesh holds a box with min > max or a NaN (kBoxUnordered)
     const DevInstance* instances;
     const DevMaterial* materials;
     int32_t num_instances;

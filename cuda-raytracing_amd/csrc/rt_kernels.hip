@@ -55,6 +55,23 @@ __device__ __forceinline__ float slab(float dnx, float dny, float dnz, float dxx
     return hit ? dst_near : FLT_MAX;
 }
 
+// The same test for a ray whose sign octant is known at compile time (OCT bit k set = dinv component k negative): with
+// box.min <= box.max, a finite origin and a finite non-zero dinv, rounding is monotone, so fl((min-o)*dinv) <= fl((max-o)*dinv)
+// for dinv > 0 and the reverse for dinv < 0 -- which of the two products is the near one and which the far one is a choice
+// of operand per axis, not an instruction.  The values equal fminf / fmaxf of the pair except for the sign of a zero, which
+// no compare below can see.  (12 VALU fewer per interior node; trace_instance checks the preconditions per wave.)
+template <int OCT>
+__device__ __forceinline__ float slab_oct(float dnx, float dny, float dnz, float dxx, float dxy, float dxz, V3 dinv)
+{
+    float t1x = ((OCT & 1) ? dxx : dnx) * dinv.x, t2x = ((OCT & 1) ? dnx : dxx) * dinv.x;
+    float t1y = ((OCT & 2) ? dxy : dny) * dinv.y, t2y = ((OCT & 2) ? dny : dxy) * dinv.y;
+    float t1z = ((OCT & 4) ? dxz : dnz) * dinv.z, t2z = ((OCT & 4) ? dnz : dxz) * dinv.z;
+    float dst_far = fminf(fminf(t2x, t2y), t2z);
+    float dst_near = fmaxf(fmaxf(t1x, t1y), t1z);
+    bool hit = dst_far >= dst_near && dst_far > 0.0f;
+    return hit ? dst_near : FLT_MAX;
+}
+
 // The first twelve words of an interior record are the two child boxes (min xyz, max xyz each); this turns them into
 // box - origin, written over the record's registers q0..q2.  W = the record itself, or the 16-word scalar-register
 // vector of a wave-uniform fetch: the subtraction then takes its box operand from the scalar register directly and the
@@ -99,7 +116,10 @@ struct Counters<false> {};
 // LDS part at 16 entries lets 8 waves/SIMD stay resident (16 KB per 256-thread workgroup).
 constexpr int kLdsStack = 16;
 typedef __attribute__((address_space(3))) int lds_int;      // typed LDS pointer: keeps stack traffic on ds_read/ds_write
-template <int STRIDE>                                       // STRIDE = threads per workgroup (ints between two entries of a lane)
+// SPILL = false: the tree is shallow enough for the LDS part alone (a tree of L levels never holds more than L - 1 postponed
+// nodes: the entries of a stack sit at strictly increasing levels below the root) -- no private array, and neither push
+// nor pop carries the "which memory" branch (5 + 4 scalar instructions of exec-mask bookkeeping per iteration).
+template <int STRIDE, bool SPILL = true>                    // STRIDE = threads per workgroup (ints between two entries of a lane)
 struct StackT {
     lds_int* lds;               // this lane's LDS column
     int* spill;                 // this lane's private overflow, kMaxStack - kLdsStack entries
@@ -107,12 +127,14 @@ struct StackT {
     int sp;
     __device__ __forceinline__ void push(int32_t v)
     {
-        if (sp < lds_depth) lds[sp * STRIDE] = v; else spill[sp - lds_depth] = v;
+        if constexpr (SPILL) { if (sp < lds_depth) lds[sp * STRIDE] = v; else spill[sp - lds_depth] = v; }
+        else lds[sp * STRIDE] = v;
         sp++;
     }
     __device__ __forceinline__ int32_t pop()
     {
         --sp;
+        if constexpr (!SPILL) return lds[sp * STRIDE];
         // always an LDS read (index clamped) and, rarely, a private read on top: a select between the two
         // address spaces would turn into one slow flat_load
         int32_t v = lds[(sp < lds_depth ? sp : lds_depth - 1) * STRIDE];
@@ -142,22 +164,34 @@ __device__ __forceinline__ MeshRay to_mesh_space(const DevInstance& in, V3 org, 
 // One interior node (raycast.cu:66-79) from its already fetched 64-B record: tests both children, pushes the
 // far one if it passes `dist < hit.min`, and leaves in `cur` the entry the reference would pop next (the entry
 // pushed last never goes through the stack).  Returns false when nothing was pushed.
-template <bool DEBUG, class STK>
+template <bool DEBUG, class STK, int OCT = -1>
 __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, float4 q3, const MeshRay& r, float hit_min,
                                                int32_t& cur, STK& stack, Counters<DEBUG>& cnt)
 {
-    float da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.dinv);       // q0..q2: box - origin (box_differences)
-    float db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.dinv);
+    float da, db;                                                       // q0..q2: box - origin (box_differences)
+    if constexpr (OCT < 0) {
+        da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.dinv);
+        db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.dinv);
+    } else {
+        da = slab_oct<OCT>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.dinv);
+        db = slab_oct<OCT>(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.dinv);
+    }
     int32_t ra = __float_as_int(q3.x), rb = __float_as_int(q3.y);
     if constexpr (DEBUG) cnt.aabb += 2;
-    // push order of raycast.cu:72-79: `first` is pushed first, `second` last (= popped next)
+    // push order of raycast.cu:72-79: the farther child is pushed first, the nearer one last (= popped next); each only if
+    // its distance passes `dist < hit.min`.  With pa / pb = "child a / b passes": both pass -> push the far one (b when
+    // da < db, else a -- a tie takes the else branch) and go on with the near one; one passes -> go on with that one (it is
+    // the nearer: the other failed the same bound); none -> the caller pops.  (da, db are never NaN: slab returns a
+    // distance or FLT_MAX; a NaN hit_min fails every compare, as in the reference.)
     const bool a_near = da < db;
-    const int32_t first = a_near ? rb : ra, second = a_near ? ra : rb;
-    const float d_first = fmaxf(da, db), d_second = fminf(da, db);      // (never NaN: slab returns a distance or FLT_MAX)
-    const bool pf = d_first < hit_min, ps = d_second < hit_min;
-    if (pf && ps) stack.push(first);                            // the only entry that really goes through the stack
-    cur = ps ? second : first;                                  // (not used when neither passed: the caller pops)
-    return pf || ps;
+    const bool pa = da < hit_min, pb = db < hit_min;
+    int32_t next = pa ? ra : rb;
+    if (pa && pb) {
+        stack.push(a_near ? rb : ra);                           // the only entry that really goes through the stack
+        next = a_near ? ra : rb;
+    }
+    cur = next;                                                 // (not used when neither passed)
+    return pa || pb;
 }
 
 // What a triangle test proposes as the new closest hit.  Deliberately left uninitialised by the callers: it is only
@@ -229,7 +263,8 @@ __device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevIn
         c.dist = magnitude(loc - org);
         if constexpr (EX) c.loc = loc;
         // raycast.cu:107-109: same_dir = dot(r_ray.direction, normal) is `denom`
-        accept = denom < 0 && (hit_min == FLT_MAX || c.dist < hit_min);
+        // (bitwise: as `&&` / `||` the compiler builds a chain of exec-mask regions for the three compares)
+        accept = (denom < 0) & ((hit_min == FLT_MAX) | (c.dist < hit_min));
     }
     return accept;
 }
@@ -242,12 +277,11 @@ __device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevIn
 // PROF = diagnostic copy with s_memtime stamps per phase (RT_TRACE_FILE); its frames are never timed.
 // COUNT: *iters counts this lane's loop iterations (the cost measure behind the heavy-first dispatch order).
 // POPS (the extension kernel): *pops counts the lane's node pops, the one visit count that kernel reports.
-template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false>
-__device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
-                                               V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
-                                               int* pops = nullptr)
+// OCT >= 0: every lane of the wave is known to hold a ray of sign octant OCT that meets slab_oct's preconditions.
+template <bool DEBUG, bool PROF, bool EX, bool COUNT, class STK, bool POPS, int OCT>
+__device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInstance& in, int inst_index, const MeshRay& r,
+                                           V3 org, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters, int* pops)
 {
-    const MeshRay r = to_mesh_space(in, org, dir);
     stack.sp = 0;
     int32_t cur = in.root_ref;                                  // raycast.cu:58 (kept in a register)
     bool have = true;
@@ -306,16 +340,16 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             t2 = __builtin_amdgcn_s_memtime();
             n_it++; n_int += __ballot(interior) != 0; n_leaf += __ballot(!interior) != 0;
         }
-        if (interior) have = interior_apply<DEBUG, STK>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
+        if (interior) have = interior_apply<DEBUG, STK, OCT>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t3 = __builtin_amdgcn_s_memtime(); }
         bool accept = false;
         Candidate c;                                            // uninitialised on purpose, see Candidate
         const int slot = cur & kSlotMask;
         if (!interior) {                                        // leaf: contiguous triangle slots, raycast.cu:83-137
-            if (rem < 0) {                                      // first visit: decode the triangle count
-                rem = (cur >> kSlotBits) & 31;
-                if (rem == 31) rem = p.leaf_count[slot];
-            }
+            const bool first = rem < 0;                         // first visit: decode the triangle count
+            const int coded = (cur >> kSlotBits) & 31;
+            rem = first ? coded : rem;
+            if (first & (coded == 31)) rem = p.leaf_count[slot];    // (leaves of more than 30 triangles: rare)
             if (rem > 0) accept = triangle_test<DEBUG, EX>(p, in, exact_uv, identity_inv, r, org, slot, hit.min, cnt, r0, r1, r2, r3, c);
             rem--;
             have = rem > 0;
@@ -359,6 +393,46 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
     }
 }
 
+// Octant-specialised loops (RT_OCTANTS=0 at compile time keeps only the generic one).  The rays of a wave -- an 8x8-pixel
+// tile, or the samples of a few pixels -- almost always share the sign octant of their mesh-space direction: one ballot per
+// instance decides whether the wave runs the loop instantiated for that octant (slab_oct: the min / max pairs of the slab test
+// become operand choices) or the generic loop.  A wave qualifies when every active lane has a finite origin and finite,
+// non-zero direction inverses of the same signs, and the mesh has no interior record with an unordered or NaN box
+// (mesh_flags bit 0, kept by every writer of interior records: upload, device rebuild, refit).
+#ifndef RT_OCTANTS
+#define RT_OCTANTS 1
+#endif
+template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false>
+__device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
+                                               V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
+                                               int* pops = nullptr)
+{
+    const MeshRay r = to_mesh_space(in, org, dir);
+    int oct = -1;
+    if constexpr (RT_OCTANTS && !PROF) {
+        const float inf = __int_as_float(0x7f800000);
+        const bool usable = fabsf(r.dinv.x) < inf && fabsf(r.dinv.y) < inf && fabsf(r.dinv.z) < inf &&
+                            r.dinv.x != 0.0f && r.dinv.y != 0.0f && r.dinv.z != 0.0f &&
+                            fabsf(r.ro.x) < inf && fabsf(r.ro.y) < inf && fabsf(r.ro.z) < inf;
+        const int mine = (r.dinv.x < 0.0f ? 1 : 0) | (r.dinv.y < 0.0f ? 2 : 0) | (r.dinv.z < 0.0f ? 4 : 0);
+        const int first = __builtin_amdgcn_readfirstlane(mine);
+        if ((p.mesh_flags[in.mesh_index] & 1) == 0 && __ballot(!usable || mine != first) == 0ull) oct = first;
+    }
+#define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops)
+    switch (oct) {                                              // (wave-uniform: a scalar branch)
+    case 0: RT_TRACE_LOOP(0); break;
+    case 1: RT_TRACE_LOOP(1); break;
+    case 2: RT_TRACE_LOOP(2); break;
+    case 3: RT_TRACE_LOOP(3); break;
+    case 4: RT_TRACE_LOOP(4); break;
+    case 5: RT_TRACE_LOOP(5); break;
+    case 6: RT_TRACE_LOOP(6); break;
+    case 7: RT_TRACE_LOOP(7); break;
+    default: RT_TRACE_LOOP(-1); break;
+    }
+#undef RT_TRACE_LOOP
+}
+
 __device__ __forceinline__ uint8_t to_u8(float f) { return (uint8_t)(int)f; }
 
 // texture / albedo colour of a hit, raycast.cu:224-245 (ray.color starts at 1,1,1: Ray.hpp:22)
@@ -397,7 +471,7 @@ __device__ __forceinline__ uint32_t shade(const RenderParams& p, const Hit& hit)
 
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
 // (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
-template <bool DEBUG, bool PROF, bool COUNT = false>
+template <bool DEBUG, bool PROF, bool COUNT = false, bool SPILL = true>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x, int ly, int y, lds_int* lds_column,
                                              int* iters = nullptr)
 {
@@ -407,11 +481,11 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
     Counters<DEBUG> cnt;
-    int spill[kMaxStack - kLdsStack];
-    Stack stack;
+    int spill[SPILL ? kMaxStack - kLdsStack : 1];
+    StackT<kBlock, SPILL> stack;
     stack.lds = lds_column; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
     for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
-        trace_instance<DEBUG, PROF, false, COUNT>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
+        trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, SPILL>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
 
     const uint32_t px = shade(p, hit);
     uint8_t* out = f.img + (size_t)ly * p.pitch + 3 * (size_t)x;
@@ -439,7 +513,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
 // otherwise idle chip; started first, those waves run beside the bulk of the frame instead of after it
 // (measured: -22 % / -12 % / 0 % frame time for the far / mid / near camera).  Which tile a workgroup renders does not
 // change what a pixel computes.
-template <bool DEBUG, bool PROF, bool ORDERED = false>
+template <bool DEBUG, bool PROF, bool ORDERED = false, bool SPILL = true>
 __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];                          // [min(stack_depth, kLdsStack)][kBlock] (+ 1 int when ORDERED)
@@ -471,7 +545,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
     if (x < p.width && ly < p.local_rows) {
         // stripes: local row -> frame row (identity when num_ranks == 1)
         const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
-        render_pixel<DEBUG, PROF, ORDERED>(p, p.frames[frame], x, ly, y, (lds_int*)lds_stack + tid, &iters);
+        render_pixel<DEBUG, PROF, ORDERED, SPILL>(p, p.frames[frame], x, ly, y, (lds_int*)lds_stack + tid, &iters);
     }
     if constexpr (ORDERED) {
         // cost of the tile = loop iterations of its longest lane: deterministic, unlike a lifetime, which also measures
@@ -1049,7 +1123,7 @@ __device__ __forceinline__ void refit_child_box(const float4* records, const int
 
 // one level of interior nodes, deepest level first: sched[begin .. end) are the record indices of the level
 __global__ void refit_level_kernel(float4* records, const int32_t* __restrict__ tri_id, const int32_t* __restrict__ leaf_count,
-                                   const float* __restrict__ vertices, const int32_t* __restrict__ sched, int begin, int end)
+                                   const float* __restrict__ vertices, const int32_t* __restrict__ sched, int begin, int end, int32_t* mesh_flag)
 {
     const int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= end) return;
@@ -1061,6 +1135,8 @@ __global__ void refit_level_kernel(float4* records, const int32_t* __restrict__ 
     q[0] = make_float4(amn[0], amn[1], amn[2], amx[0]);
     q[1] = make_float4(amx[1], amx[2], bmn[0], bmn[1]);
     q[2] = make_float4(bmn[2], bmx[0], bmx[1], bmx[2]);
+    const float w[12] = {amn[0], amn[1], amn[2], amx[0], amx[1], amx[2], bmn[0], bmn[1], bmn[2], bmx[0], bmx[1], bmx[2]};
+    if (!boxes_ordered(w)) *mesh_flag = kBoxUnordered;          // (only ever set here: a refit never makes a mesh eligible again)
 }
 
 // A run of consecutive NARROW levels (the top of every tree, and the thin bottom of a deep one: each a launch of a few dozen
@@ -1070,7 +1146,7 @@ constexpr int kRefitRunLevels = 32, kRefitRunThreads = 256;
 struct RefitRun { int32_t levels; int32_t bound[kRefitRunLevels + 1]; };       // level k of the run = sched[bound[k] .. bound[k + 1])
 __global__ __launch_bounds__(kRefitRunThreads) void refit_run_kernel(float4* records, const int32_t* __restrict__ tri_id,
                                                                    const int32_t* __restrict__ leaf_count, const float* __restrict__ vertices,
-                                                                   const int32_t* __restrict__ sched, const RefitRun run)
+                                                                   const int32_t* __restrict__ sched, const RefitRun run, int32_t* mesh_flag)
 {
     for (int l = 0; l < run.levels; l++) {
         for (int i = run.bound[l] + (int)threadIdx.x; i < run.bound[l + 1]; i += kRefitRunThreads) {
@@ -1082,6 +1158,8 @@ __global__ __launch_bounds__(kRefitRunThreads) void refit_run_kernel(float4* rec
             q[0] = make_float4(amn[0], amn[1], amn[2], amx[0]);
             q[1] = make_float4(amx[1], amx[2], bmn[0], bmn[1]);
             q[2] = make_float4(bmn[2], bmx[0], bmx[1], bmx[2]);
+            const float w[12] = {amn[0], amn[1], amn[2], amx[0], amx[1], amx[2], bmn[0], bmn[1], bmn[2], bmx[0], bmx[1], bmx[2]};
+            if (!boxes_ordered(w)) *mesh_flag = kBoxUnordered;
         }
         __threadfence_block();
         __syncthreads();
@@ -1164,7 +1242,7 @@ int fill_params(RenderParams& p, const RtScene* s, const RtCameraParams* cams, u
         f.img = d_imgs[i];
     }
     p.records = s->d_records; p.tri_uv = s->d_tri_uv; p.tri_id = s->d_tri_id;
-    p.leaf_count = s->d_leaf_count;
+    p.leaf_count = s->d_leaf_count; p.mesh_flags = s->d_mesh_flags;
     p.instances = s->d_instances; p.materials = s->d_materials;
     p.num_instances = (int32_t)s->instances.size();
     p.stack_depth = s->max_stack;
@@ -1208,6 +1286,14 @@ bool order_state_idle(RtScene::TileOrder& o)
     return true;
 }
 }  // namespace
+
+// a tree of L levels never holds more than L - 1 postponed nodes (see StackT): the kernels without the private overflow
+// RT_STACK_SPILL=1 forces the general kernels (tests: both forms on every scene)
+bool lds_stack_suffices(const RenderParams& p)
+{
+    static const bool forced = [] { const char* e = getenv("RT_STACK_SPILL"); return e && e[0] == '1'; }();
+    return !forced && p.stack_depth - 1 <= kLdsStack;
+}
 
 int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchronize)
 {
@@ -1256,7 +1342,8 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     p.tile_order = (mine && o->cur >= 0) ? o->d_order[o->cur] : nullptr;
     p.tile_cost = mine ? o->d_cost : nullptr;
     const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int) + 2 * sizeof(int);
-    hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
+    if (lds_stack_suffices(p)) hipLaunchKernelGGL((render_kernel<false, false, true, false>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
+    else hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     RT_HIP(hipGetLastError());
     if (mine) RT_HIP(hipEventRecord(mine->done, stream));
     if (mine && !o->pending) {
@@ -1292,6 +1379,7 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     if (trace_file) RT_HIP(trace_begin(p, trace_n));
     if (trace_file && getenv("RT_TRACE_PROF")) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, stream, p);
     else if (debug) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);
+    else if (lds_stack_suffices(p)) hipLaunchKernelGGL((render_kernel<false, false, false, false>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, stream, p);
     RT_HIP(hipGetLastError());
     if (trace_file) RT_HIP(trace_end(p, trace_n, trace_file, stream));
@@ -1369,7 +1457,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     // leaf order.  The per-triangle side arrays use the same index (their entries at interior records are unused).
     std::vector<float4> records;
     std::vector<float> tri_uv;
-    std::vector<int32_t> tri_id, leaf_count;
+    std::vector<int32_t> tri_id, leaf_count, mesh_flags;
     std::vector<int> build_on_device;               // meshes that arrive without a tree (num_nodes == 0)
     try {
         for (int mi = 0; mi < desc->num_meshes && rc == RT_OK; mi++) {
@@ -1392,6 +1480,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                 rf.slot_base = (int32_t)slot_base; rf.num_slots = 0; rf.num_triangles = 0;
                 s->mesh_refit.push_back(std::move(rf));
                 build_on_device.push_back(mi);
+                mesh_flags.push_back(0);                         // (the rebuild on the device sets it)
                 continue;
             }
             if (m.num_nodes < 1 || m.num_leaf_indices < 0 || !m.node_bounds || !m.node_children || !m.node_leaf_first || !m.node_leaf_count ||
@@ -1431,7 +1520,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             if (max_level > kMaxStack) { rc = RT_E_DEPTH; break; }
             s->max_stack = std::max(s->max_stack, max_level);
             // pass 2: emit records
-            bool exact_uv = false;
+            bool exact_uv = false, unordered = false;
             const int64_t slot_cap = std::max<int64_t>(n_slot, m.num_triangles);
             records.reserve(records.size() + (size_t)(int_cap + slot_cap) * 4 + 4);
             tri_uv.reserve(tri_uv.size() + (size_t)(int_cap + slot_cap) * 6);
@@ -1451,6 +1540,8 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                     q[1] = make_float4(A[4], A[5], B[0], B[1]);
                     q[2] = make_float4(B[2], B[3], B[4], B[5]);
                     q[3] = make_float4(i2f(entry[a]), i2f(entry[b]), 0.0f, 0.0f);
+                    const float w[12] = {A[0], A[1], A[2], A[3], A[4], A[5], B[0], B[1], B[2], B[3], B[4], B[5]};
+                    if (!boxes_ordered(w)) unordered = true;
                 } else {
                     const int first = m.node_leaf_first[i], count = m.node_leaf_count[i];
                     for (int k = 0; k < count; k++) {
@@ -1484,6 +1575,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             leaf_count.resize((size_t)slot_base + (size_t)slot_cap, 0);
             s->mesh_root_ref.push_back(entry[0]);
             s->mesh_exact_uv.push_back(exact_uv ? 1 : 0);
+            mesh_flags.push_back(unordered ? kBoxUnordered : 0);
             {
                 RtScene::MeshRefit rf;
                 rf.node_base = (int32_t)node_base; rf.int_cap = (int32_t)int_cap; rf.slot_cap = (int32_t)slot_cap; rf.levels = max_level;
@@ -1522,6 +1614,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     if ((rc = upload(&s->d_tri_uv, tri_uv, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_tri_id, tri_id, s->device_bytes))) return fail(rc);
     if ((rc = upload(&s->d_leaf_count, leaf_count, s->device_bytes))) return fail(rc);
+    if ((rc = upload(&s->d_mesh_flags, mesh_flags, s->device_bytes))) return fail(rc);
     for (auto& rf : s->mesh_refit) {
         std::vector<int32_t> sched(rf.sched);
         sched.resize((size_t)std::max(rf.int_cap, 1), 0);            // (capacity for the schedule of any tree over the mesh)
@@ -1616,22 +1709,23 @@ int refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, const floa
     // kRefitRunThreads nodes share one single-workgroup launch (a 28-level tree: 10 launches instead of 28 -- with the arrays
     // already on the device the call is launch-bound)
     int begin = 0;
+    int32_t* mesh_flag = s->d_mesh_flags + mesh_index;
     RefitRun run;
     run.levels = 0;
     auto flush = [&] {
         if (run.levels == 0) return;
         if (run.levels == 1)
             hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)((run.bound[1] - run.bound[0] + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
-                               s->d_leaf_count, d_v, rf.d_sched, run.bound[0], run.bound[1]);
+                               s->d_leaf_count, d_v, rf.d_sched, run.bound[0], run.bound[1], mesh_flag);
         else
-            hipLaunchKernelGGL(refit_run_kernel, dim3(1), dim3(kRefitRunThreads), 0, st, s->d_records, s->d_tri_id, s->d_leaf_count, d_v, rf.d_sched, run);
+            hipLaunchKernelGGL(refit_run_kernel, dim3(1), dim3(kRefitRunThreads), 0, st, s->d_records, s->d_tri_id, s->d_leaf_count, d_v, rf.d_sched, run, mesh_flag);
         run.levels = 0;
     };
     for (int32_t end : rf.level_end) {
         if (end - begin > kRefitRunThreads) {
             flush();
             hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)((end - begin + 255) / 256)), dim3(256), 0, st, s->d_records, s->d_tri_id,
-                               s->d_leaf_count, d_v, rf.d_sched, begin, end);
+                               s->d_leaf_count, d_v, rf.d_sched, begin, end, mesh_flag);
         } else {
             if (run.levels == kRefitRunLevels) flush();
             if (run.levels == 0) run.bound[0] = begin;
@@ -1690,7 +1784,7 @@ int rt_scene_destroy(RtScene* s)
     (void)hipFree(s->d_refit_scratch);
     (void)hipFree(s->d_ex_scratch);
     (void)hipFree(s->d_records); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
-    (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
+    (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_mesh_flags); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
     for (uint8_t* t : s->d_textures) (void)hipFree(t);
     delete s;
     return RT_OK;

@@ -17,6 +17,7 @@ struct RtScene {
     float* d_tri_uv = nullptr;
     int32_t* d_tri_id = nullptr;
     int32_t* d_leaf_count = nullptr;
+    int32_t* d_mesh_flags = nullptr;             // per mesh, rt::kBoxUnordered: written by every writer of interior records
     DevInstance* d_instances = nullptr;
     DevMaterial* d_materials = nullptr;
     std::vector<uint8_t*> d_textures;
