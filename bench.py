@@ -8,6 +8,8 @@ Workloads (BASELINE.json configs[1..4]; scenes are synthetic, see cuda-raytracin
   c3  the same mesh, 64 spp, 8 specular bounces, sun + shadow rays     (extension kernel)
   c4  260k-triangle atrium, 3840x2160, 16 spp                           (--spp 1: the primary kernel at 4K)
   c5  the c3 workload at 7680x4320, meant for --gpus 8 (frame tiled over the ranks, RCCL gather to rank 0)
+  c6  the atrium generator at 4.07 M triangles (395 MB of records: larger than the 256 MiB Infinity Cache), 3840x2160, 1 primary
+      ray per pixel -- the HBM regime; `--bounces 2 --metallic 1 --roughness 0.3` is its incoherent variant
 One "step" = one frame.  `value` = primary rays (width x height x spp) per second of wall clock over K steps, scene and
 frame buffers resident in HBM, timed between two barrier + synchronise pairs, max over ranks.  The untimed warm-up is at
 least W steps and, for the 1-spp stream, at least 320 frames (a frame is 0.13 ms; the GPU's clock needs tens of
@@ -60,7 +62,7 @@ VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 2 / 1e9     # wave64 VALU instructions per
 L1_PEAK_GBS = 256 * 64 * CLOCK_HZ / 1e9           # vector L1: one 64-B access per CU per clock
 STRIPE_ROWS = 16
 MIN_WARM_FRAMES = 320            # 1-spp stream workloads: untimed frames before the timed region, whatever --warmup asks (see run_stream)
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r03_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r04_counters.json")
 _build = importlib.import_module("cuda-raytracing_amd._build")
 
 
@@ -105,13 +107,48 @@ class PhaseWatchdog:
                 phase, done = self.phase, list(self.done)
             if late:
                 try:
-                    err = rt.Comm.last_error()
+                    err = rt.Comm.last_error_any()                      # (rt_comm_last_error() is per thread: this thread made no comm call)
                 except Exception as e:                                  # (the library may not even be loaded yet)
                     err = "unavailable (%s)" % e
                 log("bench.py rank %d: phase '%s' exceeded its deadline of %.0f s -- giving up (exit code 3).  rt_comm_last_error(): %r; "
                     "phases completed: %s; NCCL_DEBUG=%s" % (self.rank, phase, self.seconds, err, ", ".join(done) or "none", os.environ.get("NCCL_DEBUG", "")))
                 sys.stderr.flush()
                 os._exit(3)
+
+
+REPEATS_SHORT = 9                # a timed region of ONE launch is measured this many times, back to back; the line reports the median
+
+
+def aggregate_repeats(dts, steps):
+    """dts = wall-clock seconds of each repeat of the K-step timed region (max over ranks already taken per repeat).
+    -> dict(dt = the region's time the line is priced with (the median), fields = what the line says about it)."""
+    d = sorted(float(v) for v in dts)
+    n = len(d)
+    med = d[n // 2] if n % 2 else 0.5 * (d[n // 2 - 1] + d[n // 2])
+    fields = {"repeats": n}
+    if n > 1:
+        fields.update({"ms_per_step_min": round(d[0] / steps * 1e3, 4), "ms_per_step_max": round(d[-1] / steps * 1e3, 4),
+                       "timed_region": "median of %d back-to-back repeats of the %d-step region (each between barrier + synchronise pairs)" % (n, steps)})
+    return {"dt": med, "fields": fields}
+
+
+def multi_rank_report(per_rank, comm):
+    """N > 1 stream runs: the stage times every rank measured (tiling.StripePipeline.stage_times: hipEvents at the stage
+    boundaries of every timed group), how unevenly the stripes loaded the ranks, and what is known about the RCCL in use."""
+    renders = [r.get("render_ms_per_group") for r in per_rank if r and r.get("render_ms_per_group") is not None]
+    out = {"per_rank": per_rank,
+           "stripe_share_imbalance": round(max(renders) / (sum(renders) / len(renders)), 4) if renders and sum(renders) > 0 else None}
+    ver = None
+    try:
+        v = C.c_int32(0)
+        if rt.libs()[0].rt_comm_available(C.byref(v)) == 0:
+            ver = v.value
+    except Exception:
+        pass
+    out["rccl"] = {"version": ver, "through": "rt_comm (C-ABI)" if comm is not None else "torch.distributed",
+                   "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                   "note": "channel count = RCCL's own choice unless NCCL_MAX_NCHANNELS is set (--rccl-max-channels); RCCL exposes no query for it"}
+    return out
 
 
 def camera_path(base, n):
@@ -143,6 +180,12 @@ def scene_path(workload):
         p = os.path.join(d, "atrium.obj")
         if not os.path.exists(p):
             scenes.write_atrium_obj(p)
+        return p
+    if workload == "c6":                                                # (296 MB of text, written in about 15 s)
+        p = os.path.join(d, "atrium_c6.obj")
+        if not os.path.exists(p):
+            log("bench.py: writing the c6 scene (%d triangles) to %s" % (scenes.C6["n_tris"], p))
+            scenes.write_atrium_obj(p, **scenes.C6["atrium"])
         return p
     p = os.path.join(d, "blob70k.obj")
     if not os.path.exists(p):
@@ -302,7 +345,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="frames to time (default: 960 for the 1-spp stream, 20 for spp / bounce workloads)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed frames before (default 64 / 3)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "c6"])
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -326,6 +369,9 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="N > 1 data path: rccl = RtComm of the C-ABI (rt_gather / rt_all_to_all / rt_render_tiled), torch = the same buffers "
                          "through torch.distributed's nccl backend (what a failed RtComm creation falls back to, announced in the line)")
+    ap.add_argument("--rccl-max-channels", type=int, default=0,
+                    help="N > 1: NCCL_MAX_NCHANNELS for the ranks (0 = RCCL's own choice): bounds the CUs RCCL's kernels take from render_kernel, "
+                         "for an A/B of the contention between the exchange of group i and the render of group i + 1")
     ap.add_argument("--one-stream", action="store_true", help="N > 1: launch every group on the same compute stream")
     ap.add_argument("--two-streams", action="store_true", help="one GPU: alternate consecutive groups between two streams")
     ap.add_argument("--force-collective", action="store_true",
@@ -341,6 +387,8 @@ def main():
     if args.steps < 1:
         sys.exit("bench.py: --steps must be at least 1")
 
+    if args.rccl_max_channels > 0:                               # (before any communicator exists; inherited by the ranks self_launch starts)
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_channels)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
@@ -390,8 +438,9 @@ def main():
     lighting = args.lighting if args.lighting >= 0 else wl.get("lighting", 0)
     stream_mode = (spp, bounces, lighting) == (1, 0, 0)           # the primary kernel, frames in groups; else one frame per step
     K, D = scenes.scaled_K(W), scenes.D_REF
-    base_pose = wl["cam_pose"] if args.workload == "c4" else scenes.C2_CAMERAS[args.camera]
-    cam_name = "inside" if args.workload == "c4" else args.camera
+    atrium = args.workload in ("c4", "c6")
+    base_pose = wl["cam_pose"] if atrium else scenes.C2_CAMERAS[args.camera]
+    cam_name = "inside" if atrium else args.camera
     key = "%s_%s_%dx%d_%d_%d_%d" % (args.workload, cam_name, W, H, spp, bounces, lighting)
     if args.metallic >= 0 or args.roughness >= 0:
         key += "_m%g_r%g" % (wl.get("metallic", 0.0), wl.get("roughness", 0.0))
@@ -603,19 +652,40 @@ def run_stream(args, env):
     for i, c in enumerate(warm_groups):
         step_group(i, c)
     sync()
-    g["phase"]("timed loop", 4.0)
-    t0 = time.perf_counter()
-    for i, c in enumerate(groups):
-        step_group(i, c)
-    t_issue = time.perf_counter() - t0                           # host time to issue all groups (must stay below the GPU's)
     if pipe is not None:
-        pipe.drain()
-    sync()
-    dt = time.perf_counter() - t0
+        pipe.stage_timing(True)                                  # per group: wait for buffer / render / exchange / un-stripe (events, no waits)
+    g["phase"]("timed loop", 4.0)
+    # The timed region = the K steps between two barrier + synchronise pairs.  When K fits ONE launch (the driver's
+    # --steps 20) that region is a single 2.7 ms sample: it is then measured REPEATS_SHORT times back to back and the line
+    # reports the median (with min / max / repeats); still a few tens of milliseconds in all.
+    repeats = REPEATS_SHORT if len(groups) == 1 else 1
+    dts, t_issue = [], 0.0
+    for rep in range(repeats):
+        t0 = time.perf_counter()
+        for i, c in enumerate(groups):
+            step_group(i + rep * len(groups), c)
+        t_issue = time.perf_counter() - t0                       # host time to issue all groups (must stay below the GPU's)
+        if pipe is not None:
+            pipe.drain()
+        sync()
+        dts.append(time.perf_counter() - t0)
     if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tmax = torch.tensor(dts, dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)              # per repeat: the slowest rank
+        dts = [float(v) for v in tmax.tolist()]
+    timing = aggregate_repeats(dts, args.steps)
+    dt = timing["dt"]
+    # where a rank's time went, per group of F frames: every rank reports, rank 0 prints all of them
+    per_rank = None
+    if pipe is not None:
+        mine_t = dict(pipe.stage_times() or {}, rank=rank)
+        pipe.stage_timing(False)
+        box = [None] * world
+        if world > 1:
+            dist.all_gather_object(box, mine_t)
+        else:
+            box = [mine_t]
+        per_rank = box
 
     # ---- kernel-only duration with hipEvents on the launch stream (roofline denominator); latency figures ----
     g["phase"]("check", 4.0)
@@ -634,7 +704,7 @@ def run_stream(args, env):
         dist.barrier()
 
     # ---- every rank checks frames it assembled in the last group against the debug kernel at the same pose ----
-    last_b, last_c = (len(groups) - 1) & 1, (groups[-1] if groups else F)
+    last_b, last_c = (repeats * len(groups) - 1) & 1, (groups[-1] if groups else F)
     mine = my_frames(last_c)
     held = frames_of(last_b).cpu().numpy().reshape(F, H, W, 3)
     frame_ok, ids_ok, dbg0 = True, True, None
@@ -661,7 +731,7 @@ def run_stream(args, env):
           "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
     alg = algorithmic_bytes(st)
     mesh, wl = g["mesh"], g["wl"]
-    name = {"c2": "C2 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ"}.get(args.workload, args.workload)
+    name = {"c2": "C2 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ", "c6": "C6 atrium OBJ at 16 x the triangles of C4 (records exceed the Infinity Cache)"}.get(args.workload, args.workload)
     config = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s; every frame of a group has its own pose "
                           "(a 4 mm loop around that camera)" % (name, mesh.num_triangles, mesh.num_nodes, W, H, g["cam_name"], str(tuple(base_pose[:3]))),
               "key": g["key"] + ("_f1" if F == 1 and not dist_on else ""), "width": W, "height": H, "spp": 1, "bounces": 0, "lighting": 0,
@@ -675,13 +745,18 @@ def run_stream(args, env):
               "algorithmic_bytes_per_ray": round(alg / st["rays"], 1)}
     # one frame per launch goes through the heavy-first variant of the kernel: its own profile entry
     single = F == 1 and not dist_on
-    roof = roofline("render_kernel<false,false,true>" if single else "render_kernel<false,false,false>", g["key"] + ("_f1" if single else ""),
+    # (fourth template argument: the kernel with the private overflow of the traversal stack, for trees deeper than its LDS part)
+    spill = scene.info()["max_stack"] - 1 > 16 or os.environ.get("RT_STACK_SPILL", "")[:1] == "1"
+    roof = roofline("render_kernel<false,false,%s,%s>" % ("true" if single else "false", "true" if spill else "false"), g["key"] + ("_f1" if single else ""),
                     kernel_ms, F, 1.0 / world, alg)
     # ms_per_step is the throughput figure of a batch (F frames per launch); what one frame takes on its own is spelled out next to it
     extra = {"frames_per_launch": F,
              "ms_per_frame_single_launch": None if latency is None else latency["f1_kernel_ms"],
              "ms_per_frame_reference_loop": None if latency is None else latency["reference_loop_2_renders_per_sync_wall_ms_per_frame"],
              "frame_matches_debug_kernel": frame_ok, "production_hit_ids_match_debug_kernel": ids_ok}
+    extra.update(timing["fields"])
+    if per_rank is not None:
+        extra.update(multi_rank_report(per_rank, g["comm"]))
     value = W * H * args.steps / dt / 1e6
     out = base_line(args, g, value, dt, len(warm_groups) * F, config, roof, extra)
     if not dist_on and not args.no_cpu_baseline:
@@ -882,7 +957,7 @@ def run_frames(args, env):
     frame_ok = bool(np.array_equal(got, whole["img"]))
     pops = int(whole["total_pops"].astype(np.int64).sum())
     mesh, wl = g["mesh"], g["wl"]
-    name = {"c3": "C3 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ", "c5": "C5 bunny-class blob OBJ"}.get(args.workload, args.workload)
+    name = {"c3": "C3 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ", "c5": "C5 bunny-class blob OBJ", "c6": "C6 atrium OBJ at 16 x the triangles of C4"}.get(args.workload, args.workload)
     config = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, %d spp, %d specular bounces, lighting %d (material roughness %.2f metallic %.2f), camera '%s' %s"
                           % (name, mesh.num_triangles, mesh.num_nodes, W, H, spp, bounces, lighting, wl.get("roughness", 0.0), wl.get("metallic", 0.0),
                              g["cam_name"], str(tuple(base_pose[:3]))),

@@ -51,6 +51,10 @@ public:
         std::vector<int32_t> leaf_indices;
     };
     DeviceCompatible to_device_compatible() const;
+    // BVHTree.hpp:364-383 under its own name: the reference walks the tree's node list, converts every node with
+    // to_device_compatible() and uploads the array; here the conversion of the whole tree is one call and the upload is
+    // Scene::upload_to_device's (or MeshPrimitive::to_device's), so this returns the arrays that upload takes.
+    static DeviceCompatible compile_tree(BVHTree& top) { return top.to_device_compatible(); }
 
 private:
     void fill(int self, int depth, int max_depth);

@@ -1,9 +1,20 @@
-// MeshPrimitive.h -- a triangle array plus its BVH (MeshPrimitive.h:27-43).  The device copy is
-// made by Scene::upload_to_device through the C-ABI, so there is no per-mesh to_device().
+// MeshPrimitive.h -- a triangle array plus its BVH (MeshPrimitive.h:27-43).  A scene's device copy is
+// made as a whole by Scene::upload_to_device through the C-ABI; to_device() exists for callers of the reference's
+// per-mesh upload (MeshPrimitive.h:36, MeshPrimitive.cpp:17-36).
 #pragma once
 #include <vector>
 #include "BVHTree.hpp"
 #include "TrianglePrimitive.hpp"
+
+struct RtScene;
+// What MeshPrimitive::to_device() returns (the reference's d_MeshPrimitive, MeshPrimitive.h:13-25, holds raw device pointers
+// to an AoS triangle array and a d_BVHTree array; here the mesh's device form is the record arrays of the C-ABI): a HOST
+// object that owns a one-mesh device scene.  Like the reference's, it is never freed unless the caller does
+// (rt_scene_destroy(d->device) + delete d).
+struct d_MeshPrimitive {
+    int num_triangles = 0;
+    RtScene* device = nullptr;      // rt_scene_upload of this mesh alone (no materials, no instances); nullptr if the upload failed
+};
 
 class MeshPrimitive {
 public:
@@ -18,6 +29,7 @@ public:
     bool builds_at_upload() const { return tree_needs_rebuild; }
     int num_triangles;
     BVHTree bvh_top;
+    d_MeshPrimitive* to_device();                               // MeshPrimitive.h:36: this mesh's records on the current device
     const std::vector<TrianglePrimitive>& triangle_array() const { return triangles; }
     // deformation with fixed connectivity: replaces the triangles (same count) and refits the BVH bounds; false if the count differs.
     // defer_tree = true leaves bvh_top's bounds as they are until sync_tree() -- Scene::refit_mesh does that for an uploaded

@@ -35,9 +35,11 @@ public:
     // A mesh deforms (same triangle count and order): host copy and device copy get the moved triangles and refitted
     // bounds; no rebuild, no re-upload of anything else.  Ordered on `stream` like update_mesh_instance(.., stream).
     void refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream = nullptr);
-    // A mesh changes beyond what a refit can follow (large motion, or other triangles -- at most as many as it was uploaded with):
-    // the device copy gets a NEW tree, built on the GPU straight into the scene's arrays (rt_scene_rebuild_mesh_device), the
-    // host copy rebuilds its tree when it is next needed.  Returns when the new tree is in place.
+    // A mesh changes beyond what a refit can follow (large motion, or other triangles): the device copy gets a NEW tree, built on
+    // the GPU straight into the scene's arrays (rt_scene_rebuild_mesh_device), the host copy rebuilds its tree when it is next
+    // needed.  More triangles than the mesh was uploaded with do not fit its part of the arrays: the whole scene is uploaded
+    // again then (upload_to_device).  The host mesh changes only once the device call has succeeded: on an error (last_error)
+    // host and device still describe the old mesh.  Returns when the new tree is in place.
     void rebuild_mesh(int mesh_index, std::vector<TrianglePrimitive> triangles, void* stream = nullptr);
     RtScene* d_scene = nullptr;
     int num_mesh_instances = 0;

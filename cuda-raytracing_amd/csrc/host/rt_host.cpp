@@ -310,6 +310,61 @@ MeshPrimitive::MeshPrimitive(std::vector<TrianglePrimitive> tris, bool build_on_
     if (rc) throw std::runtime_error(std::string("MeshPrimitive: GPU BVH build failed: ") + rt_error_string(rc));
 }
 
+// MeshPrimitive.cpp:17-36: the reference uploads the triangle array and the compiled tree and returns a device struct of
+// raw pointers; the C-ABI's device form of a mesh is its part of a scene's record arrays, so this uploads a scene that holds
+// nothing but this mesh.
+static void flatten_mesh(const MeshPrimitive& m, std::vector<float>& v, std::vector<float>& n, std::vector<float>& uv)
+{
+    const auto& tris = m.triangle_array();
+    v.resize(tris.size() * 9); n.resize(tris.size() * 3); uv.resize(tris.size() * 6);
+    for (size_t t = 0; t < tris.size(); t++) {
+        for (int k = 0; k < 3; k++) {
+            v[9 * t + 3 * k] = tris[t].vertices[k].x; v[9 * t + 3 * k + 1] = tris[t].vertices[k].y; v[9 * t + 3 * k + 2] = tris[t].vertices[k].z;
+            uv[6 * t + 2 * k] = tris[t].uv_coords[k].x; uv[6 * t + 2 * k + 1] = tris[t].uv_coords[k].y;
+        }
+        n[3 * t] = tris[t].normal.x; n[3 * t + 1] = tris[t].normal.y; n[3 * t + 2] = tris[t].normal.z;
+    }
+}
+
+d_MeshPrimitive* MeshPrimitive::to_device()
+{
+    const bool device_build = builds_at_upload();
+    if (!device_build) sync_tree();
+    std::vector<float> v, n, uv;
+    flatten_mesh(*this, v, n, uv);
+    RtMeshDesc d;
+    memset(&d, 0, sizeof d);
+    d.num_triangles = num_triangles;
+    d.vertices = v.data(); d.normals = n.data(); d.uvs = uv.data();
+    BVHTree::DeviceCompatible tree;
+    if (!device_build) {
+        tree = BVHTree::compile_tree(bvh_top);                    // BVHTree.hpp:364-383
+        d.num_nodes = (int32_t)bvh_top.nodes.size();
+        d.node_bounds = tree.node_bounds.data(); d.node_children = tree.node_children.data();
+        d.node_leaf_first = tree.node_leaf_first.data(); d.node_leaf_count = tree.node_leaf_count.data();
+        d.num_leaf_indices = (int32_t)tree.leaf_indices.size(); d.leaf_indices = tree.leaf_indices.data();
+    }
+    RtSceneDesc sd;
+    memset(&sd, 0, sizeof sd);
+    sd.num_meshes = 1; sd.meshes = &d;
+    d_MeshPrimitive* out = new d_MeshPrimitive;
+    out->num_triangles = num_triangles;
+    if (rt_scene_upload(&sd, &out->device) != RT_OK) out->device = nullptr;
+    return out;
+}
+
+Material* Material::to_device() const
+{
+    RtMaterialDesc d;
+    memset(&d, 0, sizeof d);
+    d.roughness = roughness; d.albedo[0] = albedo.x; d.albedo[1] = albedo.y; d.albedo[2] = albedo.z;
+    d.metallic = metallic; d.illumination = illumination;
+    void* dev = nullptr;
+    if (rt_malloc(&dev, sizeof d) != RT_OK) return nullptr;
+    if (rt_memcpy_h2d(dev, &d, sizeof d, nullptr) != RT_OK) { (void)rt_free(dev); return nullptr; }
+    return reinterpret_cast<Material*>(dev);
+}
+
 MeshPrimitive MeshPrimitive::for_device_build(std::vector<TrianglePrimitive> tris)
 {
     MeshPrimitive m;
@@ -441,13 +496,27 @@ void Scene::rebuild_mesh(int mesh_index, std::vector<TrianglePrimitive> tris, vo
 {
     if (mesh_index < 0 || mesh_index >= (int)meshes.size()) { last_error = RT_E_INVALID; return; }
     MeshPrimitive& m = meshes[(size_t)mesh_index];
-    m.replace(std::move(tris), d_scene != nullptr);
-    if (!d_scene) { last_error = RT_OK; return; }               // not uploaded yet: upload_to_device() will send the new mesh
-    const size_t n = (size_t)m.num_triangles;
+    if (!d_scene) {                                             // not uploaded yet: upload_to_device() will send the new mesh
+        m.replace(std::move(tris), false);
+        last_error = RT_OK;
+        return;
+    }
+    // The device goes first and the host mesh follows only when the device has the new tree: host and device must never
+    // describe different meshes (a later refit_mesh would be refused for its triangle count with nothing to explain it).
+    const size_t n = tris.size();
+    int32_t capacity = 0;
+    last_error = rt_scene_mesh_capacity(d_scene, mesh_index, &capacity);
+    if (last_error) return;
+    if (n > (size_t)capacity) {
+        // more triangles than the mesh's part of the device arrays has room for: the whole scene is uploaded again
+        m.replace(std::move(tris), false);
+        upload_to_device();
+        return;
+    }
     std::vector<float> host(n * 18);                            // vertices [n][9], normals [n][3], uvs [n][6]
     float *v = host.data(), *nn = v + n * 9, *uv = nn + n * 3;
     for (size_t t = 0; t < n; t++) {
-        const TrianglePrimitive& tr = m.triangle_array()[t];
+        const TrianglePrimitive& tr = tris[t];
         for (int k = 0; k < 3; k++) {
             v[9 * t + 3 * k] = tr.vertices[k].x; v[9 * t + 3 * k + 1] = tr.vertices[k].y; v[9 * t + 3 * k + 2] = tr.vertices[k].z;
             uv[6 * t + 2 * k] = tr.uv_coords[k].x; uv[6 * t + 2 * k + 1] = tr.uv_coords[k].y;
@@ -461,6 +530,7 @@ void Scene::rebuild_mesh(int mesh_index, std::vector<TrianglePrimitive> tris, vo
     const float* dv = (const float*)d;
     if (last_error == RT_OK) last_error = rt_scene_rebuild_mesh_device(d_scene, mesh_index, dv, dv + n * 9, dv + n * 12, (int32_t)n, stream);
     (void)rt_free(d);
+    if (last_error == RT_OK) m.replace(std::move(tris), true);  // (the host tree is rebuilt when it is next needed)
 }
 
 void Scene::refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream)

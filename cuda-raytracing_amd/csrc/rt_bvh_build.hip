@@ -1092,6 +1092,9 @@ extern "C" int rt_scene_rebuild_mesh_device(RtScene* s, int32_t mesh_index, cons
     RebuildResult* d_result = (RebuildResult*)(level_cursor + (kMaxLevels + 2));
     static_assert(sizeof(RebuildResult) + 2 * (kMaxLevels + 2) * sizeof(int32_t) <= kExtraBytes, "scratch of the rebuild");
     RebuildResult res;
+    // From here on kernels that use the shared build arena and write the scene's arrays are in flight on `stream`: an error
+    // return must not release the arena (g_arena_mutex) to another build, nor hand the scene back, before they have finished.
+    struct DrainOnError { hipStream_t s; bool armed; ~DrainOnError() { if (armed) (void)hipStreamSynchronize(s); } } drain{stream, true};
     {
         // the mesh's part of the scene arrays starts from zero (what rt_scene_upload leaves in unused records), tri_id from -1
         ClearRanges c;
@@ -1119,6 +1122,7 @@ extern "C" int rt_scene_rebuild_mesh_device(RtScene* s, int32_t mesh_index, cons
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemcpyAsync(&res, d_result, sizeof res, hipMemcpyDeviceToHost, stream));
     RT_HIP(hipStreamSynchronize(stream));
+    drain.armed = false;
     if (debug) fprintf(stderr, "rebuild timing: build %.3f ms, emit into the scene %.3f ms\n", t1 - t0, now() - t1);
     // ---- host bookkeeping: what rt_scene_upload records for a mesh ----
     rf.num_triangles = n; rf.num_slots = n; rf.levels = b.st.levels;

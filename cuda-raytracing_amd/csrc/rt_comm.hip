@@ -56,6 +56,17 @@ struct Rccl {
 };
 
 thread_local std::string g_comm_error;
+// the same text for readers on OTHER threads (a watchdog that reports where a stuck main thread last failed): the most recent
+// RT_E_COMM of any thread, behind a mutex; rt_comm_last_error_any() copies it into the caller's thread-local buffer
+std::mutex g_comm_error_any_mutex;
+std::string g_comm_error_any;
+thread_local std::string g_comm_error_any_copy;
+void set_comm_error(const std::string& text)
+{
+    g_comm_error = text;
+    std::lock_guard<std::mutex> lock(g_comm_error_any_mutex);
+    g_comm_error_any = text;
+}
 
 Rccl* rccl()
 {
@@ -97,13 +108,13 @@ Rccl* rccl()
         r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
         r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
     });
-    if (!r.lib) { g_comm_error = r.load_error; return nullptr; }
+    if (!r.lib) { set_comm_error(r.load_error); return nullptr; }
     return &r;
 }
 
 int comm_fail(Rccl* r, ncclResult_t e, const char* what)
 {
-    g_comm_error = std::string(what) + ": " + (r ? r->GetErrorString(e) : "?");
+    set_comm_error(std::string(what) + ": " + (r ? r->GetErrorString(e) : "?"));
     return RT_E_COMM;
 }
 
@@ -190,6 +201,12 @@ int render_local(RtScene* scene, RtComm* c, const RtCameraParams* cam, const RtR
 extern "C" {
 
 const char* rt_comm_last_error(void) { return g_comm_error.c_str(); }
+const char* rt_comm_last_error_any(void)
+{
+    std::lock_guard<std::mutex> lock(g_comm_error_any_mutex);
+    g_comm_error_any_copy = g_comm_error_any;
+    return g_comm_error_any_copy.c_str();
+}
 
 int rt_comm_available(int32_t* rccl_version)
 {

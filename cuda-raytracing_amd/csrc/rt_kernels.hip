@@ -469,12 +469,24 @@ __device__ __forceinline__ uint32_t shade(const RenderParams& p, const Hit& hit)
            ((uint32_t)to_u8(illumination * c.z * 255.0f) << 16);
 }
 
+// pixel of thread `tid` in the 16x16 tile at (x0, y0): a wave64 is an 8x8-pixel block (neighbouring rays walk the same nodes:
+// L1 hits, little divergence).  (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
+__device__ __forceinline__ void pixel_of(const RenderParams& p, int tid, int x0, int y0, int& x, int& ly, int& y)
+{
+    const int wave = tid >> 6, lane = tid & 63;
+    x = x0 + (wave & 1) * 8 + (lane & 7);
+    ly = y0 + (wave >> 1) * 8 + (lane >> 3);
+    y = ly;                                                     // stripes: local row -> frame row (the identity for one rank)
+    if (p.num_ranks != 1) y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
+}
+
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
-// (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
 template <bool DEBUG, bool PROF, bool COUNT = false, bool SPILL = true>
-__device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x, int ly, int y, lds_int* lds_column,
+__device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x0, int y0, lds_int* lds_base, lds_int*& lds_column,
                                              int* iters = nullptr)
 {
+    int x, ly, y;
+    pixel_of(p, (int)(lds_column - lds_base), x0, y0, x, ly, y);
     const V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     const V3 dir = camera_direction(f, (float)x, (float)y);
 
@@ -487,6 +499,12 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
         trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, SPILL>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
 
+    // The pixel's coordinates are not kept across the traversal (three registers in a kernel that has none to spare: they
+    // were spilled to scratch): they are derived again from the one per-thread value the loop keeps anyway, the address of
+    // the lane's LDS stack column.  (The empty asm hides that address's origin from the optimiser, which would otherwise
+    // recognise the recomputation and keep the first copies alive.)
+    asm volatile("" : "+v"(lds_column));
+    pixel_of(p, (int)(lds_column - lds_base), x0, y0, x, ly, y);
     const uint32_t px = shade(p, hit);
     uint8_t* out = f.img + (size_t)ly * p.pitch + 3 * (size_t)x;
     out[0] = (uint8_t)px; out[1] = (uint8_t)(px >> 8); out[2] = (uint8_t)(px >> 16);
@@ -536,17 +554,18 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
     }
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
 
-    // a wave64 is an 8x8-pixel block: neighbouring rays walk the same nodes (L1 hits, little divergence)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int x = tx * kTile + (wave & 1) * 8 + (lane & 7);
-    const int ly = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     unsigned long long t_start = 0;
     if (p.trace) t_start = wall_clock64();
-    if (x < p.width && ly < p.local_rows) {
-        // stripes: local row -> frame row (identity when num_ranks == 1)
-        const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
-        render_pixel<DEBUG, PROF, ORDERED, SPILL>(p, p.frames[frame], x, ly, y, (lds_int*)lds_stack + tid, &iters);
+    // the thread's index lives on as the address of its LDS stack column only (see render_pixel)
+    lds_int* column = (lds_int*)lds_stack + threadIdx.x;
+    {
+        int x, ly, y;
+        pixel_of(p, (int)threadIdx.x, tx * kTile, ty * kTile, x, ly, y);
+        if (x < p.width && ly < p.local_rows)
+            render_pixel<DEBUG, PROF, ORDERED, SPILL>(p, p.frames[frame], tx * kTile, ty * kTile, (lds_int*)lds_stack, column, &iters);
     }
+    asm volatile("" : "+v"(column));
+    const int tid = (int)(column - (lds_int*)lds_stack), wave = tid >> 6, lane = tid & 63;
     if constexpr (ORDERED) {
         // cost of the tile = loop iterations of its longest lane: deterministic, unlike a lifetime, which also measures
         // how full the chip was while the workgroup ran
@@ -1795,6 +1814,14 @@ int rt_scene_info(const RtScene* s, size_t* device_bytes, int32_t* max_stack)
     if (!s) return RT_E_INVALID;
     if (device_bytes) *device_bytes = s->device_bytes;
     if (max_stack) *max_stack = s->max_stack;
+    return RT_OK;
+}
+
+int rt_scene_mesh_capacity(const RtScene* s, int32_t mesh_index, int32_t* max_triangles)
+{
+    if (!s || !max_triangles || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size()) return RT_E_INVALID;
+    const RtScene::MeshRefit& rf = s->mesh_refit[(size_t)mesh_index];
+    *max_triangles = std::min(rf.slot_cap, rf.int_cap + 1);
     return RT_OK;
 }
 

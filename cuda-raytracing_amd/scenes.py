@@ -91,25 +91,20 @@ def write_atrium_obj(path, seed=4321, cols_x=6, cols_y=10, col_seg=48, col_rings
     Written as independent grids in one OBJ (v/vt indices are global).
     """
     rng = np.random.default_rng(seed)
-    verts, uvs, faces = [], [], []
+    verts, uvs, faces = [], [], []                                 # per grid: [n, 3] positions, [n, 2] uvs, [m, 3] 1-based indices
 
     def add_grid(P, U, V, flip):
         rows, cols = P.shape[0] - 1, P.shape[1] - 1
-        base = len(verts)
-        verts.extend(P.reshape(-1, 3).tolist())
-        uvs.extend(np.stack([U, V], -1).reshape(-1, 2).tolist())
-        for j in range(rows):
-            for i in range(cols):
-                a = base + j * (cols + 1) + i + 1
-                b = a + 1
-                c = a + cols + 1
-                d = c + 1
-                if flip:
-                    faces.append((a, b, c))
-                    faces.append((b, d, c))
-                else:
-                    faces.append((a, c, b))
-                    faces.append((b, c, d))
+        base = sum(len(v) for v in verts)
+        verts.append(P.reshape(-1, 3))
+        uvs.append(np.stack([U, V], -1).reshape(-1, 2))
+        jj, ii = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+        a = (base + jj * (cols + 1) + ii + 1).ravel()
+        b, c = a + 1, a + cols + 1
+        d = c + 1
+        # two triangles per quad, quads row by row: (a b c)(b d c) when flipped, (a c b)(b c d) otherwise
+        quad = np.stack([a, b, c, b, d, c] if flip else [a, c, b, b, c, d], -1)
+        faces.append(quad.reshape(-1, 3))
 
     LX, LY, LZ = 12.0, 20.0, 8.0
     s = np.linspace(0, 1, wall_div + 1)
@@ -137,13 +132,16 @@ def write_atrium_obj(path, seed=4321, cols_x=6, cols_y=10, col_seg=48, col_rings
             P = np.stack([x0 + rad * np.cos(A), y0 + rad * np.sin(A), H * LZ], -1)
             add_grid(P, A / (2 * np.pi), H, flip=True)
 
-    out = ["# synthetic atrium\n"]
-    out.extend("v %.6f %.6f %.6f\n" % tuple(v) for v in verts)
-    out.extend("vt %.6f %.6f\n" % tuple(t) for t in uvs)
-    out.extend("f %d/%d %d/%d %d/%d\n" % (f[0], f[0], f[1], f[1], f[2], f[2]) for f in faces)
+    verts, uvs, faces = np.concatenate(verts), np.concatenate(uvs), np.concatenate(faces)
     tmp = path + ".tmp%d" % os.getpid()
     with open(tmp, "w") as f:
-        f.writelines(out)
+        f.write("# synthetic atrium\n")
+        # (text in pieces: the 4 M-triangle scale of workload c6 would otherwise hold every line as a Python string at once)
+        for fmt, rows in (("v %.6f %.6f %.6f\n", verts.tolist()), ("vt %.6f %.6f\n", uvs.tolist())):
+            for k in range(0, len(rows), 1 << 18):
+                f.write("".join(fmt % tuple(r) for r in rows[k:k + (1 << 18)]))
+        for k in range(0, len(faces), 1 << 18):
+            f.write("".join("f %d/%d %d/%d %d/%d\n" % (q[0], q[0], q[1], q[1], q[2], q[2]) for q in faces[k:k + (1 << 18)].tolist()))
     os.replace(tmp, path)
     return len(faces)
 
@@ -169,4 +167,7 @@ C4 = dict(width=3840, height=2160, D=D_REF, albedo=(0.8, 0.8, 0.7),
 C3 = dict(width=1920, height=1080, D=D_REF, albedo=(0.9, 0.5, 0.2), n_tris=69936, roughness=0.05, metallic=0.4,
           spp=64, bounces=8, lighting=1)
 C5 = dict(C3, width=7680, height=4320)
-WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5}
+# c6: the HBM regime.  The atrium generator at 16 x the triangle count of c4 (4 073 472 triangles: 395 MB of 64-B records, more
+# than the 256 MiB Infinity Cache; most triangles are smaller than a pixel at 4K), same camera, 1 primary ray per pixel.
+C6 = dict(C4, spp=1, atrium=dict(col_seg=192, col_rings=100, wall_div=384), n_tris=4073472)
+WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5, "c6": C6}

@@ -152,36 +152,86 @@ class StripePipeline:
         self.frames_done = 0
         self.rendered = self.free = None
         self.used = [False, False]
+        self.timing = False                                     # stage_timing(True): every group records its stage boundaries
+        self._marks = []                                        # per timed group: five events (streams) or five clock readings (inline)
         if comm_stream is not None:
             import torch
             self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
 
+    def stage_timing(self, on):
+        """Per-group stage times for stage_times(): with streams, timing events at the five boundaries of a group (before the
+        wait for its buffer set, render start, render end = exchange may start, exchange end, un-stripe end); inline, the
+        host clock at the same places.  Events cost a few microseconds per group and nothing waits for them."""
+        self.timing = bool(on)
+        if on:
+            self._marks = []
+
     def step(self, i):
         b = i & 1
         if self.comm is None:
+            import time
+            t = [time.perf_counter()] * 2                       # (no buffer wait inline: everything is synchronous)
             self.render_fn(b)
+            t.append(time.perf_counter())
             self.exchange_fn(b)
+            t.append(time.perf_counter())
             if self.assembles:
                 self.unstripe_fn(b)
+            t.append(time.perf_counter())
+            if self.timing:
+                self._marks.append(t)
         else:
             import torch
             cs = self.compute[b] if self.compute is not None else torch.cuda.current_stream()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.timing else None
+            if ev:
+                ev[0].record(cs)                                # completes when the stream has nothing left but this group
             if self.used[b]:
                 cs.wait_event(self.free[b])            # group i - 2 has left buffer set b
             with torch.cuda.stream(cs):
+                if ev:
+                    ev[1].record(cs)
                 self.render_fn(b)
                 self.rendered[b].record(cs)
+                if ev:
+                    ev[2].record(cs)
             self.comm.wait_event(self.rendered[b])
             with torch.cuda.stream(self.comm):
                 self.exchange_fn(b)
+                if ev:
+                    ev[3].record(self.comm)
                 if self.assembles:
                     self.unstripe_fn(b)
                 self.free[b].record(self.comm)
+                if ev:
+                    ev[4].record(self.comm)
             self.used[b] = True
+            if ev:
+                self._marks.append(ev)
         self.frames_done += 1
 
     def drain(self):
         """Host wait for everything issued so far."""
         if self.comm is not None:
             self.comm.synchronize()
+
+    def stage_times(self):
+        """Mean milliseconds per timed group of each stage, after drain():
+        wait_for_buffer (the compute stream idle until group i - 2 had left the buffer set), render, exchange (from the end
+        of the render: includes any wait for the comm stream to finish the previous group), unstripe, and group_span (first
+        boundary to last: wait + render + exchange + unstripe = span by construction)."""
+        if not self._marks:
+            return None
+        if self.comm is None:
+            d = [[(m[k + 1] - m[k]) * 1e3 for k in range(4)] for m in self._marks]
+        else:
+            self.drain()
+            for m in self._marks:
+                m[4].synchronize()
+            d = [[m[k].elapsed_time(m[k + 1]) for k in range(4)] for m in self._marks]
+        n = float(len(d))
+        mean = [sum(row[k] for row in d) / n for k in range(4)]
+        return {"groups_timed": len(d), "wait_for_buffer_ms": round(mean[0], 4), "render_ms_per_group": round(mean[1], 4),
+                "exchange_ms_per_group": round(mean[2], 4), "unstripe_ms_per_group": round(mean[3], 4),
+                "group_span_ms": round(sum(mean), 4)}

@@ -148,6 +148,9 @@ int rt_scene_refit_mesh_device(RtScene *scene, int32_t mesh_index, const float *
 int rt_scene_destroy(RtScene *scene);
 /* bytes of device memory the scene holds, and the traversal-stack depth it needs */
 int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);
+/* the largest triangle count rt_scene_rebuild_mesh_device accepts for this mesh (= the count it was uploaded with: its part of
+ * the record arrays has room for any tree over that many triangles) */
+int rt_scene_mesh_capacity(const RtScene *scene, int32_t mesh_index, int32_t *max_triangles);
 
 /* Device-resident rebuild of one mesh of an uploaded scene: a NEW tree (the reference's, node for node, as rt_bvh_build gives
  * it) over the n triangles in DEVICE arrays d_vertices [n][3][3], d_normals [n][3] and d_uvs [n][3][2] (NULL = all zero), n at
@@ -156,7 +159,10 @@ int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack
  * without a host copy of vertices, tree or records: for a mesh whose motion has outgrown refitting, or whose triangles change.
  * Ordered on `stream` like rt_scene_refit_mesh_device; the call returns when the new tree is in place (it reads a few words
  * of build state back while it runs).  Replaces MeshPrimitive::build_bvh + Scene::upload_to_device (MeshPrimitive.cpp:38-56,
- * Scene.cpp:25-65) for that mesh. */
+ * Scene.cpp:25-65) for that mesh.
+ * Errors: RT_E_INVALID for a bad index or more triangles than rt_scene_mesh_capacity() -- nothing has been touched then.  A
+ * HIP error after the rebuild has started (the mesh's records are cleared first) returns once `stream` has drained, and
+ * leaves the mesh WITHOUT a valid tree: do not render it until a later rebuild (or a fresh rt_scene_upload) has succeeded. */
 int rt_scene_rebuild_mesh_device(RtScene *scene, int32_t mesh_index, const float *d_vertices, const float *d_normals,
                                  const float *d_uvs, int32_t num_triangles, void *stream);
 /* tests: copies one of the scene's device arrays to the host (which: 0 records [float4], 1 tri_uv, 2 tri_id, 3 leaf_count,
@@ -242,6 +248,9 @@ typedef struct RtComm RtComm;
 #define RT_COMM_ID_BYTES 128
 int rt_comm_available(int32_t *rccl_version);            /* RT_OK when RCCL could be loaded */
 const char *rt_comm_last_error(void);                    /* text of the calling thread's last RT_E_COMM */
+/* text of the most recent RT_E_COMM of ANY thread of the process (for a watchdog thread that reports on a main thread stuck
+ * inside a collective); the pointer is the calling thread's own copy, valid until its next call */
+const char *rt_comm_last_error_any(void);
 int rt_comm_unique_id(uint8_t *id /* [RT_COMM_ID_BYTES] */);
 int rt_comm_init_rank(const uint8_t *id, int32_t rank, int32_t num_ranks, RtComm **out);   /* on the current device */
 int rt_comm_init_all(const int32_t *devices, int32_t num_devices, RtComm **comms);

@@ -33,3 +33,31 @@ def test_single_gpu_run_fails_loudly_without_gpu():
         pytest.skip("this check is for the GPU-less container")
     r = _run("--steps", "2", "--warmup", "1")
     assert r.returncode != 0 and r.stdout.strip() == "" and "needs a GPU" in r.stderr
+
+
+def test_timed_region_aggregation():
+    """The one driver-timed number: a K-step region that fits one launch is measured nine times and the line is priced with
+    the median (bench.aggregate_repeats); a longer run stays one measurement."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.aggregate_repeats([0.0030, 0.0027, 0.0100, 0.0026, 0.0028, 0.0027, 0.0029, 0.0027, 0.0031], 20)
+    assert a["dt"] == 0.0028 and a["fields"]["repeats"] == 9
+    assert a["fields"]["ms_per_step_min"] == 0.13 and a["fields"]["ms_per_step_max"] == 0.5
+    assert "median of 9" in a["fields"]["timed_region"]
+    b = bench.aggregate_repeats([0.5], 960)
+    assert b["dt"] == 0.5 and b["fields"] == {"repeats": 1}
+    c = bench.aggregate_repeats([0.004, 0.002], 10)                     # (an even count: mean of the middle two)
+    assert abs(c["dt"] - 0.003) < 1e-12
+    assert bench.REPEATS_SHORT == 9
+
+
+def test_multi_rank_report_fields():
+    """What an N > 1 result line says about its ranks (bench.multi_rank_report): the per-rank stage times as given, the
+    stripe-share imbalance = max / mean of the ranks' render time, and the RCCL facts that can be known."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ranks = [dict(rank=0, groups_timed=4, wait_for_buffer_ms=0.1, render_ms_per_group=0.6, exchange_ms_per_group=0.2, unstripe_ms_per_group=0.05, group_span_ms=0.95),
+             dict(rank=1, groups_timed=4, wait_for_buffer_ms=0.0, render_ms_per_group=0.4, exchange_ms_per_group=0.3, unstripe_ms_per_group=0.0, group_span_ms=0.7)]
+    r = bench.multi_rank_report(ranks, None)
+    assert r["per_rank"] == ranks and r["stripe_share_imbalance"] == 1.2
+    assert set(r["rccl"]) >= {"version", "through", "NCCL_MAX_NCHANNELS"} and r["rccl"]["through"] == "torch.distributed"

@@ -106,3 +106,44 @@ def test_c5_full_size_8k_64spp_tiled(rt, orc, scenes, blob70k):
     _check_bands(so, scenes, got, W, H, pose, wl["spp"], wl["bounces"], wl["lighting"], (8, 2160, H - 8), 8)
     so.close()
     assert np.array_equal(_stitched(rt, sp, cam, W, H), got["img"])
+
+
+def test_c6_four_million_triangles_band_parity(rt, orc, scenes, atrium_c6):
+    """Workload c6 (bench.py --workload c6): the atrium generator at 4 073 472 triangles -- 395 MB of 64-byte records, more than
+    the 256 MiB Infinity Cache -- at 3840x2160, one primary ray per pixel, camera inside.  The tree is built on the GPU at
+    upload (the library-scan path of the build, above a million triangles); three 8-row bands of the frame against the
+    oracle (whose builder is the reference's) on every plane: RGB, hit ids, node pops, AABB tests, triangle tests, inside
+    hits; the production kernel's frame and hit ids equal the instrumented kernel's over the whole frame; and a frame with
+    two rough mirror bounces (rays that scatter over the whole scene) against the oracle on one band."""
+    wl = scenes.C6
+    W, H, pose = wl["width"], wl["height"], wl["cam_pose"]
+    K = scenes.scaled_K(W)
+    mesh = rt.Mesh.load_obj(atrium_c6, gpu_build=True)
+    assert mesh.num_triangles == wl["n_tris"]
+    sp = rt.Scene()
+    sp.add_material(wl["albedo"], roughness=0.3, metallic=1.0)
+    sp.add_mesh(mesh)
+    sp.add_mesh_instance(0, 0)
+    sp.upload_to_device()
+    assert sp.info()["device_bytes"] > 500e6 and sp.info()["max_stack"] > 17         # (records alone: 385 MB; the stack spills)
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose(pose)
+    dbg = rt.render_debug(sp, cam)
+    assert np.array_equal(rt.render(sp, cam), dbg["img"])
+    ids = rt.render_ids(sp, cam)
+    assert np.array_equal(ids["hit_tri"], dbg["hit_tri"]) and np.array_equal(ids["hit_inst"], dbg["hit_inst"])
+    assert (dbg["hit_tri"] >= 0).mean() > 0.999 and len(np.unique(dbg["hit_tri"])) > 300000   # (372 347 different triangles are visible)
+    o = orc.oracle()
+    so = orc.OracleScene(o)
+    so.add_material(wl["albedo"], roughness=0.3, metallic=1.0)
+    so.add_mesh(o.obj_load(atrium_c6))
+    so.add_instance(0, 0)
+    for y0 in (64, 1076, H - 72):
+        ref = so.render(W, H, K, scenes.D_REF, pose, y0=y0, y1=y0 + 8, threads=32)
+        for k in ("img", "hit_inst", "hit_tri", "pops", "aabb", "tris", "inside"):
+            assert np.array_equal(dbg[k][y0:y0 + 8], ref[k][y0:y0 + 8]), (k, y0)
+    cam.set_options(1, 2, 0)
+    got = rt.render_ex(sp, cam)
+    _check_bands(so, scenes, got, W, H, pose, 1, 2, 0, (1500,), 8)
+    so.close()
+    sp.close()

@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C-ABI, driven by the host C++ API) against the CPU oracle
 on the same scene, camera and pixels.  Bit-exact: RGB bytes, hit (instance, triangle) ids,
 node-pop / AABB-test / triangle-test / inside-hit counts per pixel."""
+import ctypes as C
 import json
 import os
 
@@ -554,8 +555,27 @@ def test_device_resident_rebuild_of_a_mesh(rt, orc, scenes, blob5k):
         so, om = oracle_scene(tris)
         check(sp, so, name)
         so.close()
-    with pytest.raises(rt.RtError):
-        sp.rebuild_mesh(0, np.concatenate([rest, rest[:10]]))   # more triangles than the mesh was uploaded with
+    # more triangles than the mesh was uploaded with do not fit its part of the device arrays: the C-ABI call refuses them
+    # untouched, and Scene::rebuild_mesh uploads the scene again -- host and device describe the same mesh afterwards
+    # (the host mesh used to change first and a refused device call left the two apart)
+    bigger = np.concatenate([rest, scrambled(2)[:10]])
+    h = rt.libs()[0]
+    cap = C.c_int32(0)
+    assert h.rt_scene_mesh_capacity(sp.device_handle, 0, C.byref(cap)) == 0 and cap.value == len(rest)
+    dummy = rt.DeviceBuffer(width_bytes=64, height=1)           # (never read: the count is refused first)
+    assert h.rt_scene_rebuild_mesh_device(sp.device_handle, 0, dummy.ptr, dummy.ptr, None, len(bigger), None) == -1      # RT_E_INVALID
+    sp.rebuild_mesh(0, rest)
+    sp.rebuild_mesh(0, bigger)
+    so, om = oracle_scene(bigger)
+    check(sp, so, "more triangles than at upload")
+    assert h.rt_scene_mesh_capacity(sp.device_handle, 0, C.byref(cap)) == 0 and cap.value == len(bigger)
+    b2 = bigger.copy()
+    b2[:, :9].reshape(-1, 3, 3)[..., 0] += np.float32(0.01)
+    b2 = with_normals(b2)
+    sp.refit_mesh(0, b2)                                        # (the count the host holds is the count the device holds)
+    o.mesh_refit(om, b2)
+    check(sp, so, "refit after growing")
+    so.close()
     sp.rebuild_mesh(0, rest)                                    # and back: the first frame again
     so, om = oracle_scene(rest)
     check(sp, so, "back to rest")

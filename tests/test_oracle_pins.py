@@ -172,15 +172,60 @@ def test_extension_degenerates_to_pinned_frames(orc, scenes, blob5k, pins):
 
 @pytest.mark.parametrize("cam", ["far", "mid", "near"])
 def test_c2_frame_pins(orc, scenes, blob70k, pins, cam):
-    """BASELINE.json configs[1] at full size: oracle frame hash == the hash SURVEY.md 8(d) recorded
-    from the reference's render() on the byte-identical OBJ."""
+    """BASELINE.json configs[1] at full size: oracle frame hash == the hash SURVEY.md 8(d) recorded from the reference's
+    render() on the byte-identical OBJ, the frame's visit statistics == the ones SURVEY.md section 6 printed from the same
+    reference run (node pops, AABB tests and triangle tests per ray, deepest stack, coverage -- everything the survey wrote
+    down about cast_ray's control flow), and the oracle's own planes == their frozen hashes (self-regression: the oracle
+    and the kernels are compared with each other on every run, this keeps the pair from drifting together)."""
     import scene_defs as sd
     assert hashlib.sha256(open(blob70k, "rb").read()).hexdigest() == pins["frames"]["blob70k_obj_sha256"]
     s = sd.blob_scene(scenes, blob70k).build_oracle(orc)
     c = scenes.C2
-    out = s.render(c["width"], c["height"], scenes.scaled_K(c["width"]), c["D"], scenes.C2_CAMERAS[cam], planes=False, threads=8)
+    out = s.render(c["width"], c["height"], scenes.scaled_K(c["width"]), c["D"], scenes.C2_CAMERAS[cam], planes=True, threads=8)
     assert orc.fnv1a64(out["img"]) == pins["frames"]["C2_%s_1920x1080" % cam]["fnv1a64"]
+    st, want = out["stats"], pins["survey_c2_stats"][cam]
+    rays = st["rays"]
+    assert rays == c["width"] * c["height"]
+    assert round(st["pops"] / rays, 2) == want["pops_per_ray"]
+    assert round(st["aabb"] / rays, 2) == want["aabb_per_ray"]
+    assert round(st["tris"] / rays, 2) == want["tris_per_ray"]
+    assert st["max_stack"] == want["max_stack"]
+    assert round(100.0 * st["hits"] / rays, 1) == want["coverage_pct"]
+    # the planes add up to the frame totals, and equal their frozen hashes
+    assert int(out["pops"].sum()) == st["pops"] and int(out["aabb"].sum()) == st["aabb"] and int(out["tris"].sum()) == st["tris"]
+    _check_frozen_planes(out, pins, "C2_%s_1920x1080" % cam)
     s.close()
+
+
+def _check_frozen_planes(out, pins, name):
+    frozen = pins["oracle_planes_self_regression"]["frames"][name]
+    for k in ("hit_inst", "hit_tri", "pops", "aabb", "tris", "inside"):
+        assert hashlib.sha256(np.ascontiguousarray(out[k], np.int32).tobytes()).hexdigest() == frozen[k], \
+            "%s: the oracle's %s plane changed (tests/golden/make_plane_pins.py re-freezes it -- only after the change is understood)" % (name, k)
+    assert hashlib.sha256(out["img"].tobytes()).hexdigest() == frozen["img_sha256"], name
+
+
+def test_frozen_oracle_planes_small_scenes(orc, scenes, blob70k, blob5k, pins):
+    """Self-regression pins (NOT reference-derived) of the oracle's hit-id and visit-count planes: C1 and the multi-instance
+    textured scene (rotated, non-uniformly scaled instances, two meshes, a texture)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_plane_pins", os.path.join(GOLDEN, "make_plane_pins.py"))
+    mpp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mpp)
+    import scene_defs as sd
+    for name, (desc, W, H, K, pose) in mpp.cases(scenes, sd, blob70k, blob5k).items():
+        if name.startswith("C2_"):
+            continue                                                    # (full size: test_c2_frame_pins)
+        s = desc.build_oracle(orc)
+        _check_frozen_planes(s.render(W, H, K, scenes.D_REF, pose, threads=4), pins, name)
+        s.close()
+
+
+def test_blob5k_bvh_stats_survey(oracle, blob5k, pins):
+    """SURVEY.md line 255: the reference builder on the 5 000-triangle mesh gives 9 197 nodes, 4 599 leaves, depth 12."""
+    st = oracle.mesh_stats(oracle.obj_load(blob5k))
+    p = pins["survey_c2_stats"]["blob5k_bvh"]
+    assert (st["nodes"], st["leaves"], st["max_depth"]) == (p["nodes"], p["leaves"], p["print_stats_max_depth"])
 
 
 def test_blob70k_bvh_stats(orc, oracle, blob70k, pins):

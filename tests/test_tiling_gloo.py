@@ -79,10 +79,20 @@ def _pipeline_worker(rank, world, port, blob, H, W, stripe, nframes, out_path):
 
     ex = tiling.TorchExchange(rank, world)
     pipe = tiling.StripePipeline(render_fn, lambda b: ex.to_root(local[b], gathered[b], 0), unstripe_fn, assembles=rank == 0)
+    pipe.stage_timing(True)
     for i in range(nframes):
         pipe.step(i)
     pipe.drain()
     assert pipe.frames_done == nframes
+    # what an N > 1 bench line says about where a rank's time went (bench.multi_rank_report prints these per rank)
+    st = pipe.stage_times()
+    assert st["groups_timed"] == nframes and st["render_ms_per_group"] > 0 and st["exchange_ms_per_group"] > 0
+    assert st["wait_for_buffer_ms"] >= 0 and st["unstripe_ms_per_group"] >= 0 and (rank != 0 or st["unstripe_ms_per_group"] > 0)
+    parts = st["wait_for_buffer_ms"] + st["render_ms_per_group"] + st["exchange_ms_per_group"] + st["unstripe_ms_per_group"]
+    assert parts <= st["group_span_ms"] + 1e-3
+    box = [None] * world
+    dist.all_gather_object(box, dict(st, rank=rank))
+    assert [b["rank"] for b in box] == list(range(world))
     if rank == 0:
         ok = len(frames) == nframes
         for f in range(nframes):

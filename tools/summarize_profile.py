@@ -2,7 +2,7 @@
 """Turns a tools/profile_bench.sh output directory into the committed summaries under profiles/:
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
   profiles/<tag>_bench_line.json    the line bench.py printed under the profiler
-  profiles/r03_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
+  profiles/r04_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
                                     hash of the kernel source + build flags they were taken from (bench.py checks it)
 A frame = width x height x spp primary rays.  A dispatch of G work-items renders G / (tiles * 256 * spp) frames (one 256-thread
 workgroup per 16x16 tile per frame of the batch, or per sample of the frame), so counters are summed over every dispatch of
@@ -26,6 +26,8 @@ W, H, key = cfg["width"], cfg["height"], cfg["key"]
 kernel = bench_line["roofline"]["kernel"].replace(",", ", ")
 if kernel == "render_kernel<false, false>":                 # (lines printed before the ORDERED template parameter existed)
     kernel = "render_kernel<false, false, false>"
+if kernel.startswith("render_kernel<") and kernel.count(",") == 2:      # (lines printed before the SPILL parameter existed: either form)
+    kernel = kernel[:-1] + ", "
 tiles = ((W + 15) // 16) * ((H + 15) // 16)
 per_frame_items = tiles * 256 * (cfg["spp"] if "render_ex" in kernel else 1)
 # render_ex_kernel<.., PX> (4 and more samples per pixel): a launch covers up to 64 samples of every pixel, a frame is
@@ -77,7 +79,7 @@ if kt:
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-tp = os.path.join(dst, "r03_counters.json")
+tp = os.path.join(dst, "r04_counters.json")
 out = json.load(open(tp)) if os.path.exists(tp) else {}
 out[key] = entry
 json.dump(out, open(tp, "w"), indent=1, sort_keys=True)
