@@ -323,15 +323,34 @@ def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_fra
         out["profile_stale"] = False
         n = frames_per_launch * share
         valu = e["valu_insts_per_frame"] * n / sec / 1e9
-        out.update({"bound": "valu_issue", "achieved": round(valu, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
-                    "frac": round(valu / VALU_PEAK_GINST, 4),
+        l1 = e["tcp_accesses_per_frame"] * 64 * n / sec / 1e9 if e.get("tcp_accesses_per_frame") else None
+        hbm = e["hbm_bytes_per_frame"] * n / sec / 1e9 if e.get("hbm_bytes_per_frame") is not None else None
+        # the bound = whichever unit is busiest (fractions of: VALU issue slots, L1 accesses, HBM bytes)
+        fr = {"valu_issue": valu / VALU_PEAK_GINST}
+        if l1 is not None:
+            fr["l1"] = l1 / L1_PEAK_GBS
+        if hbm is not None:
+            fr["hbm"] = hbm / HBM_PEAK_GBS
+        bound = max(fr, key=fr.get)
+        ach, peak, unit = {"valu_issue": (valu, VALU_PEAK_GINST, "G wave-instr/s"), "l1": (l1, L1_PEAK_GBS, "GB/s"), "hbm": (hbm, HBM_PEAK_GBS, "GB/s")}[bound]
+        out.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
                     "traffic": int(e["hbm_bytes_per_frame"] * n) if e.get("hbm_bytes_per_frame") is not None else None,
+                    "fractions": {k: round(v, 4) for k, v in fr.items()},
                     "lanes_active_per_valu": e.get("lanes_active_per_valu"),
                     "useful_lane_slot_frac": round(valu / VALU_PEAK_GINST * e["lanes_active_per_valu"] / 64.0, 4) if e.get("lanes_active_per_valu") else None,
-                    "l1_bw_frac": round(e["tcp_accesses_per_frame"] * 64 * n / sec / 1e9 / L1_PEAK_GBS, 4) if e.get("tcp_accesses_per_frame") else None,
-                    "hbm_physical_frac": round(e["hbm_bytes_per_frame"] * n / sec / 1e9 / HBM_PEAK_GBS, 5) if e.get("hbm_bytes_per_frame") is not None else None,
+                    "valu_issue_frac": round(valu / VALU_PEAK_GINST, 4),
+                    "l1_bw_frac": round(l1 / L1_PEAK_GBS, 4) if l1 is not None else None,
+                    "hbm_physical_frac": round(hbm / HBM_PEAK_GBS, 5) if hbm is not None else None,
                     "profile": e.get("tag"),
                     "peaks": "VALU: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; L1: 256 CUs x 64 B/clk; HBM 8 TB/s"})
+        if hbm is not None:
+            # FETCH_SIZE / WRITE_SIZE count what leaves the L2s (Infinity Cache hits included): an upper bound on HBM bytes.
+            # No x2 on FETCH_SIZE here: tools/fetch_calibration.sh measures 0.99 bytes reported per byte for this kernel's
+            # access pattern (a gather of 64-B records; the guide's x2 is for 16 B-per-lane streaming reads).
+            out["hbm"] = {"physical_GBs": round(hbm, 1), "frac_of_8TBs": round(hbm / HBM_PEAK_GBS, 5), "frac_of_6.29TBs": round(hbm / 6290.0, 5),
+                          "fetch_bytes_per_launch": int(e.get("fetch_bytes_per_frame", 0) * n), "write_bytes_per_launch": int(e.get("write_bytes_per_frame", 0) * n),
+                          "physical_over_algorithmic": round(e["hbm_bytes_per_frame"] / alg_bytes_per_frame, 5) if alg_bytes_per_frame else None,
+                          "counted": "L2 misses towards the fabric (FETCH_SIZE + WRITE_SIZE, Infinity Cache hits included): an upper bound on HBM traffic"}
     if alg_bytes_per_frame is not None:
         a = alg_bytes_per_frame * frames_per_launch * share / sec / 1e9
         out["hbm_algorithmic"] = {"achieved_GBs": round(a, 1), "frac_of_8TBs": round(a / HBM_PEAK_GBS, 4), "bytes_per_launch": int(alg_bytes_per_frame * frames_per_launch * share),

@@ -402,14 +402,18 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 #ifndef RT_OCTANTS
 #define RT_OCTANTS 1
 #endif
-template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false>
+// OCTANTS = false keeps one loop: the bounce / shadow kernels of the extension renderer carry their path state across every
+// cast in registers they do not have (spilled to scratch); nine loops per cast site made that worse (c3 24.9 ms against
+// 23.7 ms with the generic loop alone, profiles/r04_experiments/octants_in_extension_kernels.log), while the samples-only
+// kernel, which carries nothing, gains like the primary kernel (c4 at 16 spp: 8.27 against 8.50 ms).
+template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
                                                int* pops = nullptr)
 {
     const MeshRay r = to_mesh_space(in, org, dir);
     int oct = -1;
-    if constexpr (RT_OCTANTS && !PROF) {
+    if constexpr (RT_OCTANTS && !PROF && OCTANTS) {
         const float inf = __int_as_float(0x7f800000);
         const bool usable = fabsf(r.dinv.x) < inf && fabsf(r.dinv.y) < inf && fabsf(r.dinv.z) < inf &&
                             r.dinv.x != 0.0f && r.dinv.y != 0.0f && r.dinv.z != 0.0f &&
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 // semantics are defined in DESIGN.md section 7 (and restated by the test oracle); with spp = 1, bounces = 0, lighting = 0 the
 // result equals render_kernel's bit for bit.
 // ---------------------------------------------------------------------------------------------------------
-template <bool LOC = true>                                  // LOC: keep the accepted hit's world location (secondary rays start there)
+template <bool LOC = true, bool OCTANTS = false>           // LOC: keep the accepted hit's world location (secondary rays start there)
 __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, Stack& stack, int& pops)
 {
     Hit hit;
@@ -600,7 +604,7 @@ __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir
     hit.loc = v3(0.0f, 0.0f, 0.0f);
     Counters<false> none;
     for (int i = 0; i < p.num_instances; i++)
-        trace_instance<false, false, LOC, false, Stack, true>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
+        trace_instance<false, false, LOC, false, Stack, true, OCTANTS>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
     return hit;
 }
 
@@ -632,16 +636,13 @@ __device__ __forceinline__ V3 hit_normal(const RenderParams& p, const Hit& hit)
 // take several launches, the running sums wait in ex_acc in between.  What a (pixel, sample) pair computes does not depend on
 // the lane it runs in, so the frame is the same bit for bit (tests/test_gpu_parity.py compares the two mappings).
 // (8 waves per SIMD stays the best residency with this mapping too: 7 / 6 / 5 waves +1.6 % / +6 % / +17 % on c3, +4 % on c4)
-template <bool SIMPLE, bool PX = false>
-__global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams p)
+// Which (pixel, sample) pair thread `tid` of workgroup (tile, row) works on.  A function of its own so that the kernel can call
+// it again after the casts instead of keeping the results (see render_pixel: registers the traversal loop has no room for).
+template <bool PX>
+__device__ __forceinline__ void ex_work_item(const RenderParams& p, int tile, int row, int tid, int& x, int& ly, int& y, int& s, bool& valid)
 {
-    extern __shared__ int lds_stack[];
-    const FrameParams& f = p.frames[0];
-    const int tile = blockIdx.x;
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int x, ly, s;
-    bool valid;
+    const int wave = tid >> 6, lane = tid & 63;
     if constexpr (PX) {
         const int pix = lane / p.px_n, sl = lane % p.px_n;
         x = tx * 2 * p.px_pw + (wave & 1) * p.px_pw + pix % p.px_pw;
@@ -651,32 +652,63 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     } else {
         x = tx * kTile + (wave & 1) * 8 + (lane & 7);
         ly = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
-        s = p.sample_base + (int)blockIdx.y;
+        s = p.sample_base + row;
         valid = x < p.width && ly < p.local_rows;
-        if (!valid) return;
     }
-    const int y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;   // stripes: local -> frame row
+    y = ly;                                                     // stripes: local -> frame row (the identity for one rank)
+    if (p.num_ranks != 1) y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
+}
+
+// The random stream of (pixel, sample) after `drawn` values: the reference's per-pixel seed (raycast.cu:190: int idx * 1000)
+// plus the sample index.  A path does not carry the six words of its stream across its casts; it carries how many values
+// it has drawn and steps a fresh copy forward when it next needs one (a few dozen integer operations against the hundreds
+// of a cast; the sequence of values is the same).
+__device__ __forceinline__ Xorwow ex_stream(const RenderParams& p, int x, int y, int s, int drawn)
+{
+    Xorwow rng;
+    xorwow_init(rng, (unsigned long long)((long long)(int32_t)((uint32_t)(y * p.width + x) * 1000u) + (long long)s));
+    for (int k = 0; k < drawn; k++) (void)xorwow_next(rng);
+    return rng;
+}
+
+template <bool SIMPLE, bool PX = false>
+__global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams p)
+{
+    extern __shared__ int lds_stack[];
+    const FrameParams& f = p.frames[0];
+    const int tile = blockIdx.x;
+    int x, ly, y, s;
+    bool valid;
+    ex_work_item<PX>(p, tile, (int)blockIdx.y, (int)threadIdx.x, x, ly, y, s, valid);
+    if constexpr (!PX) { if (!valid) return; }
     unsigned long long t_start = 0;
     if (p.trace) t_start = wall_clock64();
 
     int spill[kMaxStack - kLdsStack];
     Stack stack;
-    stack.lds = (lds_int*)lds_stack + tid; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
+    // (the thread's index lives on as the address of its LDS stack column only)
+    stack.lds = (lds_int*)lds_stack + threadIdx.x; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
+    auto where = [&](int& x_, int& ly_, int& y_, int& s_, bool& valid_) {
+        asm volatile("" : "+v"(stack.lds));                     // (hides the address's origin: the optimiser would keep the first results alive)
+        ex_work_item<PX>(p, tile, (int)blockIdx.y, (int)(stack.lds - (lds_int*)lds_stack), x_, ly_, y_, s_, valid_);
+    };
     int pops = 0;
     V3 sample = v3(0.0f, 0.0f, 0.0f);
     if (valid) {
 
-    // stream of (pixel, sample): the reference's per-pixel seed (raycast.cu:190: int idx * 1000) plus the sample index
-    Xorwow rng;
-    xorwow_init(rng, (unsigned long long)((long long)(int32_t)((uint32_t)(y * p.width + x) * 1000u) + (long long)s));
     const V3 sun = normalize(v3(-0.2f, 0.0f, 1.0f));                                                    // raycast.cu:249-250
     float px = (float)x, py = (float)y;
-    if (s > 0) { px = px + (xorwow_uniform(rng) - 0.5f); py = py + (xorwow_uniform(rng) - 0.5f); }
+    int drawn = 0;                                              // values taken from the (pixel, sample) stream so far
+    if (s > 0) {
+        Xorwow rng = ex_stream(p, x, y, s, 0);
+        px = px + (xorwow_uniform(rng) - 0.5f); py = py + (xorwow_uniform(rng) - 0.5f);
+        drawn = 2;
+    }
     V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     V3 dir = camera_direction(f, px, py);
     V3 weight = v3(1.0f, 1.0f, 1.0f);
     if constexpr (SIMPLE) {                                     // the loop below for bounces = 0, lighting = 0, written out
-        const Hit hit = cast_ray_ex<false>(p, org, dir, stack, pops);
+        const Hit hit = cast_ray_ex<false, true>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) sample = sample + weight * v3(1.0f, 0.8f, 0.6f);
         else {
             const V3 base = base_colour(p, hit);
@@ -712,6 +744,10 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
         const float k = 2.0f * dot(dir, n);
         V3 r = dir - n * k;
         if (mat.roughness > 0.0f) {
+            int x_, ly_, y_, s_; bool v_;
+            where(x_, ly_, y_, s_, v_);
+            Xorwow rng = ex_stream(p, x_, y_, s_, drawn);
+            drawn += 3;
             float rx = 2.0f * xorwow_uniform(rng) - 1.0f, ry = 2.0f * xorwow_uniform(rng) - 1.0f, rz = 2.0f * xorwow_uniform(rng) - 1.0f;
             r = r + v3(rx, ry, rz) * mat.roughness;
         }
@@ -720,6 +756,8 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
         dir = r;
     }
     }
+    where(x, ly, y, s, valid);
+    const int tid = (int)(stack.lds - (lds_int*)lds_stack), wave = tid >> 6, lane = tid & 63;
     if constexpr (PX) {
         // the wave's samples -> its own LDS columns (the traversal stacks are idle now), four rows of 64 words: r g b pops
         lds_int* mine = (lds_int*)lds_stack + wave * 64;

@@ -58,9 +58,12 @@ if "SQ_THREAD_CYCLES_VALU" in pf and "SQ_ACTIVE_INST_VALU" in pf:
 if "TCP_TOTAL_CACHE_ACCESSES_sum" in pf:
     entry["tcp_accesses_per_frame"] = pf["TCP_TOTAL_CACHE_ACCESSES_sum"]
 if "FETCH_SIZE" in pf and "WRITE_SIZE" in pf:
-    # KiB units; FETCH_SIZE x 2: the gfx950 correction of MI355X_MICROARCH.md "HBM" (128-B requests tallied at 64 B)
-    entry.update({"hbm_bytes_per_frame": (2 * pf["FETCH_SIZE"] + pf["WRITE_SIZE"]) * 1024, "fetch_bytes_per_frame_corrected": 2 * pf["FETCH_SIZE"] * 1024,
-                  "write_bytes_per_frame": pf["WRITE_SIZE"] * 1024})
+    # KiB units.  No x2 on FETCH_SIZE: the render kernels read 64-B records at unrelated addresses (four 16-B loads per lane),
+    # and for that pattern tools/fetch_calibration.sh measures 0.99 bytes reported per byte read (profiles/r04_fetch_calibration.json);
+    # the x2 of MI355X_MICROARCH.md "HBM" is for 16 B-per-lane streaming reads (0.50 measured with the same tool).  Both
+    # counters sit on the fabric side of the L2s: Infinity Cache hits are included.
+    entry.update({"hbm_bytes_per_frame": (pf["FETCH_SIZE"] + pf["WRITE_SIZE"]) * 1024, "fetch_bytes_per_frame": pf["FETCH_SIZE"] * 1024,
+                  "write_bytes_per_frame": pf["WRITE_SIZE"] * 1024, "fetch_size_correction": 1.0})
 if "GRBM_GUI_ACTIVE" in pf and "SQ_INSTS_VALU" in pf:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction holds a SIMD-32 for 2 cycles
     entry["valu_issue_frac_under_profiler"] = round(pf["SQ_INSTS_VALU"] * 2 / (1024 * pf["GRBM_GUI_ACTIVE"] / 8), 4)
