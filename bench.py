@@ -60,6 +60,7 @@ CLOCK_HZ = 2.4e9                 # max shader clock
 N_SIMD = 256 * 4
 VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 2 / 1e9     # wave64 VALU instructions per second: 2 cycles each on a SIMD-32 (MICROARCH "Wave scheduling")
 L1_PEAK_GBS = 256 * 64 * CLOCK_HZ / 1e9           # vector L1: one 64-B access per CU per clock
+SALU_PEAK_GINST = 256 * CLOCK_HZ / 1e9            # one scalar unit per CU (MICROARCH glossary "CU"), one instruction per clock
 STRIPE_ROWS = 16
 MIN_WARM_FRAMES = 320            # 1-spp stream workloads: untimed frames before the timed region, whatever --warmup asks (see run_stream)
 COUNTERS_JSON = os.path.join(ROOT, "profiles", "r04_counters.json")
@@ -325,14 +326,18 @@ def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_fra
         valu = e["valu_insts_per_frame"] * n / sec / 1e9
         l1 = e["tcp_accesses_per_frame"] * 64 * n / sec / 1e9 if e.get("tcp_accesses_per_frame") else None
         hbm = e["hbm_bytes_per_frame"] * n / sec / 1e9 if e.get("hbm_bytes_per_frame") is not None else None
-        # the bound = whichever unit is busiest (fractions of: VALU issue slots, L1 accesses, HBM bytes)
+        salu = e["per_frame"]["SQ_INSTS_SALU"] * n / sec / 1e9 if e.get("per_frame", {}).get("SQ_INSTS_SALU") else None
+        # the bound = whichever unit is busiest (fractions of: VALU issue slots, L1 accesses, the CU's scalar unit, HBM bytes)
         fr = {"valu_issue": valu / VALU_PEAK_GINST}
         if l1 is not None:
             fr["l1"] = l1 / L1_PEAK_GBS
+        if salu is not None:
+            fr["salu_issue"] = salu / SALU_PEAK_GINST
         if hbm is not None:
             fr["hbm"] = hbm / HBM_PEAK_GBS
         bound = max(fr, key=fr.get)
-        ach, peak, unit = {"valu_issue": (valu, VALU_PEAK_GINST, "G wave-instr/s"), "l1": (l1, L1_PEAK_GBS, "GB/s"), "hbm": (hbm, HBM_PEAK_GBS, "GB/s")}[bound]
+        ach, peak, unit = {"valu_issue": (valu, VALU_PEAK_GINST, "G wave-instr/s"), "l1": (l1, L1_PEAK_GBS, "GB/s"),
+                           "salu_issue": (salu, SALU_PEAK_GINST, "G instr/s"), "hbm": (hbm, HBM_PEAK_GBS, "GB/s")}[bound]
         out.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
                     "traffic": int(e["hbm_bytes_per_frame"] * n) if e.get("hbm_bytes_per_frame") is not None else None,
                     "fractions": {k: round(v, 4) for k, v in fr.items()},
@@ -342,7 +347,7 @@ def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_fra
                     "l1_bw_frac": round(l1 / L1_PEAK_GBS, 4) if l1 is not None else None,
                     "hbm_physical_frac": round(hbm / HBM_PEAK_GBS, 5) if hbm is not None else None,
                     "profile": e.get("tag"),
-                    "peaks": "VALU: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; L1: 256 CUs x 64 B/clk; HBM 8 TB/s"})
+                    "peaks": "VALU: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; L1: 256 CUs x 64 B/clk; SALU: 256 CUs x 1 instruction/clk; HBM 8 TB/s"})
         if hbm is not None:
             # FETCH_SIZE / WRITE_SIZE count what leaves the L2s (Infinity Cache hits included): an upper bound on HBM bytes.
             # No x2 on FETCH_SIZE here: tools/fetch_calibration.sh measures 0.99 bytes reported per byte for this kernel's
