@@ -183,6 +183,62 @@ def test_degenerate_and_extreme_geometry(rt, orc, scenes, kind):
     assert ref["tris"].sum() > 0 and (hits > 0 or kind == "tiny")
 
 
+@pytest.mark.parametrize("gpu_build", [False, True])
+def test_non_finite_vertices_and_the_octant_preconditions(rt, orc, scenes, gpu_build):
+    """The octant-specialised slab test (rt_kernels.hip slab_oct) is only valid for boxes with min <= max and no NaN, rays with
+    a finite origin and finite non-zero direction inverses of one sign pattern per wave; everything else must take the generic
+    loop.  Triangles with NaN and infinite coordinates (NaN-ignoring min / max leave such boxes partly infinite, a node whose
+    triangles are all NaN on an axis keeps (FLT_MAX, -FLT_MAX): min > max -- the mesh is flagged by whoever writes its interior
+    records: upload, device build, refit); a camera whose central rays are exactly parallel to two axes (dinv = inf) and whose
+    8x8 tiles straddle all sign octants; a refit that moves NaNs into a mesh that had none.  All planes against the oracle."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    rng = np.random.default_rng(41)
+    clean = sd.random_triangles(120, seed=21, spread=0.9, size=0.35)
+    bad = clean.copy()
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    bad[3, 0] = nan                                              # one NaN coordinate
+    bad[10, 0:9] = nan                                           # a triangle of NaNs
+    bad[17, 1] = inf; bad[18, 5] = -inf                          # infinite coordinates
+    bad[25:31, 2] = nan; bad[25:31, 5] = nan; bad[25:31, 8] = nan   # six triangles with no z at all
+    for i in (3, 10, 17, 18, 25, 26, 27, 28, 29, 30):
+        bad[i, :12] = o.tri_from_vertices(bad[i, :9])[:12]
+    W, H = 128, 96
+    K = scenes.scaled_K(W)
+    # looking along +y from a point with x = z = 0: the centre pixels' rays have direction components that are exactly zero
+    K_centred = (K[0], 0.0, W / 2.0, 0.0, K[4], H / 2.0, 0.0, 0.0, 1.0)
+    for tris, name in ((bad, "non-finite"), (clean, "clean")):
+        d = sd.SceneDesc([((0.3, 0.6, 0.9), sd.checker_texture(8, 8, seed=2))], [("tris", tris)], [(0, 0, (0,) * 6, (1.0, 0.7, 1.3))])
+        for pose, Kc in (((0.0, -3.0, 0.0, 0, 0, 0), K_centred), ((0.2, -2.5, 0.1, 0.3, -0.2, 0.1), K)):
+            _compare(rt, orc, d, W, H, Kc, scenes.D_REF, pose, gpu_build=gpu_build)
+    # a refit that brings NaNs into a mesh uploaded clean: the flag is set by the refit kernels
+    so = orc_mod.OracleScene(o)
+    so.add_material((0.3, 0.6, 0.9))
+    om = o.mesh_from_triangles(clean)
+    so.add_mesh(om)
+    so.add_instance(0, 0)
+    sp = rt.Scene()
+    sp.add_material((0.3, 0.6, 0.9))
+    sp.add_mesh(rt.Mesh.from_triangles(clean, gpu_build=gpu_build))
+    sp.add_mesh_instance(0, 0)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose((0.0, -3.0, 0.0, 0, 0, 0))
+    moved = clean.copy()
+    moved[:, 2] += np.float32(0.05); moved[:, 5] += np.float32(0.05); moved[:, 8] += np.float32(0.05)
+    moved[40:44, 0:9] = nan
+    for i in range(len(moved)):
+        moved[i, :12] = o.tri_from_vertices(moved[i, :9])[:12]
+    sp.refit_mesh(0, moved)
+    o.mesh_refit(om, moved)
+    ref = so.render(W, H, K, scenes.D_REF, (0.0, -3.0, 0.0, 0, 0, 0), threads=4)
+    dbg = rt.render_debug(sp, cam)
+    for n in ("img",) + PLANES:
+        assert np.array_equal(dbg[n], ref[n]), ("refit with NaNs", n)
+    assert np.array_equal(rt.render(sp, cam), ref["img"])
+    so.close()
+
+
 def test_exact_uv_path(rt, orc, scenes):
     """uv values near FLT_MAX switch the kernel to the per-candidate uv test of raycast.cu:96."""
     tris = sd.random_triangles(50, seed=5, spread=0.6, size=0.5)
