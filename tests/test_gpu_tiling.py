@@ -124,7 +124,7 @@ def test_stripe_pipeline_on_streams_with_distinct_poses(rt, scenes, blob5k, comm
     assert not np.array_equal(got[0, 0], got[1, 0])
 
 
-@pytest.mark.parametrize("extra", [["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8"],
+@pytest.mark.parametrize("extra", [["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8", "--rccl-max-channels", "4"],
                                    ["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8", "--gather", "root0"],
                                    ["--workload", "c3", "--width", "320", "--height", "180", "--spp", "4", "--bounces", "2", "--steps", "3", "--warmup", "1"],
                                    ["--workload", "c2", "--width", "640", "--height", "360", "--steps", "40", "--warmup", "8", "--exchange", "torch"],
@@ -141,6 +141,9 @@ def test_bench_forced_collective_path(extra):
     assert line["n_gpus"] == 1 and line["FORCED_COLLECTIVE_PATH"]
     assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
     assert ("EXCHANGE_FALLBACK" in line) == ("torch" in extra)
+    if "c2" in extra:                                                   # the stream workloads run the pipeline: one rank's stage times
+        assert len(line["per_rank"]) == 1 and line["per_rank"][0]["render_ms_per_group"] > 0 and line["stripe_share_imbalance"] == 1.0
+        assert line["rccl"]["NCCL_MAX_NCHANNELS"] == ("4" if "--rccl-max-channels" in extra else None)
 
 
 @pytest.mark.parametrize("workload", [["--workload", "c2", "--width", "480", "--height", "272", "--steps", "24", "--warmup", "4"],
@@ -191,6 +194,23 @@ def test_bench_ranks_as_processes_over_mock_transport(mock_rccl, extra):
     assert line["ranks_seen"] == int(extra[1])                       # the size the (mock) communicator itself reports
     assert line.get("frame_matches_debug_kernel", line.get("frame_matches_single_gpu_render")) is True
     assert "rt_" in line["config"]["parallelism"]
+    if "c2" in extra:
+        _check_per_rank_report(line, int(extra[1]))
+
+
+def _check_per_rank_report(line, world):
+    """An N > 1 stream line says where every rank's time went: per group of frames the wait for a free buffer
+    set, the render, the exchange and the un-stripe pass, measured with hipEvents at the stage boundaries."""
+    ranks = line["per_rank"]
+    assert [r["rank"] for r in ranks] == list(range(world))
+    for r in ranks:
+        assert r["groups_timed"] >= 1
+        assert r["render_ms_per_group"] > 0 and r["exchange_ms_per_group"] > 0 and r["unstripe_ms_per_group"] >= 0 and r["wait_for_buffer_ms"] >= 0
+        parts = r["wait_for_buffer_ms"] + r["render_ms_per_group"] + r["exchange_ms_per_group"] + r["unstripe_ms_per_group"]
+        assert parts <= r["group_span_ms"] * 1.001 + 1e-3, r          # the four stages of a group follow one another: they add up to its span
+    assert any(r["unstripe_ms_per_group"] > 0 for r in ranks)          # somebody assembles frames
+    assert line["stripe_share_imbalance"] >= 1.0
+    assert set(line["rccl"]) >= {"version", "through", "NCCL_MAX_NCHANNELS"} and line["rccl"]["through"].startswith("rt_comm")
 
 
 def test_bench_rank_that_never_joins_ends_the_run_inside_the_deadline(mock_rccl):

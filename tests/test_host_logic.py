@@ -677,6 +677,28 @@ def test_forced_rccl_library_that_cannot_be_loaded_is_an_error(rt, tmp_path):
         assert r.stdout.split()[0] == "-5" and needle in r.stdout, r.stdout
 
 
+def test_comm_error_text_is_readable_from_another_thread(rt, tmp_path):
+    """rt_comm_last_error() is the CALLING thread's last RT_E_COMM.  bench.py's phase watchdog is another thread: it reads
+    rt_comm_last_error_any(), the most recent error of any thread (it used to print the per-thread text, which is
+    always empty there)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, threading; rt = importlib.import_module('cuda-raytracing_amd'); import ctypes as C\n"
+            "h = rt.libs()[0]; v = C.c_int32(0); rc = h.rt_comm_available(C.byref(v))\n"
+            "box = {}\n"
+            "t = threading.Thread(target=lambda: box.update(own=rt.Comm.last_error(), any=rt.Comm.last_error_any())); t.start(); t.join()\n"
+            "print(rc); print('OWN=' + box['own']); print('ANY=' + box['any']); print('MAIN=' + rt.Comm.last_error())")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(os.environ, RT_RCCL_LIBRARY=str(tmp_path / "missing.so")))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "-5"
+    assert lines[1] == "OWN="                                           # the other thread made no comm call
+    assert "could not be loaded" in lines[2] and lines[2].startswith("ANY=")
+    assert lines[3] == "MAIN=" + lines[2][4:]
+
+
 def test_damaged_obj_files_never_crash_and_parse_the_same_on_any_thread_count(rt, tmp_path, blob5k, monkeypatch):
     """Truncated (also at page-size multiples: the file is memory-mapped, nothing may be read past its end), bit-flipped and
     spliced OBJ files: every one is either parsed or refused with a message -- the same triangles or the same message on one
