@@ -23,6 +23,26 @@
 
 using namespace rt;
 
+// build-time switches of the traversal loop (A/B experiments only: RT_HIPCC_EXTRA=-DRT_OCTANTS=0 ...; the defaults are what ships)
+#ifndef RT_OCTANTS
+#define RT_OCTANTS 1            // octant-specialised loops, see trace_instance
+#endif
+#ifndef RT_WAIT_AT_FETCH
+#define RT_WAIT_AT_FETCH 0      // 1: the vector fetch waits for its four loads where it issues them (measured +0.5 %), see trace_loop
+#endif
+#ifndef RT_SENTINEL
+#define RT_SENTINEL 1           // the traversal stack starts with a sentinel entry: "stack empty" is a value popped, see trace_loop
+#endif
+#ifndef RT_STACK_WAVE_CHECK
+#define RT_STACK_WAVE_CHECK 0   // 1: push / pop ask once per wave whether any lane is beyond the LDS part of the stack (measured +0.8 %), see StackT
+#endif
+#ifndef RT_LEAF_FLAT
+#define RT_LEAF_FLAT 1          // leaf step without the empty-leaf region; the wave's "any accept" asked inside the leaf region
+#endif
+#ifndef RT_NEED_POP_VALUE
+#define RT_NEED_POP_VALUE 1     // "this lane must pop" is a value of `cur` (kNeedPop), not a flag merged across the loop's branches
+#endif
+
 // =====================================================================================
 //                                      device code
 // =====================================================================================
@@ -36,8 +56,8 @@ struct Hit {
     float min;                  // HitInfo::min, raycast.cu:12
     int32_t slot;               // triangle slot of the accepted hit
     int32_t instance;
-    float u, v;                 // barycentrics of the accepted hit (uv is interpolated once, at shade time)
-    float2 uv;                  // used only by the exact-uv variant
+    float u, v;                 // barycentrics of the accepted hit (uv is interpolated once, at shade time) -- or, for a mesh in the
+                                // exact-uv mode, the interpolated uv itself (the two never coexist: two registers, not four)
     V3 loc;                     // world-space location of the accepted hit (extension kernel only)
 };
 
@@ -115,6 +135,16 @@ struct Counters<false> {};
 // deep but rays seldom hold more than a dozen postponed nodes -- spill to a private (scratch) array.  Keeping the
 // LDS part at 16 entries lets 8 waves/SIMD stay resident (16 KB per 256-thread workgroup).
 constexpr int kLdsStack = 16;
+// Two entries no tree contains: leaf references whose slot field is beyond every slot a scene can hold (rt_scene_upload and the
+// rebuild keep slot_base + n + 1 <= kSlotMask, so the largest first-slot of a leaf is kSlotMask - 2).  Chosen among the
+// hardware's inline integer constants (-16 .. 64): compares and selects against them need no register.
+// kSentinel: with RT_SENTINEL the first entry of every traversal; popping it ends the loop.
+// kNeedPop: what interior_apply / the leaf step leave in `cur` when the lane has to pop.
+constexpr int32_t kSentinel = -2;               // = leaf flag | count 31 | slot kSlotMask - 1
+constexpr int32_t kNeedPop = -1;                // = leaf flag | count 31 | slot kSlotMask
+static_assert((kSentinel & kSlotMask) == kSlotMask - 1 && (kNeedPop & kSlotMask) == kSlotMask, "beyond the slot space");
+// rows of a workgroup's LDS stack block ([row][thread] ints): the postponed nodes kept in LDS, plus the sentinel's row
+__host__ __device__ inline int lds_rows(int stack_depth) { return (stack_depth < kLdsStack ? stack_depth : kLdsStack) + RT_SENTINEL; }
 typedef __attribute__((address_space(3))) int lds_int;      // typed LDS pointer: keeps stack traffic on ds_read/ds_write
 // SPILL = false: the tree is shallow enough for the LDS part alone (a tree of L levels never holds more than L - 1 postponed
 // nodes: the entries of a stack sit at strictly increasing levels below the root) -- no private array, and neither push
@@ -123,11 +153,18 @@ template <int STRIDE, bool SPILL = true>                    // STRIDE = threads 
 struct StackT {
     lds_int* lds;               // this lane's LDS column
     int* spill;                 // this lane's private overflow, kMaxStack - kLdsStack entries
-    int lds_depth;              // entries kept in LDS (<= kLdsStack)
+    int lds_depth;              // entries kept in LDS: lds_rows(stack_depth)
     int sp;
+    // (RT_STACK_WAVE_CHECK: whether ANY lane of the wave is beyond the LDS part is asked once per wave -- a scalar branch; the
+    // per-lane "which memory" regions then only run when one is.  Deep entries are rare (the c2 tree has 28 levels and no
+    // ray of its three cameras holds more than 16 postponed nodes), but the ballot costs what the regions cost: measured
+    // +0.8 % on c2, off.)
     __device__ __forceinline__ void push(int32_t v)
     {
-        if constexpr (SPILL) { if (sp < lds_depth) lds[sp * STRIDE] = v; else spill[sp - lds_depth] = v; }
+        if constexpr (SPILL && RT_STACK_WAVE_CHECK) {
+            if (__builtin_amdgcn_ballot_w64(sp >= lds_depth) == 0ull) lds[sp * STRIDE] = v;
+            else if (sp < lds_depth) lds[sp * STRIDE] = v; else spill[sp - lds_depth] = v;
+        } else if constexpr (SPILL) { if (sp < lds_depth) lds[sp * STRIDE] = v; else spill[sp - lds_depth] = v; }
         else lds[sp * STRIDE] = v;
         sp++;
     }
@@ -135,6 +172,7 @@ struct StackT {
     {
         --sp;
         if constexpr (!SPILL) return lds[sp * STRIDE];
+        if constexpr (RT_STACK_WAVE_CHECK) { if (__builtin_amdgcn_ballot_w64(sp >= lds_depth) == 0ull) return lds[sp * STRIDE]; }
         // always an LDS read (index clamped) and, rarely, a private read on top: a select between the two
         // address spaces would turn into one slow flat_load
         int32_t v = lds[(sp < lds_depth ? sp : lds_depth - 1) * STRIDE];
@@ -164,7 +202,7 @@ __device__ __forceinline__ MeshRay to_mesh_space(const DevInstance& in, V3 org, 
 // One interior node (raycast.cu:66-79) from its already fetched 64-B record: tests both children, pushes the
 // far one if it passes `dist < hit.min`, and leaves in `cur` the entry the reference would pop next (the entry
 // pushed last never goes through the stack).  Returns false when nothing was pushed.
-template <bool DEBUG, class STK, int OCT = -1>
+template <bool DEBUG, class STK, int OCT = -1, bool NEED_POP = false>
 __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, float4 q3, const MeshRay& r, float hit_min,
                                                int32_t& cur, STK& stack, Counters<DEBUG>& cnt)
 {
@@ -190,7 +228,7 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
         stack.push(a_near ? rb : ra);                           // the only entry that really goes through the stack
         next = a_near ? ra : rb;
     }
-    cur = next;                                                 // (not used when neither passed)
+    cur = NEED_POP ? ((pa | pb) ? next : kNeedPop) : next;      // (without NEED_POP: not used when neither passed, the caller pops)
     return pa || pb;
 }
 
@@ -283,8 +321,18 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
                                            V3 org, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters, int* pops)
 {
     stack.sp = 0;
+#if RT_SENTINEL
+    // The stack starts with a sentinel (raycast.cu:58 starts it with the root, which here stays in a register): "pop from an
+    // empty stack" (raycast.cu:60) is then an ordinary pop that returns the sentinel, and the loop ends on the VALUE popped --
+    // one compare for all lanes at the bottom of the loop instead of an `if (sp == 0) break` nested in the pop branch, which
+    // cost ten scalar instructions of exec-mask bookkeeping per iteration.
+    stack.push(kSentinel);
+#endif
     int32_t cur = in.root_ref;                                  // raycast.cu:58 (kept in a register)
     bool have = true;
+    // "this lane must pop" as a value of `cur` instead of the flag `have`: -1.5 % on the primary kernel, +0.8 % on the bounce
+    // casts of the extension kernel (EX: they keep the flag) -- profiles/r04_experiments/sentinel_loop_ab.log
+    constexpr bool kNeedPopValue = RT_SENTINEL && RT_NEED_POP_VALUE && !EX;
     int rem = -1;                                               // triangles left in the leaf being walked, -1 = not in a leaf
     unsigned long long c_pop = 0, c_mem = 0, c_int = 0, c_leaf = 0, n_it = 0, n_int = 0, n_leaf = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     // One iteration = one interior node or ONE triangle of a leaf (a leaf with k triangles takes k iterations and
@@ -294,7 +342,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     // hit record leaves the loop after its update: with the exit at the top it was live across the back edge in two
     // copies.
     const bool exact_uv = in.exact_uv != 0, identity_inv = in.identity_inv != 0;    // (read once, not per triangle)
-    while (true) {
+    do {
         if constexpr (PROF) t1 = __builtin_amdgcn_s_memtime();
         if constexpr (COUNT) (*iters)++;
         const bool interior = cur >= 0;
@@ -307,13 +355,15 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
         float4 r0, r1, r2, r3;          // the record; for interior lanes r0..r2 become child boxes - ray origin
         const int32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
         if (!PROF && __ballot(cur != cur0) == 0ull) {
-            const float4* g = p.records + (size_t)(cur0 & kSlotMask) * 4;
             typedef float f16v __attribute__((ext_vector_type(16)));
             f16v w;
             // inline asm: hipcc would otherwise merge this load with the per-lane one below into a single vector load.
             // No "memory" clobber: the records are read-only, and a clobber makes every other load in the loop
             // (instance fields, ...) repeat each iteration.
-            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(g));
+            // The record's byte offset goes into the instruction's scalar offset operand (no 64-bit address arithmetic):
+            // entry << 6 drops the flag and count bits of a leaf reference and stays below 4 GiB (at most 2^26 - 2 records).
+            const uint32_t off = (uint32_t)cur0 << 6;
+            asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p.records), "s"(off));
             if (cur0 >= 0) {                                    // (a scalar branch: the whole wave holds this interior node)
                 box_differences(w, r.ro, r0, r1, r2);
             } else {
@@ -330,6 +380,13 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
         } else {
             const float4* rec = p.records + (size_t)(cur & kSlotMask) * 4;     // node or triangle: one array, one index space
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+#if RT_WAIT_AT_FETCH
+            // All four loads are waited for HERE (the empty asm uses a word of each): otherwise every later use of r0..r3 -- in
+            // code that the wave-uniform path shares -- gets its own s_waitcnt vmcnt(n), ten no-ops per iteration on the
+            // path that issued no vector load at all.  Measured: ten fewer instructions per iteration and 0.5 % MORE time (the
+            // subtractions of box_differences no longer overlap the later loads): off, kept as a switch for the record.
+            asm volatile("" : "+v"(r0.x), "+v"(r1.x), "+v"(r2.x), "+v"(r3.x));
+#endif
             if (interior) {
                 const float w[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
                 box_differences(w, r.ro, r0, r1, r2);
@@ -340,9 +397,10 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
             t2 = __builtin_amdgcn_s_memtime();
             n_it++; n_int += __ballot(interior) != 0; n_leaf += __ballot(!interior) != 0;
         }
-        if (interior) have = interior_apply<DEBUG, STK, OCT>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
+        if (interior) have = interior_apply<DEBUG, STK, OCT, kNeedPopValue>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t3 = __builtin_amdgcn_s_memtime(); }
         bool accept = false;
+        unsigned long long any_accept = 0ull;
         Candidate c;                                            // uninitialised on purpose, see Candidate
         const int slot = cur & kSlotMask;
         if (!interior) {                                        // leaf: contiguous triangle slots, raycast.cu:83-137
@@ -350,26 +408,40 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
             const int coded = (cur >> kSlotBits) & 31;
             rem = first ? coded : rem;
             if (first & (coded == 31)) rem = p.leaf_count[slot];    // (leaves of more than 30 triangles: rare)
-            if (rem > 0) accept = triangle_test<DEBUG, EX>(p, in, exact_uv, identity_inv, r, org, slot, hit.min, cnt, r0, r1, r2, r3, c);
+            if constexpr (DEBUG || !RT_LEAF_FLAT) {             // (the instrumented kernel counts triangle tests: none for an empty leaf)
+                if (rem > 0) accept = triangle_test<DEBUG, EX>(p, in, exact_uv, identity_inv, r, org, slot, hit.min, cnt, r0, r1, r2, r3, c);
+            } else {
+                // An empty leaf (degenerate splits only) holds no triangle to test: its "test" runs on whatever record sits at
+                // the slot (always readable: the arrays are padded) and the result is masked -- one exec-mask region less
+                // in every leaf iteration of every other scene.
+                accept = triangle_test<DEBUG, EX>(p, in, exact_uv, identity_inv, r, org, slot, hit.min, cnt, r0, r1, r2, r3, c) & (rem > 0);
+            }
+            if constexpr (RT_LEAF_FLAT) any_accept = __builtin_amdgcn_ballot_w64(accept);   // (asked here, where `accept` is a compare result, not a merged flag)
             rem--;
             have = rem > 0;
-            cur = have ? cur + 1 : cur;                         // next slot of the same leaf (the slot field never overflows)
+            cur = have ? cur + 1 : (kNeedPopValue ? kNeedPop : cur);    // next slot of the same leaf (the slot field never overflows)
             rem = have ? rem : -1;
         }
-        if (__builtin_amdgcn_ballot_w64(accept) != 0ull) {                         // (wave-level: most iterations accept nothing)
+        if constexpr (!RT_LEAF_FLAT) any_accept = __builtin_amdgcn_ballot_w64(accept);
+        if (any_accept != 0ull) {                               // (wave-level: most iterations accept nothing)
             hit.min = accept ? c.dist : hit.min;
             hit.slot = accept ? slot : hit.slot;
             hit.instance = accept ? inst_index : hit.instance;
-            hit.u = accept ? c.u : hit.u;
-            hit.v = accept ? c.v : hit.v;
-            if (exact_uv) { hit.uv.x = accept ? c.uv.x : hit.uv.x; hit.uv.y = accept ? c.uv.y : hit.uv.y; }
+            hit.u = accept ? (exact_uv ? c.uv.x : c.u) : hit.u;
+            hit.v = accept ? (exact_uv ? c.uv.y : c.v) : hit.v;
             if constexpr (EX) { hit.loc.x = accept ? c.loc.x : hit.loc.x; hit.loc.y = accept ? c.loc.y : hit.loc.y; hit.loc.z = accept ? c.loc.z : hit.loc.z; }
         }
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t0 = __builtin_amdgcn_s_memtime(); }
+#if RT_SENTINEL
+        // (kNeedPopValue: `have` is not read -- as a flag it is a lane mask that every branch of the loop has to merge into,
+        // eight scalar instructions per iteration; as a value of `cur` it costs one select)
+        if (kNeedPopValue ? cur == kNeedPop : !have) cur = stack.pop();     // raycast.cu:60-61 (the sentinel when nothing is left)
+#else
         if (!have) {
             if (stack.sp == 0) break;
             cur = stack.pop();                                  // raycast.cu:61
         }
+#endif
         // One latch for both ways round (popped / kept going): a convergent no-op that the optimiser may not clone.
         // Without it the two back edges are split into nested loops ("iterate while nobody pops" inside "pop"),
         // i.e. lanes that need a pop wait for every lane that does not: +50 % time on views with sky.
@@ -378,7 +450,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
             __builtin_amdgcn_s_waitcnt(0);
             c_mem += t2 - t1; c_int += t3 - t2; c_leaf += t0 - t3; c_pop += __builtin_amdgcn_s_memtime() - t0;
         }
-    }
+    } while (!RT_SENTINEL || cur != kSentinel);
     if constexpr (PROF) {
         if (p.trace) {                                          // the longest-lived lane's view of the wave
             unsigned long long v[7] = {c_pop, c_mem, c_int, c_leaf, n_it, n_int, n_leaf};
@@ -399,9 +471,6 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 // become operand choices) or the generic loop.  A wave qualifies when every active lane has a finite origin and finite,
 // non-zero direction inverses of the same signs, and the mesh has no interior record with an unordered or NaN box
 // (mesh_flags bit 0, kept by every writer of interior records: upload, device rebuild, refit).
-#ifndef RT_OCTANTS
-#define RT_OCTANTS 1
-#endif
 // OCTANTS = false keeps one loop: the bounce / shadow kernels of the extension renderer carry their path state across every
 // cast in registers they do not have (spilled to scratch); nine loops per cast site made that worse (c3 24.9 ms against
 // 23.7 ms with the generic loop alone, profiles/r04_experiments/octants_in_extension_kernels.log), while the samples-only
@@ -445,7 +514,7 @@ __device__ __forceinline__ V3 base_colour(const RenderParams& p, const Hit& hit)
     const DevInstance& in = p.instances[hit.instance];
     const DevMaterial& m = p.materials[in.material_index];
     if (m.texture_width > 0) {                                  // raycast.cu:224-240
-        float2 uv = hit.uv;
+        float2 uv = make_float2(hit.u, hit.v);                  // exact-uv meshes: the hit carries uv itself
         if (!in.exact_uv) {
             const float* q = p.tri_uv + (size_t)hit.slot * 6;
             float w = 1.0f - hit.u - hit.v;
@@ -495,11 +564,11 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     const V3 dir = camera_direction(f, (float)x, (float)y);
 
     Hit hit;
-    hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
+    hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
     Counters<DEBUG> cnt;
     int spill[SPILL ? kMaxStack - kLdsStack : 1];
     StackT<kBlock, SPILL> stack;
-    stack.lds = lds_column; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
+    stack.lds = lds_column; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
     for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
         trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, SPILL>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
 
@@ -538,7 +607,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
 template <bool DEBUG, bool PROF, bool ORDERED = false, bool SPILL = true>
 __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 {
-    extern __shared__ int lds_stack[];                          // [min(stack_depth, kLdsStack)][kBlock] (+ 1 int when ORDERED)
+    extern __shared__ int lds_stack[];                          // [lds_rows(stack_depth)][kBlock] (+ 2 ints when ORDERED)
 
     // Workgroup b renders tile b (row-major).  Consecutive workgroups are dealt round-robin to the 8 XCDs, so every
     // XCD sees tiles from the whole frame: measured faster than giving each XCD one contiguous band (better load
@@ -552,7 +621,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
         frame = tile % p.num_frames;
         tile = tile / p.num_frames;
         if (p.tile_order) tile = p.tile_order[tile];
-        group = (lds_int*)lds_stack + (p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack) * kBlock;
+        group = (lds_int*)lds_stack + lds_rows(p.stack_depth) * kBlock;
         if (threadIdx.x == 0) { group[0] = 0; group[1] = 0; }
         __syncthreads();                                        // (at the very start: the four waves arrive together)
     }
@@ -600,7 +669,7 @@ template <bool LOC = true, bool OCTANTS = false>           // LOC: keep the acce
 __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, Stack& stack, int& pops)
 {
     Hit hit;
-    hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
+    hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
     hit.loc = v3(0.0f, 0.0f, 0.0f);
     Counters<false> none;
     for (int i = 0; i < p.num_instances; i++)
@@ -687,7 +756,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     int spill[kMaxStack - kLdsStack];
     Stack stack;
     // (the thread's index lives on as the address of its LDS stack column only)
-    stack.lds = (lds_int*)lds_stack + threadIdx.x; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
+    stack.lds = (lds_int*)lds_stack + threadIdx.x; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
     auto where = [&](int& x_, int& ly_, int& y_, int& s_, bool& valid_) {
         asm volatile("" : "+v"(stack.lds));                     // (hides the address's origin: the optimiser would keep the first results alive)
         ex_work_item<PX>(p, tile, (int)blockIdx.y, (int)(stack.lds - (lds_int*)lds_stack), x_, ly_, y_, s_, valid_);
@@ -852,7 +921,7 @@ __global__ __launch_bounds__(kBlock, 8) void ex_wave_kernel(const RenderParams p
 
     int spill[kMaxStack - kLdsStack];
     Stack stack;
-    stack.lds = (lds_int*)lds_stack + tid; stack.spill = spill; stack.lds_depth = p.stack_depth < kLdsStack ? p.stack_depth : kLdsStack; stack.sp = 0;
+    stack.lds = (lds_int*)lds_stack + tid; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
 
     // ---- what this wave reads: GEN = its pixel quad and sample; queue launches = every fourth pass of the group's items ----
     int pass = MODE == kExGen ? 0 : wave, npass = 1, total = 0, incl = 0, count = 0;
@@ -940,7 +1009,7 @@ __global__ __launch_bounds__(kBlock, 8) void ex_wave_kernel(const RenderParams p
         }
 
         Hit hit;
-        hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f; hit.uv = make_float2(0.0f, 0.0f);
+        hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
         hit.loc = v3(0.0f, 0.0f, 0.0f);
         if (valid) {
             if constexpr (MODE == kExShadow) hit = cast_ray_ex<false>(p, org, dir, stack, pops);   // only hit-or-miss survives
@@ -1398,7 +1467,7 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     }
     p.tile_order = (mine && o->cur >= 0) ? o->d_order[o->cur] : nullptr;
     p.tile_cost = mine ? o->d_cost : nullptr;
-    const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int) + 2 * sizeof(int);
+    const size_t lds = (size_t)lds_rows(p.stack_depth) * kBlock * sizeof(int) + 2 * sizeof(int);
     if (lds_stack_suffices(p)) hipLaunchKernelGGL((render_kernel<false, false, true, false>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     else hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     RT_HIP(hipGetLastError());
@@ -1421,7 +1490,7 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     if (p.local_rows == 0) return RT_OK;
     p.tiles_x = (p.width + kTile - 1) / kTile;
     p.tiles_y = (p.local_rows + kTile - 1) / kTile;
-    const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int);
+    const size_t lds = (size_t)lds_rows(p.stack_depth) * kBlock * sizeof(int);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kBlock);
     const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
     // Heavy-first dispatch (RT_TILE_ORDER=0 turns it off): for one frame per launch with enough tiles to have a tail worth
@@ -1940,7 +2009,7 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
         }
         p.ex_acc = s->d_ex_scratch;
         // (four LDS rows per lane hold a wave's samples for the in-wave sum, whatever the depth of the stack)
-        const size_t lds = (size_t)std::max(std::min(p.stack_depth, kLdsStack), 4) * kBlock * sizeof(int);
+        const size_t lds = (size_t)std::max(lds_rows(p.stack_depth), 4) * kBlock * sizeof(int);
         for (int base = 0; base < p.spp; base += 64) {
             const int n = std::min(64, p.spp - base);
             int slots = 4;
@@ -1991,7 +2060,7 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
     }
     p.ex_acc = s->d_ex_scratch;
     p.ex_samples = s->d_ex_scratch + npix;
-    const size_t lds = (size_t)std::min(p.stack_depth, kLdsStack) * kBlock * sizeof(int);
+    const size_t lds = (size_t)lds_rows(p.stack_depth) * kBlock * sizeof(int);
     for (int base = 0; base < p.spp; base += chunk) {
         const int n = std::min(chunk, p.spp - base);
         p.sample_base = base;
