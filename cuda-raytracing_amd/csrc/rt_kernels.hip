@@ -335,6 +335,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     constexpr bool kNeedPopValue = RT_SENTINEL && RT_NEED_POP_VALUE && !EX;
     int rem = -1;                                               // triangles left in the leaf being walked, -1 = not in a leaf
     unsigned long long c_pop = 0, c_mem = 0, c_int = 0, c_leaf = 0, n_it = 0, n_int = 0, n_leaf = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    unsigned long long n_g1 = 0, n_g2 = 0, n_g34 = 0;
     // One iteration = one interior node or ONE triangle of a leaf (a leaf with k triangles takes k iterations and
     // keeps `cur` pointing at its next slot), so the loop has no inner loop and every record -- node or triangle,
     // first or later -- comes through the same fetch below.
@@ -396,6 +397,17 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             t2 = __builtin_amdgcn_s_memtime();
             n_it++; n_int += __ballot(interior) != 0; n_leaf += __ballot(!interior) != 0;
+            // how many DIFFERENT entries the wave's lanes hold in this iteration: one (the scalar-fetch case), two, three or four, more
+            {
+                unsigned long long left = __ballot(true);
+                int groups = 0;
+                while (left != 0ull && groups < 5) {
+                    const int32_t c = __shfl(cur, __ffsll((long long)left) - 1);
+                    left &= ~__ballot(cur == c);
+                    groups++;
+                }
+                n_g1 += groups == 1; n_g2 += groups == 2; n_g34 += groups == 3 || groups == 4;
+            }
         }
         if (interior) have = interior_apply<DEBUG, STK, OCT, kNeedPopValue>(r0, r1, r2, r3, r, hit.min, cur, stack, cnt);
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t3 = __builtin_amdgcn_s_memtime(); }
@@ -453,13 +465,13 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     } while (!RT_SENTINEL || cur != kSentinel);
     if constexpr (PROF) {
         if (p.trace) {                                          // the longest-lived lane's view of the wave
-            unsigned long long v[7] = {c_pop, c_mem, c_int, c_leaf, n_it, n_int, n_leaf};
+            unsigned long long v[10] = {c_pop, c_mem, c_int, c_leaf, n_it, n_int, n_leaf, n_g1, n_g2, n_g34};
             unsigned long long best = n_it;
             for (int o = 32; o > 0; o >>= 1) { unsigned long long x = __shfl_xor(best, o); best = x > best ? x : best; }
             const unsigned long long owner = __ballot(n_it == best);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)owner) - 1) {
                 unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + 4;
-                for (int k = 0; k < 7; k++) t[k] += v[k];
+                for (int k = 0; k < 10; k++) t[k] += v[k];
             }
         }
     }

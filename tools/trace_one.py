@@ -36,6 +36,10 @@ for name, pose in scenes.C2_CAMERAS.items():
             cp, cm, ci, cl, nit, nint, nleaf = [int(v) for v in t[w, 4:11]]
             print("   heavy wave: dur %.1f us iters %d (with interior lanes %d, with leaf lanes %d) cycles: pop %d fetch %d interior %d leaf %d  per-iter %.0f"
                   % (dur[w], nit, nint, nleaf, cp, cm, ci, cl, (cp + cm + ci + cl) / max(nit, 1)))
+        g = t[:, 11:14].astype(np.float64).sum(0)               # wave iterations whose lanes hold 1 / 2 / 3-4 different entries
+        n_all = float(t[:, 8].astype(np.float64).sum())
+        print("   different entries per wave iteration: one %.3f, two %.3f, three or four %.3f, more %.3f"
+              % (g[0] / n_all, g[1] / n_all, g[2] / n_all, 1.0 - g.sum() / n_all))
         tot = t[:, 4:11].astype(np.float64).sum(0)
         print("   all waves: iters %.3g (interior %.3g, leaf %.3g); cycle shares pop %.2f fetch %.2f interior %.2f leaf %.2f; cycles/iter %.0f"
               % (tot[4], tot[5], tot[6], *(tot[:4] / tot[:4].sum()), tot[:4].sum() / tot[4]))
