@@ -36,6 +36,9 @@ using namespace rt;
 #ifndef RT_STACK_WAVE_CHECK
 #define RT_STACK_WAVE_CHECK 0   // 1: push / pop ask once per wave whether any lane is beyond the LDS part of the stack (measured +0.8 %), see StackT
 #endif
+#ifndef RT_LANE_MORTON
+#define RT_LANE_MORTON 0        // 1: lanes of a wave cover their 8x8 pixels in Z-order (a quad of lanes = 2x2 pixels; measured +-0.3 %), see pixel_of
+#endif
 #ifndef RT_LEAF_FLAT
 #define RT_LEAF_FLAT 1          // leaf step without the empty-leaf region; the wave's "any accept" asked inside the leaf region
 #endif
@@ -133,7 +136,7 @@ struct Counters<false> {};
 // Per-lane traversal stack (raycast.cu:54-61).  The first `lds_depth` entries live in LDS, one column per lane
 // ([entry][kBlock] ints: a wave's accesses are conflict-free); deeper entries -- rare: the tree may be 28+ levels
 // deep but rays seldom hold more than a dozen postponed nodes -- spill to a private (scratch) array.  Keeping the
-// LDS part at 16 entries lets 8 waves/SIMD stay resident (16 KB per 256-thread workgroup).
+// LDS part at 16 entries (+ the sentinel's row) lets 8 waves/SIMD stay resident (17 KB per 256-thread workgroup, 136 of 160 KB).
 constexpr int kLdsStack = 16;
 // Two entries no tree contains: leaf references whose slot field is beyond every slot a scene can hold (rt_scene_upload and the
 // rebuild keep slot_base + n + 1 <= kSlotMask, so the largest first-slot of a leaf is kSlotMask - 2).  Chosen among the
@@ -559,8 +562,17 @@ __device__ __forceinline__ uint32_t shade(const RenderParams& p, const Hit& hit)
 __device__ __forceinline__ void pixel_of(const RenderParams& p, int tid, int x0, int y0, int& x, int& ly, int& y)
 {
     const int wave = tid >> 6, lane = tid & 63;
-    x = x0 + (wave & 1) * 8 + (lane & 7);
-    ly = y0 + (wave >> 1) * 8 + (lane >> 3);
+#if RT_LANE_MORTON
+    // Z-order inside the wave's 8x8 block: four consecutive lanes are a 2x2 block of pixels, sixteen a 4x4 block (the idea: the
+    // vector memory path coalesces the lanes of a quad that read the same line, and rays of a 2x2 block hold the same entry
+    // more often than four rays in a row).  Measured: no difference on any camera (profiles/r04_experiments/sentinel_loop_ab.log);
+    // off.  (Which lane renders which pixel changes nothing a pixel computes.)
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), lyy = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+#else
+    const int lx = lane & 7, lyy = lane >> 3;
+#endif
+    x = x0 + (wave & 1) * 8 + lx;
+    ly = y0 + (wave >> 1) * 8 + lyy;
     y = ly;                                                     // stripes: local row -> frame row (the identity for one rank)
     if (p.num_ranks != 1) y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
 }
