@@ -319,7 +319,9 @@ __device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevIn
 // COUNT: *iters counts this lane's loop iterations (the cost measure behind the heavy-first dispatch order).
 // POPS (the extension kernel): *pops counts the lane's node pops, the one visit count that kernel reports.
 // OCT >= 0: every lane of the wave is known to hold a ray of sign octant OCT that meets slab_oct's preconditions.
-template <bool DEBUG, bool PROF, bool EX, bool COUNT, class STK, bool POPS, int OCT>
+// ANYHIT (the extension's shadow rays): raycast.cu:129-133 restored -- cast_ray(..., lighting_pass = true, light_distance =
+// FLT_MAX) returns at the first accepted hit whose distance is below light_distance.
+template <bool DEBUG, bool PROF, bool EX, bool COUNT, class STK, bool POPS, int OCT, bool ANYHIT = false>
 __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInstance& in, int inst_index, const MeshRay& r,
                                            V3 org, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters, int* pops)
 {
@@ -336,6 +338,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     // "this lane must pop" as a value of `cur` instead of the flag `have`: -1.5 % on the primary kernel, +0.8 % on the bounce
     // casts of the extension kernel (EX: they keep the flag) -- profiles/r04_experiments/sentinel_loop_ab.log
     constexpr bool kNeedPopValue = RT_SENTINEL && RT_NEED_POP_VALUE && !EX;
+    static_assert(!ANYHIT || kNeedPopValue, "the early return ends a lane by handing it the sentinel: needs the value form of the pop decision");
     int rem = -1;                                               // triangles left in the leaf being walked, -1 = not in a leaf
     unsigned long long c_pop = 0, c_mem = 0, c_int = 0, c_leaf = 0, n_it = 0, n_int = 0, n_leaf = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     unsigned long long n_g1 = 0, n_g2 = 0, n_g34 = 0;
@@ -445,6 +448,9 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
             hit.u = accept ? (exact_uv ? c.uv.x : c.u) : hit.u;
             hit.v = accept ? (exact_uv ? c.uv.y : c.v) : hit.v;
             if constexpr (EX) { hit.loc.x = accept ? c.loc.x : hit.loc.x; hit.loc.y = accept ? c.loc.y : hit.loc.y; hit.loc.z = accept ? c.loc.z : hit.loc.z; }
+            // raycast.cu:129-133: `if (lighting_pass && distance < light_distance) return hit_info;` -- the lane is done with
+            // this cast: it takes the sentinel, which ends its loop at the bottom test (and cast_ray_ex skips its other instances)
+            if constexpr (ANYHIT) cur = (accept & (c.dist < FLT_MAX)) ? kSentinel : cur;
         }
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t0 = __builtin_amdgcn_s_memtime(); }
 #if RT_SENTINEL
@@ -490,7 +496,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 // cast in registers they do not have (spilled to scratch); nine loops per cast site made that worse (c3 24.9 ms against
 // 23.7 ms with the generic loop alone, profiles/r04_experiments/octants_in_extension_kernels.log), while the samples-only
 // kernel, which carries nothing, gains like the primary kernel (c4 at 16 spp: 8.27 against 8.50 ms).
-template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true>
+template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true, bool ANYHIT = false>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
                                                int* pops = nullptr)
@@ -506,7 +512,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         const int first = __builtin_amdgcn_readfirstlane(mine);
         if ((p.mesh_flags[in.mesh_index] & 1) == 0 && __ballot(!usable || mine != first) == 0ull) oct = first;
     }
-#define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops)
+#define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O, ANYHIT>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops)
     switch (oct) {                                              // (wave-uniform: a scalar branch)
     case 0: RT_TRACE_LOOP(0); break;
     case 1: RT_TRACE_LOOP(1); break;
@@ -689,15 +695,20 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 // semantics are defined in DESIGN.md section 7 (and restated by the test oracle); with spp = 1, bounces = 0, lighting = 0 the
 // result equals render_kernel's bit for bit.
 // ---------------------------------------------------------------------------------------------------------
-template <bool LOC = true, bool OCTANTS = false>           // LOC: keep the accepted hit's world location (secondary rays start there)
+// LOC: keep the accepted hit's world location (secondary rays start there).  ANYHIT: a shadow ray, cast_ray(..., true, FLT_MAX)
+// of raycast.cu:272 -- it returns at its first accepted hit (:129-133), i.e. a lane that has one (then, and only then, its
+// hit.min is below FLT_MAX) takes no part in the remaining instances.
+template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false>
 __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, Stack& stack, int& pops)
 {
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
     hit.loc = v3(0.0f, 0.0f, 0.0f);
     Counters<false> none;
-    for (int i = 0; i < p.num_instances; i++)
-        trace_instance<false, false, LOC, false, Stack, true, OCTANTS>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
+    for (int i = 0; i < p.num_instances; i++) {
+        if constexpr (ANYHIT) { if (hit.min < FLT_MAX) continue; }
+        trace_instance<false, false, LOC, false, Stack, true, OCTANTS, ANYHIT>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
+    }
     return hit;
 }
 
@@ -822,7 +833,9 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
             const float cos_illum = dot(n, sun);
             illum = (float)(0.4 * (double)cos_illum);
             if (dot(n, sun) > 0) {
-                const Hit sh = cast_ray_ex(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
+                // (only hit-or-miss survives a shadow cast: no hit location to keep.  Octant loops at either cast of this
+                // kernel: within +-0.6 %, profiles/r04_experiments/octants_in_extension_kernels.log)
+                const Hit sh = cast_ray_ex<false, false, true>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
                 if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);
             }
         }
@@ -1036,7 +1049,7 @@ __global__ __launch_bounds__(kBlock, 8) void ex_wave_kernel(const RenderParams p
         hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
         hit.loc = v3(0.0f, 0.0f, 0.0f);
         if (valid) {
-            if constexpr (MODE == kExShadow) hit = cast_ray_ex<false>(p, org, dir, stack, pops);   // only hit-or-miss survives
+            if constexpr (MODE == kExShadow) hit = cast_ray_ex<false, false, true>(p, org, dir, stack, pops);   // only hit-or-miss survives
             else hit = cast_ray_ex(p, org, dir, stack, pops);
         }
 

@@ -663,8 +663,10 @@ static __thread int32_t *g_rec_nodes = NULL;
 static void rec_step(int v) { if (g_rec && g_rec_n < g_rec_cap) g_rec[g_rec_n] = (uint8_t)(v > 255 ? 255 : v); if (g_rec) g_rec_n++; }
 static void rec_node(int node) { if (g_rec_nodes && g_rec_n < g_rec_cap) g_rec_nodes[g_rec_n] = node; }
 
-/* raycast.cu:21-142 */
-static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
+/* raycast.cu:21-142.  lighting_pass / light_distance: the reference's last two parameters (:21); they are read only by the
+ * early return of :129-133, which the snapshot carries commented out -- the extension restores it for its shadow rays
+ * (orc_render_ex), the reference path (orc_render) never sets lighting_pass. */
+static hit_t cast_ray_lp(const ray_t *ray, const OrcScene *sc, int lighting_pass, float light_distance)
 {
     hit_t hit; int mesh_idx;
     memset(&hit, 0, sizeof hit);
@@ -734,6 +736,7 @@ static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
                             hit.material = material;
                             hit.hit_instance = mesh_idx; hit.hit_triangle = index;
                             hit.hit_location = hit.location;
+                            if (lighting_pass && distance < light_distance) return hit;  /* :129-133 (commented out in the snapshot) */
                         }
                     }
                 }
@@ -742,6 +745,8 @@ static hit_t cast_ray(const ray_t *ray, const OrcScene *sc)
     }
     return hit;
 }
+
+static hit_t cast_ray(const ray_t *ray, const OrcScene *sc) { return cast_ray_lp(ray, sc, 0, FLT_MAX); }    /* the defaults of :21 */
 
 typedef struct {
     int width, height;
@@ -898,8 +903,10 @@ void orc_camera_ray(int width, int height, const float *K9, const float *D4, con
  *             /root/reference; restated from its published algorithm: Marsaglia xorwow + cuRAND's seed scramble)
  *   sample 0 uses the reference's un-jittered pixel (x, y, 1); sample s > 0 uses (x + u - .5, y + u - .5, 1)
  *   lighting = 1: raycast.cu:249-290 with the commented lines restored: sun direction normalize(-0.2, 0, 1),
- *             illum = 0.4 * cos; if the surface faces the sun, a shadow ray (full cast_ray, the early return of
- *             :129-133 stays commented out) and illum = 1.0 * cos when it escapes; then the [0.4, 1] clamp of :289-290
+ *             illum = 0.4 * cos; if the surface faces the sun, a shadow ray -- cast_ray(..., lighting_pass = true, FLT_MAX)
+ *             as written at :272, with the early return of :129-133 restored too: the cast ends at the first accepted hit
+ *             whose distance is below light_distance (any occluder will do) -- and illum = 1.0 * cos when it escapes;
+ *             then the [0.4, 1] clamp of :289-290
  *   bounces: Material::metallic is the mirror weight, Material::roughness perturbs the mirror direction
  *   secondary rays start at the ACCEPTED hit's location (the reference's hit_info.location may hold a later, rejected
  *   candidate's point because raycast.cu:98-102 run before the acceptance test at :109)
@@ -977,7 +984,7 @@ static float sun_illumination(const hit_t *hit, const OrcScene *sc, int64_t *pop
     float cos_illum = dot3(hit->normal, light_direction);                          /* :263 */
     float illum = (float)(0.4 * (double)cos_illum);                                /* :266 */
     if (dot3(hit->normal, light_direction) > 0) {                                  /* :268 */
-        hit_t sh = cast_ray(&sray, sc);                                            /* :272 */
+        hit_t sh = cast_ray_lp(&sray, sc, 1, FLT_MAX);                             /* :272: cast_ray(..., true, FLT_MAX) */
         *pops += sh.pops; *rays += 1;
         if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);           /* :276-279 */
     }
