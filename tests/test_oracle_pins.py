@@ -191,6 +191,13 @@ def test_c2_frame_pins(orc, scenes, blob70k, pins, cam):
     assert round(st["tris"] / rays, 2) == want["tris_per_ray"]
     assert st["max_stack"] == want["max_stack"]
     assert round(100.0 * st["hits"] / rays, 1) == want["coverage_pct"]
+    # bytes per ray as the survey derived them from the same run: the reference's AoS layout (section 6, to the byte) and the
+    # SoA accounting of section 8(d) that bench.py's `hbm_algorithmic` uses ("approx": two to three significant digits)
+    aos = (48 * (st["pops"] + st["aabb"]) + 76 * st["tris"]) / rays
+    assert round(aos) == want["aos_bytes_per_ray"]
+    interior = st["aabb"] // 2
+    soa = (24 * st["aabb"] + 8 * interior + 8 * (st["pops"] - interior) + 52 * st["tris"] + 24 * st["inside"] + 3 * rays) / rays
+    assert abs(soa - want["soa_bytes_per_ray_approx"]) <= 0.015 * want["soa_bytes_per_ray_approx"]
     # the planes add up to the frame totals, and equal their frozen hashes
     assert int(out["pops"].sum()) == st["pops"] and int(out["aabb"].sum()) == st["aabb"] and int(out["tris"].sum()) == st["tris"]
     _check_frozen_planes(out, pins, "C2_%s_1920x1080" % cam)
