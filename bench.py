@@ -303,14 +303,17 @@ def counters_entry(key):
 def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_frame=None, code_hash=None):
     """What bounds the kernel.  Instruction and cache-access counts per frame are properties of (code, scene, camera, size) --
     the kernel's control flow depends on nothing else -- so they come from the committed PMC pass of the same workload
-    (profiles/r03_counters.json); the time they are divided by is measured live, here.  `share` = the fraction of
+    (COUNTERS_JSON); the time they are divided by is measured live, here.  `share` = the fraction of
     every frame this rank renders.  The counters entry carries the hash of the kernel source and build flags it was taken
-    from (cuda-raytracing_amd/_build.py kernel_code_hash): when that differs from the code running now the instruction
-    count may no longer be this kernel's, so the line says `profile_stale` and prices nothing."""
+    from (cuda-raytracing_amd/_build.py kernel_code_hash); the library carries the hash it was compiled from
+    (rt_build_info): when the two differ the instruction count is not this binary's, so the line says `profile_stale` and
+    prices nothing."""
     e = counters_entry(key)
     sec = kernel_ms * 1e-3
-    now = code_hash if code_hash is not None else _build.kernel_code_hash()
-    out = {"kernel": kernel, "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch, "profile_key": key, "code_hash": now}
+    # the hash of the library that RAN (compiled into it, rt_build_info), not of the sources lying next to it
+    now = code_hash if code_hash is not None else rt.library_hash()
+    out = {"kernel": kernel, "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch, "profile_key": key, "code_hash": now,
+           "code_hash_of": "the loaded librt_hip.so (rt_build_info)", "sources_code_hash": _build.kernel_code_hash()}
     if e is None:
         out.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s", "frac": None,
                     "traffic": None, "profile_stale": False,

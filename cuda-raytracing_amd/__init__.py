@@ -60,7 +60,7 @@ class RtSceneDesc(C.Structure):
 
 # every exported symbol of include/rt_hip.h and include/rt_host.h (tests check the libraries export them all)
 RT_HIP_SYMBOLS = [
-    "rt_abi_version", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
+    "rt_abi_version", "rt_build_info", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
     "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_render", "rt_render_batch",
     "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch",
@@ -104,14 +104,42 @@ def libs():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _hip = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
-        _host = C.CDLL(HOST_SO)
-        _declare(_hip, _host)
+        # The library must be the build of the sources next to it: profiles, roofline fractions and parity claims are about
+        # one build of the kernels, and file times prove nothing (a variant copied over the shipped library is newer than
+        # every source).  A mismatch is rebuilt when the compiler is here, else refused; RT_ALLOW_VARIANT_LIB=1
+        # (tools/ab_variants.sh) loads the variant as it is -- bench.py's line then carries the variant's own hash.
+        from . import _build as _b
+        why = _b.library_mismatch(HIP_SO)
+        if why is not None and not _b.variant_allowed():
+            try:
+                _b.build()
+            except Exception as e:
+                raise RtError("%s; rebuilding failed: %s" % (why, e))
+            why = _b.library_mismatch(HIP_SO)
+            if why is not None:
+                raise RtError(why + " (after a rebuild)")
+        hip = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        host = C.CDLL(HOST_SO)
+        _declare(hip, host)
+        loaded = library_hash(hip)
+        if loaded != _b.library_code_hash(HIP_SO) or (loaded != _b.kernel_code_hash() and not _b.variant_allowed()):
+            raise RtError("the loaded librt_hip.so reports kernel code hash %s; the file holds %s and the sources hash to %s"
+                          % (loaded, _b.library_code_hash(HIP_SO), _b.kernel_code_hash()))
+        _hip, _host = hip, host
     return _hip, _host
+
+
+def library_hash(hip=None):
+    """The kernel code hash the LOADED librt_hip.so was compiled with (rt_build_info)."""
+    h = hip if hip is not None else libs()[0]
+    text = h.rt_build_info().decode()
+    return text.split("=", 1)[1] if "=" in text else text
 
 
 def _declare(h, s):
     h.rt_error_string.restype = C.c_char_p
+    h.rt_build_info.restype = C.c_char_p
+    h.rt_build_info.argtypes = []
     h.rt_error_string.argtypes = [C.c_int]
     h.rt_device_count.argtypes = [_i]
     h.rt_malloc.argtypes = [C.POINTER(_vp), C.c_size_t]

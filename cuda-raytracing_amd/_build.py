@@ -41,6 +41,43 @@ def kernel_code_hash(sources=None, flags=None):
     return h.hexdigest()[:16]
 
 
+HASH_MARKER = b"RT_CODE_HASH="
+
+
+def library_code_hash(path=None):
+    """The kernel code hash compiled into a librt_hip.so (-DRT_CODE_HASH, returned by rt_build_info()), read from the file
+    without loading it: the 16 characters after the marker.  None if the file is missing or carries no (or no single) hash."""
+    try:
+        data = open(path or HIP_SO, "rb").read()
+    except OSError:
+        return None
+    found, at = set(), data.find(HASH_MARKER)
+    while at >= 0:
+        found.add(data[at + len(HASH_MARKER):at + len(HASH_MARKER) + 16])
+        at = data.find(HASH_MARKER, at + 1)
+    if len(found) != 1:
+        return None
+    try:
+        return found.pop().decode("ascii")
+    except UnicodeDecodeError:
+        return None
+
+
+def variant_allowed():
+    """RT_ALLOW_VARIANT_LIB=1 (tools/ab_variants.sh): a librt_hip.so built from other sources or flags than the tree's is used
+    as it is; bench.py then prices nothing with the tree's PMC profile, because the line carries the LIBRARY's hash."""
+    return os.environ.get("RT_ALLOW_VARIANT_LIB", "")[:1] == "1"
+
+
+def library_mismatch(path=None):
+    """None when the library at `path` was built from the kernel sources and flags of this tree, else a sentence saying what
+    differs.  File times are not evidence: a variant copied over the shipped library is newer than every source."""
+    want, got = kernel_code_hash(), library_code_hash(path)
+    if got == want:
+        return None
+    return "%s carries kernel code hash %s, the sources in %s hash to %s" % (path or HIP_SO, got or "none", CSRC, want)
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -70,9 +107,15 @@ def build(force=False, verbose=False):
 
 
 def _build_locked(force, verbose):
-    if force or _stale(HIP_SO, HIP_DEPS):
-        # RT_HIPCC_EXTRA: extra compiler flags for A/B experiments on the kernels (e.g. -DRT_PRED_STACK=1); never set in a normal build
-        cmd = [HIPCC] + HIP_FLAGS + os.environ.get("RT_HIPCC_EXTRA", "").split() + ["-o", HIP_SO] + HIP_SRCS
+    if force or _stale(HIP_SO, HIP_DEPS) or (library_mismatch() is not None and not variant_allowed()):
+        # RT_HIPCC_EXTRA: extra compiler flags for A/B experiments on the kernels (e.g. -DRT_PRED_STACK=1); never set in a normal build.
+        # The hash of what is being compiled goes into the binary (rt_build_info): the roofline guard of bench.py and libs()
+        # check the library that runs, not the sources next to it.
+        if not os.path.exists(HIPCC):
+            raise RuntimeError("librt_hip.so is missing or was not built from this tree (%s) and %s does not exist to rebuild it"
+                               % (library_mismatch() or "stale", HIPCC))
+        cmd = [HIPCC] + HIP_FLAGS + os.environ.get("RT_HIPCC_EXTRA", "").split() + ['-DRT_CODE_HASH="%s"' % kernel_code_hash()] + \
+              ["-o", HIP_SO] + HIP_SRCS
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
@@ -87,4 +130,7 @@ def _build_locked(force, verbose):
 
 
 if __name__ == "__main__":
+    if "--print-hash" in sys.argv:                               # (CMakeLists.txt: the definition it passes to the kernels)
+        print(kernel_code_hash())
+        sys.exit(0)
     build(force="--force" in sys.argv, verbose=True)

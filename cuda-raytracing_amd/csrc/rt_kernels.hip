@@ -1556,6 +1556,17 @@ extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
 
+// the hash of the kernel sources and build flags this binary was compiled from (cuda-raytracing_amd/_build.py passes it; a
+// build by other means says so).  The text is also what _build.library_code_hash() finds in the file without loading it.
+#ifndef RT_CODE_HASH
+#define RT_CODE_HASH "built-without-it"
+#endif
+const char* rt_build_info(void)
+{
+    static const char info[] = "RT_CODE_HASH=" RT_CODE_HASH;
+    return info;
+}
+
 int rt_device_count(int* count)
 {
     if (!count) return RT_E_INVALID;

@@ -113,6 +113,11 @@ typedef struct RtScene RtScene;
 /* ---- device / memory plumbing (replaces the cudaMallocPitch / cudaMemcpy / cudaFree /
  *      cudaDeviceSynchronize calls of kernel.cu:247-253,279,299) ------------------------------ */
 int rt_abi_version(void);
+/* "RT_CODE_HASH=<16 hex digits>": the hash of the kernel sources and compiler flags this library was built from, as
+ * cuda-raytracing_amd/_build.py kernel_code_hash() computes it ("built-without-it" for a build that did not pass
+ * -DRT_CODE_HASH).  A profile or a roofline fraction describes one build of the kernels: bench.py prices its line with the hash
+ * of the library that RAN, and the Python loader refuses a library that was not built from the sources next to it. */
+const char *rt_build_info(void);
 int rt_device_count(int *count);
 int rt_set_device(int device);
 int rt_malloc(void **dptr, size_t bytes);

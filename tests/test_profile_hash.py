@@ -59,3 +59,56 @@ def test_headline_profile_is_of_the_code_in_the_tree():
     edit therefore fails here until tools/profile_bench.sh + tools/summarize_profile.py have been run on the new code."""
     table = json.load(open(os.path.join(ROOT, "profiles", "r04_counters.json")))
     assert table["c2_mid_1920x1080_1_0_0"]["code_hash"] == build.kernel_code_hash()
+
+
+def _variant_package(tmp_path):
+    """A copy of the package whose librt_hip.so carries ANOTHER kernel code hash and is newer than every source -- what
+    tools/ab_variants.sh leaves behind if it is interrupted, or a library built from an edited tree and copied in."""
+    pkg = tmp_path / "cuda-raytracing_amd"
+    shutil.copytree(os.path.join(ROOT, "cuda-raytracing_amd"), pkg, ignore=shutil.ignore_patterns("__pycache__", "_variants", ".build.lock"))
+    so = pkg / "librt_hip.so"
+    data = so.read_bytes()
+    real = build.library_code_hash()
+    assert real == build.kernel_code_hash(), "the shipped library is not the build of this tree: run __graft_entry__.build()"
+    fake = "0123456789abcdef"
+    assert data.count(build.HASH_MARKER + real.encode()) == 1
+    so.write_bytes(data.replace(build.HASH_MARKER + real.encode(), build.HASH_MARKER + fake.encode()))
+    future = os.path.getmtime(os.path.join(build.CSRC, "rt_kernels.hip")) + 3600
+    os.utime(so, (future, future))
+    os.utime(pkg / "librt_host.so", (future + 1, future + 1))
+    return pkg, fake, real
+
+
+def test_variant_library_under_fresh_sources_is_noticed(tmp_path):
+    """the guard hashed sources, and trusted the .so through file times."""
+    import subprocess
+    pkg, fake, real = _variant_package(tmp_path)
+    assert build.library_code_hash(str(pkg / "librt_hip.so")) == fake
+    why = build.library_mismatch(str(pkg / "librt_hip.so"))
+    assert why is not None and fake in why and real in why
+    prog = ("import importlib, sys; sys.path.insert(0, %r); rt = importlib.import_module('cuda-raytracing_amd'); "
+            "print('HASH', rt.library_hash())" % str(tmp_path))
+    # no compiler within reach: the loader refuses the library and says why
+    env = dict(os.environ, ROCM_PATH=str(tmp_path / "no_rocm"))
+    env.pop("RT_ALLOW_VARIANT_LIB", None)
+    r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and fake in r.stderr and real in r.stderr and "HASH" not in r.stdout, r.stderr[-2000:]
+    # the A/B switch loads it as it is, and the library reports ITS hash -- which is what bench.py prices the line with
+    r = subprocess.run([sys.executable, "-c", prog], env=dict(env, RT_ALLOW_VARIANT_LIB="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and ("HASH " + fake) in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_prices_the_line_with_the_loaded_library(monkeypatch, tmp_path):
+    import bench
+    rt = importlib.import_module("cuda-raytracing_amd")
+    h = rt.library_hash()
+    assert h == build.library_code_hash() == build.kernel_code_hash()
+    table = tmp_path / "counters.json"
+    json.dump({"k": {"tag": "t", "code_hash": h, "valu_insts_per_frame": 1.0e8, "lanes_active_per_valu": 45.0,
+                     "tcp_accesses_per_frame": 5.4e7, "hbm_bytes_per_frame": 9.0e6}}, open(table, "w"))
+    monkeypatch.setattr(bench, "COUNTERS_JSON", str(table))
+    line = bench.roofline("render_kernel", "k", 3.7, 32, 1.0)
+    assert line["code_hash"] == h and line["sources_code_hash"] == h and line["profile_stale"] is False
+    monkeypatch.setattr(rt, "library_hash", lambda hip=None: "0123456789abcdef")        # a variant library is running
+    line = bench.roofline("render_kernel", "k", 3.7, 32, 1.0)
+    assert line["code_hash"] == "0123456789abcdef" and line["profile_stale"] is True and line["frac"] is None
