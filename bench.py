@@ -401,6 +401,14 @@ def main():
                          "for an A/B of the contention between the exchange of group i and the render of group i + 1")
     ap.add_argument("--one-stream", action="store_true", help="N > 1: launch every group on the same compute stream")
     ap.add_argument("--two-streams", action="store_true", help="one GPU: alternate consecutive groups between two streams")
+    ap.add_argument("--predict-scaling", default=None, const="2,4,8", nargs="?", metavar="N[,N...]",
+                    help="one GPU: time the render side of every virtual rank of an N-GPU run (its stripes of every group of frames, on the "
+                         "pipeline's two compute streams, no exchange) and print the predicted render-side speedup per N (default 2,4,8)")
+    ap.add_argument("--no-owner-rotation", action="store_true",
+                    help="N > 1 stream workloads: every rank renders its OWN stripes of every frame (rounds 1-4) instead of the stripe owner "
+                         "rotating over the frames of a group (rt_render_stripes_batch_rotating: equal shares for all ranks)")
+    ap.add_argument("--stripe-rows", type=int, default=0,
+                    help="N > 1 and --predict-scaling: rows per stripe (stripe s belongs to rank s %% N); 0 = the default (STRIPE_ROWS)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 path (stripes, RCCL exchange, un-stripe) even with one rank: a check of that path on a one-GPU box")
     args = ap.parse_args()
@@ -414,6 +422,9 @@ def main():
     if args.steps < 1:
         sys.exit("bench.py: --steps must be at least 1")
 
+    global STRIPE_ROWS
+    if args.stripe_rows > 0:
+        STRIPE_ROWS = args.stripe_rows
     if args.rccl_max_channels > 0:                               # (before any communicator exists; inherited by the ranks self_launch starts)
         os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_channels)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -549,7 +560,11 @@ def main():
         torch.cuda.synchronize()
 
     phase("first exchange")
-    if stream_mode:
+    if args.predict_scaling is not None:
+        if dist_on:
+            sys.exit("bench.py --predict-scaling runs on one GPU (no --gpus, no --force-collective)")
+        res = predict_scaling(args, locals())
+    elif stream_mode:
         res = run_stream(args, locals())
     else:
         res = run_frames(args, locals())
@@ -634,9 +649,12 @@ def run_stream(args, env):
         local = local_dev if on_dev else [torch.zeros_like(t, device="cpu") for t in local_dev]
         gathered = gathered_dev if on_dev else [torch.empty_like(t, device="cpu") if t is not None else None for t in gathered_dev]
         local_ptrs = [tiling.batch_local_ptrs(local_dev[b].data_ptr(), F, max_rows, pitch) for b in range(2)]
-        calls = {(b, c): cams[b].prepared_batch(scene, poses[:c], local_ptrs[b][:c], pitch, stripes=(STRIPE_ROWS, rank, world))
+        # the stripe owner rotates over the frames of a group: frame f of the group is rendered as owner (rank + f) % world
+        owner_rotation = not args.no_owner_rotation
+        stripes = (STRIPE_ROWS, rank, world, 0) if owner_rotation else (STRIPE_ROWS, rank, world)
+        calls = {(b, c): cams[b].prepared_batch(scene, poses[:c], local_ptrs[b][:c], pitch, stripes=stripes)
                  for b in range(2) for c in counts}
-        timing_call = cam.prepared_batch(scene, poses, local_ptrs[0][:F], pitch, stripes=(STRIPE_ROWS, rank, world))
+        timing_call = cam.prepared_batch(scene, poses, local_ptrs[0][:F], pitch, stripes=stripes)
         group_count = [F, F]                                     # frames in the group that currently occupies buffer set b
 
         def my_frames(c):                                        # frame indices (within a group of c) this rank assembles
@@ -663,9 +681,15 @@ def run_stream(args, env):
             if not on_dev:
                 gathered_dev[b].copy_(gathered[b])
             # rank r's block holds its stripes of my frames (rotate) or of all F frame slots (root0)
-            rank_stride = (tiling.rotating_plan(group_count[b], world)[1][rank] if rotate else F) * max_rows * pitch
-            rt.check(hlib.rt_unstripe_batch(gathered_dev[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames_b[b].data_ptr(), pitch,
-                                            H * pitch, n, W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
+            plan = tiling.rotating_plan(group_count[b], world) if rotate else None
+            rank_stride = (plan[1][rank] if rotate else F) * max_rows * pitch
+            if owner_rotation:                                  # my first frame's index in the group: which owner each source rank played
+                first = plan[2][rank] if rotate else 0
+                rt.check(hlib.rt_unstripe_batch_rotating(gathered_dev[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames_b[b].data_ptr(), pitch,
+                                                         H * pitch, n, W, H, STRIPE_ROWS, world, first, torch.cuda.current_stream().cuda_stream))
+            else:
+                rt.check(hlib.rt_unstripe_batch(gathered_dev[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames_b[b].data_ptr(), pitch,
+                                                H * pitch, n, W, H, STRIPE_ROWS, world, torch.cuda.current_stream().cuda_stream))
 
         pipe = tiling.StripePipeline(render_fn, exchange_fn, unstripe_fn, assembles=rotate or rank == 0,
                                      compute_streams=cstreams, comm_stream=torch.cuda.Stream() if on_dev else None)
@@ -762,8 +786,9 @@ def run_stream(args, env):
     config = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s; every frame of a group has its own pose "
                           "(a 4 mm loop around that camera)" % (name, mesh.num_triangles, mesh.num_nodes, W, H, g["cam_name"], str(tuple(base_pose[:3]))),
               "key": g["key"] + ("_f1" if F == 1 and not dist_on else ""), "width": W, "height": H, "spp": 1, "bounces": 0, "lighting": 0,
-              "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
-                             % (STRIPE_ROWS, world, (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames) through %s" % (F, "rt_all_to_all" if g["comm"] is not None else "torch.distributed") if rotate
+              "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s%s"
+                             % (STRIPE_ROWS, world, (", the stripe owner rotating over the frames of a group" if dist_on and not args.no_owner_rotation else ""),
+                                (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames) through %s" % (F, "rt_all_to_all" if g["comm"] is not None else "torch.distributed") if rotate
                                                   else ", one RCCL gather to rank 0 per %d frames through %s" % (F, "rt_gather" if g["comm"] is not None else "torch.distributed")) if dist_on else ""),
               "frames_per_launch": F, "host_issue_ms_per_launch": round(t_issue / max(len(groups), 1) * 1e3, 3),
               "single_frame_launch_ms": None if latency is None else latency["f1_kernel_ms"], "latency": latency,
@@ -790,6 +815,136 @@ def run_stream(args, env):
         cb, ref_img = cpu_baseline_stream(g["obj"], wl, W, H, K, D, poses[0], st)
         cb["gpu_frame_matches_oracle"] = bool(np.array_equal(ref_img, dbg["img"]))
         out["cpu_baseline"] = cb
+    return out
+
+
+def scaling_prediction(t1_ms, rank_ms):
+    """One N of a prediction: t1_ms = what one GPU takes for the unit of work (a group of F frames, or one frame), rank_ms[r] =
+    what virtual rank r of N takes for ITS share of the same unit.  The N-GPU run takes as long as its slowest rank."""
+    worst, mean = max(rank_ms), sum(rank_ms) / len(rank_ms)
+    n = len(rank_ms)
+    return {"n_gpus": n, "render_ms_per_rank": [round(v, 4) for v in rank_ms], "one_gpu_ms": round(t1_ms, 4),
+            "ideal_ms": round(t1_ms / n, 4), "stripe_share_imbalance": round(worst / mean, 4),
+            "predicted_render_speedup": round(t1_ms / worst, 3), "predicted_render_efficiency": round(t1_ms / worst / n, 4)}
+
+
+def predict_scaling(args, g):
+    """The render side of an N-GPU run, measured on ONE GPU with the kernels as they are: every virtual rank r of N renders its
+    stripes exactly as rank r of a real run would (same entry points, same launches, the pipeline's two compute streams), with no
+    exchange and no un-stripe pass.  The slowest rank sets the pace of a real run, so T(one GPU) / max_r T_r bounds the speedup
+    from above; what the exchange, RCCL's kernels and the host add is not in it."""
+    W, H, K, D, pitch, scene, cam, dev = g["W"], g["H"], g["K"], g["D"], g["pitch"], g["scene"], g["cam"], g["dev"]
+    base_pose, make_camera, stream_mode = g["base_pose"], g["make_camera"], g["stream_mode"]
+    spp, bounces, lighting = g["spp"], g["bounces"], g["lighting"]
+    Ns = sorted(set(int(v) for v in args.predict_scaling.split(",") if v.strip()))
+    if not Ns or min(Ns) < 2:
+        sys.exit("bench.py --predict-scaling: a list of GPU counts >= 2")
+    out = {"metric": METRIC, "mode": "predict-scaling", "n_gpus": 1, "unit": "ms", "data": "synthetic", "dtype": "f32",
+           "code_hash": rt.library_hash(), "stripe_rows": STRIPE_ROWS, "stripe_owner_rotates_over_frames": not args.no_owner_rotation,
+           "what": "render side only, every virtual rank of N timed on one GPU through the entry points a real rank uses; "
+                   "predicted_render_speedup = one-GPU time / slowest rank's time; exchange, un-stripe and host costs are not included"}
+    cstreams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    if stream_mode:
+        F = 32
+        poses = camera_path(base_pose, F)
+        G = max(6, min(48, args.steps // F if args.steps else 24))
+        K20 = 20                                                # the driver's --steps 20: ONE group of 20 frames between synchronises
+        cams = [make_camera(cstreams[0]), make_camera(cstreams[1])]
+
+        def hold_clock(call):
+            for _ in range(max(8, MIN_WARM_FRAMES // F)):
+                call(0)
+            torch.cuda.synchronize()
+
+        def time_groups(call, groups, streams):                 # call(b) issues one group into buffer set b on cams[b]'s stream
+            hold_clock(call)
+            t0 = time.perf_counter()
+            for i in range(groups):
+                call(i % streams)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / groups
+
+        def time_single(call20, reps=9):                        # the driver's shape: one group, synchronised on both sides; median
+            hold_clock(lambda b: call20())
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                call20()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return sorted(ts)[len(ts) // 2]
+
+        # one GPU: whole frames (what `bench.py --gpus 1` times: one stream; two alternating streams beside it)
+        frames_b = [torch.empty((F, H, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+        whole = [cams[b].prepared_batch(scene, poses, [frames_b[b][f].data_ptr() for f in range(F)], pitch) for b in range(2)]
+        whole20 = cams[0].prepared_batch(scene, poses[:K20], [frames_b[0][f].data_ptr() for f in range(K20)], pitch)
+        t1_one = time_groups(lambda b: whole[0](), G, 1)
+        t1_two = time_groups(lambda b: whole[b](), G, 2)
+        t1_20 = time_single(whole20)
+        out["stream"] = {"workload": "%s, %dx%d, 1 primary ray/pixel, camera '%s'; groups of F = %d frames, each with its own pose"
+                                     % (args.workload, W, H, g["cam_name"], F),
+                         "frames_per_group": F, "groups_timed": G,
+                         "one_gpu_ms_per_group": {"one_stream": round(t1_one, 4), "two_alternating_streams": round(t1_two, 4)},
+                         "one_gpu_ms_driver_shape_20_frames": round(t1_20, 4), "per_n": [], "driver_shape_per_n": []}
+        del frames_b
+        for N in Ns:
+            max_rows = max(tiling.stripe_rows(H, STRIPE_ROWS, r, N) for r in range(N))
+            local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
+            ptrs = [tiling.batch_local_ptrs(local[b].data_ptr(), F, max_rows, pitch) for b in range(2)]
+            two, one, single, more = [], [], [], []
+            for r in range(N):
+                own = (STRIPE_ROWS, r, N) if args.no_owner_rotation else (STRIPE_ROWS, r, N, 0)
+                calls = [cams[b].prepared_batch(scene, poses, ptrs[b], pitch, stripes=own) for b in range(2)]
+                call20 = cams[0].prepared_batch(scene, poses[:K20], ptrs[0][:K20], pitch, stripes=own)
+                two.append(time_groups(lambda b: calls[b](), G, 2))
+                if os.environ.get("PREDICT_STREAMS"):            # experiment: more than two compute streams
+                    ns = int(os.environ["PREDICT_STREAMS"])
+                    xs = [torch.cuda.Stream() for _ in range(ns)]
+                    xc = [make_camera(x) for x in xs]
+                    xl = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(ns)]
+                    xcalls = [xc[b].prepared_batch(scene, poses, tiling.batch_local_ptrs(xl[b].data_ptr(), F, max_rows, pitch), pitch, stripes=own) for b in range(ns)]
+                    more.append(time_groups(lambda b: xcalls[b](), G, ns))
+                one.append(time_groups(lambda b: calls[0](), G, 1))
+                single.append(time_single(call20))
+            # the one-GPU side of the ratio is what `bench.py --gpus 1` measures (one stream); a real N-rank run renders on two
+            pn = scaling_prediction(t1_one, two)
+            pn["render_ms_per_rank_one_stream"] = [round(v, 4) for v in one]
+            pn["predicted_render_speedup_one_stream_ranks"] = round(t1_one / max(one), 3)
+            if more:
+                pn["experiment_%s_streams_ms_per_rank" % os.environ["PREDICT_STREAMS"]] = [round(v, 4) for v in more]
+            out["stream"]["per_n"].append(pn)
+            out["stream"]["driver_shape_per_n"].append(scaling_prediction(t1_20, single))
+            log("bench.py --predict-scaling: N=%d stream: %s" % (N, json.dumps(pn)))
+            del local
+        last = out["stream"]["per_n"][-1]
+        out["value"], out["predicted_for"] = last["predicted_render_speedup"], "N=%d, stream of F=%d-frame groups" % (last["n_gpus"], F)
+    else:
+        cam.set_options(spp, bounces, lighting)
+        frame = torch.empty((H, pitch), dtype=torch.uint8, device=dev)
+        reps = max(2, min(args.steps, 5))
+
+        def time_frame(call):
+            call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / reps
+        t1 = time_frame(lambda: cam.render_scene(scene, frame.data_ptr(), pitch))
+        out["frame"] = {"workload": "%s, %dx%d, %d spp, %d bounces, lighting %d, camera '%s'" % (args.workload, W, H, spp, bounces, lighting, g["cam_name"]),
+                        "frames_timed_per_figure": reps, "one_gpu_ms_per_frame": round(t1, 3), "per_n": []}
+        for N in Ns:
+            max_rows = max(tiling.stripe_rows(H, STRIPE_ROWS, r, N) for r in range(N))
+            local = torch.zeros((max_rows, pitch), dtype=torch.uint8, device=dev)
+            ranks = [time_frame(lambda r=r: cam.render_scene_stripes(scene, local.data_ptr(), pitch, STRIPE_ROWS, r, N)) for r in range(N)]
+            pn = scaling_prediction(t1, ranks)
+            out["frame"]["per_n"].append(pn)
+            log("bench.py --predict-scaling: N=%d frame: %s" % (N, json.dumps(pn)))
+        last = out["frame"]["per_n"][-1]
+        out["value"], out["predicted_for"] = last["predicted_render_speedup"], "N=%d, one frame per step" % last["n_gpus"]
+    out["higher_is_better"] = True
     return out
 
 
@@ -832,7 +987,25 @@ def measure_latency(g, poses, f32_ms_per_frame):
         singles[k]()
         singles[k + 1]()
         torch.cuda.synchronize()
+    ref_loop_one_stream = (time.perf_counter() - t0) * 1e3 / n
+    # The reference's loop as its application writes it (kernel.cu:275-279): camera.pose = ...; camera.render_scene(scene, d_img,
+    # pitch); camera.render_scene(scene, d_img2, pitch); cudaDeviceSynchronize() -- through Camera::render_scene ITSELF, on the
+    # default stream: the library lets the two frames overlap (rt_render_overlapped), nothing here helps it
+    ref_cam = rt.Camera(W, H, g["K"], g["D"])                    # (no stream set: the default stream, as in the reference)
+    ref_calls = [ref_cam.prepared_render(scene, poses[k % len(poses)], bufs[k & 1].data_ptr(), pitch) for k in range(n)]
+    for c in ref_calls[:8]:
+        c()
+    torch.cuda.synchronize()
+    hold_clock()
+    t0 = time.perf_counter()
+    for k in range(0, n, 2):
+        ref_calls[k]()
+        ref_calls[k + 1]()
+        torch.cuda.synchronize()
     ref_loop = (time.perf_counter() - t0) * 1e3 / n
+    ref_frames = {k: bufs[k & 1].cpu().numpy().reshape(H, W, 3) for k in (n - 2, n - 1)}   # the loop's last two frames (checked after the timings)
+    ov = scene.overlap_stats()
+    hold_clock()
     t0 = time.perf_counter()
     for k in range(n):
         singles[k]()
@@ -854,10 +1027,19 @@ def measure_latency(g, poses, f32_ms_per_frame):
     torch.cuda.synchronize()
     f1_two = (time.perf_counter() - t0) * 1e3 / m
     pcie = measure_download(g, poses)
+    ref_ok = True
+    for k, got in ref_frames.items():
+        cam.set_pose(poses[k % len(poses)])
+        ref_ok = ref_ok and bool(np.array_equal(got, rt.render_debug(scene, cam)["img"]))
     return {"f1_kernel_ms": round(f1, 4), "f1_launch_plus_sync_wall_ms": round(f1_sync, 4), "f2_batch_ms_per_frame": round(f2, 4),
             "pcie_inclusive": pcie,
             "f1_two_alternating_streams_wall_ms_per_frame": round(f1_two, 4),
-            "reference_loop_2_renders_per_sync_wall_ms_per_frame": round(ref_loop, 4), "f32_batch_kernel_ms_per_frame": round(f32_ms_per_frame, 4),
+            "reference_loop_2_renders_per_sync_wall_ms_per_frame": round(ref_loop, 4),
+            "reference_loop_through": "Camera::render_scene(scene, img, pitch) twice into two images on the default stream, then a device synchronise "
+                                      "(kernel.cu:277-279); the library alternates such frames between two blocking streams of its own (rt_render_overlapped)",
+            "reference_loop_frames_match_debug_kernel": ref_ok,
+            "reference_loop_overlapped_launches": ov[0], "reference_loop_cross_stream_waits": ov[1],
+            "reference_loop_one_stream_wall_ms_per_frame": round(ref_loop_one_stream, 4), "f32_batch_kernel_ms_per_frame": round(f32_ms_per_frame, 4),
             "note": "kernel ms = hipEvents around back-to-back launches on one stream; wall ms include launch and hipDeviceSynchronize"}
 
 

@@ -62,8 +62,8 @@ class RtSceneDesc(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_build_info", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_render", "rt_render_batch",
-    "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_unstripe", "rt_unstripe_batch",
+    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_render", "rt_render_overlapped", "rt_render_overlapped_stats", "rt_render_batch",
+    "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_render_stripes_batch_rotating", "rt_unstripe", "rt_unstripe_batch", "rt_unstripe_batch_rotating",
     "rt_comm_available", "rt_comm_last_error", "rt_comm_last_error_any", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_info", "rt_comm_destroy",
     "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
     "rt_timer_elapsed_ms", "rt_timer_destroy"]
@@ -74,7 +74,7 @@ RT_HOST_SYMBOLS = [
     "rth_scene_set_material_params", "rth_scene_add_mesh", "rth_scene_add_mesh_instance", "rth_scene_upload_to_device", "rth_scene_update_mesh_instance", "rth_scene_update_mesh_instance_async", "rth_scene_refit_mesh", "rth_scene_rebuild_mesh",
     "rth_scene_num_mesh_instances", "rth_scene_device_handle", "rth_instance_build", "rth_camera_create", "rth_camera_free",
     "rth_camera_set_pose", "rth_camera_set_stream", "rth_camera_render_scene", "rth_camera_render_scene_stripes",
-    "rth_camera_render_scene_tiled", "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_set_options",
+    "rth_camera_render_scene_tiled", "rth_camera_render_scene_batch", "rth_camera_render_scene_stripes_batch", "rth_camera_render_scene_stripes_batch_rotating", "rth_camera_set_options",
     "rth_camera_render_scene_ex", "rth_xorwow", "rth_save_png", "rth_write_png_bgr",
     "rth_read_image_bgr", "rth_zlib_inflate", "rth_overlay_text_bgr", "rth_display_image", "rth_on_mouse", "rth_on_key",
     "rth_camera_params", "rth_q_rsqrt", "rth_atanf", "rth_normalize", "rth_invert_lre", "rth_apply_lre", "rth_euler2quat",
@@ -160,6 +160,8 @@ def _declare(h, s):
     h.rt_scene_debug_read.argtypes = [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
     h.rt_scene_destroy.argtypes = [_vp]
     h.rt_render.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, C.c_int]
+    h.rt_render_overlapped.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t]
+    h.rt_render_overlapped_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
     h.rt_render_ids.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, _vp, _vp, C.c_int]
     h.rt_stripe_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i]
@@ -167,6 +169,8 @@ def _declare(h, s):
     h.rt_unstripe.argtypes = [_vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp]
     h.rt_unstripe_batch.argtypes = [_vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, _vp]
+    h.rt_unstripe_batch_rotating.argtypes = [_vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_int32, _vp]
     _sz = C.POINTER(C.c_size_t)
     h.rt_comm_last_error.restype = C.c_char_p
     h.rt_comm_available.argtypes = [_i]
@@ -230,6 +234,8 @@ def _declare(h, s):
     s.rth_camera_render_scene_batch.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int]
     s.rth_camera_render_scene_stripes_batch.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
                                                         C.c_int32, C.c_int]
+    s.rth_camera_render_scene_stripes_batch_rotating.argtypes = [_vp, _vp, _f, C.POINTER(_vp), C.c_size_t, C.c_int32, C.c_int32, C.c_int32,
+                                                                 C.c_int32, C.c_int32, C.c_int]
     s.rth_camera_params.argtypes = [_vp, _vp]
     s.rth_scene_set_material_params.argtypes = [_vp, C.c_int32, C.c_float, C.c_float, C.c_float]
     s.rth_camera_set_options.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32]
@@ -409,6 +415,12 @@ class Scene:
     def device_handle(self):
         return libs()[1].rth_scene_device_handle(self.h)
 
+    def overlap_stats(self):
+        """(frames that went through rt_render_overlapped, those that had to wait for the other stream)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(libs()[0].rt_render_overlapped_stats(self.device_handle, C.byref(a), C.byref(b)), "rt_render_overlapped_stats")
+        return a.value, b.value
+
     def info(self):
         b = C.c_size_t(0)
         d = C.c_int32(0)
@@ -448,6 +460,22 @@ class Camera:
     def render_scene(self, scene, d_img, pitch, synchronize=False):
         check(libs()[1].rth_camera_render_scene(self.h, scene.h, d_img, pitch, 1 if synchronize else 0), "Camera::render_scene")
 
+    def prepared_render(self, scene, pose, d_img, pitch):
+        """A zero-argument callable for `camera.pose = pose; camera.render_scene(scene, d_img, pitch)` -- the reference's own
+        per-frame calls (kernel.cu:275-278) -- with the ctypes arguments built once."""
+        host, cam_h, scene_h = libs()[1], self.h, scene.h
+        P = _fa(pose)
+        Pp, ptr = _fp(P), _vp(int(d_img))
+        set_pose, render = host.rth_camera_set_pose, host.rth_camera_render_scene
+
+        def call():
+            set_pose(cam_h, Pp)
+            rc = render(cam_h, scene_h, ptr, pitch, 0)
+            if rc:
+                check(rc, "Camera::render_scene")
+        call._keep = (P,)
+        return call
+
     def render_scene_stripes(self, scene, d_local, local_pitch, stripe_rows, rank, num_ranks, synchronize=False):
         check(libs()[1].rth_camera_render_scene_stripes(self.h, scene.h, d_local, local_pitch, stripe_rows, rank, num_ranks,
                                                         1 if synchronize else 0), "Camera::render_scene_stripes")
@@ -475,7 +503,8 @@ class Camera:
     def prepared_batch(self, scene, poses, d_ptrs, pitch, stripes=None):
         """A zero-argument callable that issues one batched launch with pre-built ctypes arguments (the per-call Python
         overhead matters when a rank's share of a frame takes tens of microseconds).  stripes = (stripe_rows, rank,
-        num_ranks) renders this rank's stripes, None renders whole frames."""
+        num_ranks) renders this rank's stripes, (stripe_rows, rank, num_ranks, first_frame) with the stripe owner rotating over
+        the frames (frame i renders owner (rank + first_frame + i) % num_ranks), None renders whole frames."""
         n = len(poses)
         P = _fa(np.asarray(poses, np.float32).reshape(n, 6))
         ptrs = (_vp * n)(*[int(x) if not isinstance(x, _vp) else x.value for x in d_ptrs])
@@ -487,6 +516,14 @@ class Camera:
                 rc = fn(cam_h, scene_h, Pp, ptrs, pitch, n, 0)
                 if rc:
                     check(rc, "Camera::render_scene_batch")
+        elif len(stripes) == 4:
+            fn = host.rth_camera_render_scene_stripes_batch_rotating
+            sr, rk, nr, first = stripes
+
+            def call():
+                rc = fn(cam_h, scene_h, Pp, ptrs, pitch, n, sr, rk, nr, first, 0)
+                if rc:
+                    check(rc, "Camera::render_scene_stripes_batch (rotating owner)")
         else:
             fn = host.rth_camera_render_scene_stripes_batch
             sr, rk, nr = stripes
@@ -498,10 +535,15 @@ class Camera:
         call._keep = (P, ptrs)
         return call
 
-    def render_scene_stripes_batch(self, scene, poses, d_locals, local_pitch, stripe_rows, rank, num_ranks, synchronize=False):
+    def render_scene_stripes_batch(self, scene, poses, d_locals, local_pitch, stripe_rows, rank, num_ranks, synchronize=False, rotate_first=None):
         n = len(poses)
         P = _fa(np.asarray(poses, np.float32).reshape(n, 6))
         ptrs = (_vp * n)(*[int(x) if not isinstance(x, _vp) else x.value for x in d_locals])
+        if rotate_first is not None:
+            check(libs()[1].rth_camera_render_scene_stripes_batch_rotating(self.h, scene.h, _fp(P), ptrs, local_pitch, n, stripe_rows, rank,
+                                                                           num_ranks, rotate_first, 1 if synchronize else 0),
+                  "Camera::render_scene_stripes_batch (rotating owner)")
+            return
         check(libs()[1].rth_camera_render_scene_stripes_batch(self.h, scene.h, _fp(P), ptrs, local_pitch, n, stripe_rows, rank,
                                                               num_ranks, 1 if synchronize else 0), "Camera::render_scene_stripes_batch")
 

@@ -40,8 +40,10 @@ public:
     // `count` frames (<= RT_MAX_BATCH) along a camera path in one launch: frame i uses poses[i] (K, D, size from
     // this camera) and goes to img_ptrs[i]; see rt_render_batch in rt_hip.h
     void render_scene_batch(Scene& scene, const lre* poses, int count, uchar3* const* img_ptrs, size_t pitch, bool synchronize = false);
+    // rotate_first >= 0: the stripe owner rotates with the frame index -- frame i renders the stripes of owner
+    // (rank + rotate_first + i) % num_ranks, so that every rank's share of a group of frames is the same (rt_hip.h)
     void render_scene_stripes_batch(Scene& scene, const lre* poses, int count, uchar3* const* local_ptrs, size_t local_pitch,
-                                    int stripe_rows, int rank, int num_ranks, bool synchronize = false);
+                                    int stripe_rows, int rank, int num_ranks, bool synchronize = false, int rotate_first = -1);
     // One frame tiled over the GPUs of `comm` (rt_comm_init_rank / rt_comm_init_all, rt_hip.h): every rank calls this with
     // its own replica of the scene; the frame arrives in img_ptr on rank `root` (img_ptr may be null elsewhere).
     // Honours spp / bounces / lighting like render_scene.  The multi-GPU form of Camera.cu:18-41.

@@ -591,7 +591,10 @@ void Camera::render_scene(Scene& scene, uchar3* img_ptr, size_t pitch, bool sync
 {
     if (spp != 1 || bounces != 0 || lighting) { render_scene_ex(scene, img_ptr, pitch, nullptr, synchronize); return; }
     RtCameraParams p = camera_params(*this, pose);
-    last_error = rt_render(scene.d_scene, &p, (uint8_t*)img_ptr, pitch, stream, synchronize ? 1 : 0);
+    // The reference's call shape -- asynchronous, default stream, two images per synchronise (kernel.cu:277-279) -- keeps its
+    // default-stream ordering and lets frames into different images overlap (rt_render_overlapped, rt_hip.h)
+    if (stream == nullptr && !synchronize) last_error = rt_render_overlapped(scene.d_scene, &p, (uint8_t*)img_ptr, pitch);
+    else last_error = rt_render(scene.d_scene, &p, (uint8_t*)img_ptr, pitch, stream, synchronize ? 1 : 0);
 }
 
 void Camera::render_scene_ex(Scene& scene, uchar3* img_ptr, size_t pitch, int* d_total_pops, bool synchronize)
@@ -634,13 +637,17 @@ void Camera::render_scene_batch(Scene& scene, const lre* poses, int count, uchar
 }
 
 void Camera::render_scene_stripes_batch(Scene& scene, const lre* poses, int count, uchar3* const* local_ptrs, size_t local_pitch,
-                                        int stripe_rows, int rank, int num_ranks, bool synchronize)
+                                        int stripe_rows, int rank, int num_ranks, bool synchronize, int rotate_first)
 {
     if (count < 1 || count > RT_MAX_BATCH || !poses || !local_ptrs) { last_error = RT_E_INVALID; return; }
     RtCameraParams p[RT_MAX_BATCH];
     for (int i = 0; i < count; i++) p[i] = camera_params(*this, poses[i]);
-    last_error = rt_render_stripes_batch(scene.d_scene, p, (uint8_t* const*)local_ptrs, local_pitch, count, stripe_rows, rank,
-                                         num_ranks, stream, synchronize ? 1 : 0);
+    if (rotate_first >= 0)
+        last_error = rt_render_stripes_batch_rotating(scene.d_scene, p, (uint8_t* const*)local_ptrs, local_pitch, count, stripe_rows, rank,
+                                                      num_ranks, rotate_first, stream, synchronize ? 1 : 0);
+    else
+        last_error = rt_render_stripes_batch(scene.d_scene, p, (uint8_t* const*)local_ptrs, local_pitch, count, stripe_rows, rank,
+                                             num_ranks, stream, synchronize ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------- PNG out

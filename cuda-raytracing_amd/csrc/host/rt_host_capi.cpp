@@ -244,6 +244,17 @@ int rth_camera_render_scene_stripes_batch(RthCamera* c, RthScene* s, const float
                                       synchronize != 0);
     return c->cam.last_error;
 }
+int rth_camera_render_scene_stripes_batch_rotating(RthCamera* c, RthScene* s, const float* poses6, void* const* d_locals, size_t local_pitch,
+                                                   int32_t count, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t first_frame,
+                                                   int synchronize)
+{
+    if (count < 1 || count > RT_MAX_BATCH || first_frame < 0) return RT_E_INVALID;
+    lre poses[RT_MAX_BATCH];
+    for (int i = 0; i < count; i++) poses[i] = LRE(poses6 + 6 * i);
+    c->cam.render_scene_stripes_batch(s->scene, poses, count, (uchar3* const*)d_locals, local_pitch, stripe_rows, rank, num_ranks,
+                                      synchronize != 0, first_frame);
+    return c->cam.last_error;
+}
 void rth_camera_params(const RthCamera* c, void* out)
 {
     RtCameraParams p;

@@ -66,7 +66,7 @@ struct DevMaterial {            // Material.hpp:6-16
 constexpr int kExMaxGroup = 32;
 constexpr int kExPlanesA = 5, kExPlanesS = 7;
 
-constexpr int kMaxBatch = 32;   // frames per launch (rt_render_batch); 32 x 88 B of per-frame parameters keep the kernel
+constexpr int kMaxBatch = 32;   // frames per launch (rt_render_batch); 32 x 96 B of per-frame parameters keep the kernel
                                 // arguments under the 4 KB limit
 
 struct FrameParams {            // what differs between the frames of one batched launch
@@ -75,6 +75,10 @@ struct FrameParams {            // what differs between the frames of one batche
     float origin[3];
     Q4 q_cam;                   // euler2quat(inv_camera_pose ypr), raycast.cu:185
     uint8_t* img;
+    // stripes: whose stripes this frame's launch renders and how many rows they have.  Both are the launch's own (RenderParams::rank,
+    // local_rows) unless the stripe owner ROTATES with the frame index (rt_render_stripes_batch_rotating): a rank then renders every
+    // stripe class in turn, so the ranks' shares of a group of frames are equal whatever the frame shows
+    int32_t rank, local_rows;
 };
 
 struct RenderParams {
@@ -92,7 +96,7 @@ struct RenderParams {
     int32_t stack_depth;        // LDS stack entries per lane
     uint64_t pitch;
     // stripes: local row ly is frame row ((ly / stripe_rows) * num_ranks + rank) * stripe_rows + ly % stripe_rows
-    int32_t local_rows, stripe_rows, rank, num_ranks;
+    int32_t local_rows, stripe_rows, rank, num_ranks;   // (local_rows = the most rows any frame of the launch has: the grid's height)
     int32_t tiles_x, tiles_y;   // 16x16-pixel workgroup tiles over width x local_rows
     unsigned long long* trace;  // diagnostics: per-wave {start, end, hw id, tile} stamps, or null
     // single-frame launches (render_kernel<.., ORDERED>): heavy-tiles-first dispatch from the previous frame's costs

@@ -565,7 +565,7 @@ __device__ __forceinline__ uint32_t shade(const RenderParams& p, const Hit& hit)
 
 // pixel of thread `tid` in the 16x16 tile at (x0, y0): a wave64 is an 8x8-pixel block (neighbouring rays walk the same nodes:
 // L1 hits, little divergence).  (x, ly) = column and LOCAL row; y = frame row (they differ only when rendering stripes).
-__device__ __forceinline__ void pixel_of(const RenderParams& p, int tid, int x0, int y0, int& x, int& ly, int& y)
+__device__ __forceinline__ void pixel_of(const RenderParams& p, const FrameParams& f, int tid, int x0, int y0, int& x, int& ly, int& y)
 {
     const int wave = tid >> 6, lane = tid & 63;
 #if RT_LANE_MORTON
@@ -580,7 +580,7 @@ __device__ __forceinline__ void pixel_of(const RenderParams& p, int tid, int x0,
     x = x0 + (wave & 1) * 8 + lx;
     ly = y0 + (wave >> 1) * 8 + lyy;
     y = ly;                                                     // stripes: local row -> frame row (the identity for one rank)
-    if (p.num_ranks != 1) y = ((ly / p.stripe_rows) * p.num_ranks + p.rank) * p.stripe_rows + ly % p.stripe_rows;
+    if (p.num_ranks != 1) y = ((ly / p.stripe_rows) * p.num_ranks + f.rank) * p.stripe_rows + ly % p.stripe_rows;
 }
 
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
@@ -589,7 +589,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
                                              int* iters = nullptr)
 {
     int x, ly, y;
-    pixel_of(p, (int)(lds_column - lds_base), x0, y0, x, ly, y);
+    pixel_of(p, f, (int)(lds_column - lds_base), x0, y0, x, ly, y);
     const V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     const V3 dir = camera_direction(f, (float)x, (float)y);
 
@@ -607,7 +607,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     // the lane's LDS stack column.  (The empty asm hides that address's origin from the optimiser, which would otherwise
     // recognise the recomputation and keep the first copies alive.)
     asm volatile("" : "+v"(lds_column));
-    pixel_of(p, (int)(lds_column - lds_base), x0, y0, x, ly, y);
+    pixel_of(p, f, (int)(lds_column - lds_base), x0, y0, x, ly, y);
     const uint32_t px = shade(p, hit);
     uint8_t* out = f.img + (size_t)ly * p.pitch + 3 * (size_t)x;
     out[0] = (uint8_t)px; out[1] = (uint8_t)(px >> 8); out[2] = (uint8_t)(px >> 16);
@@ -663,8 +663,8 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
     lds_int* column = (lds_int*)lds_stack + threadIdx.x;
     {
         int x, ly, y;
-        pixel_of(p, (int)threadIdx.x, tx * kTile, ty * kTile, x, ly, y);
-        if (x < p.width && ly < p.local_rows)
+        pixel_of(p, p.frames[frame], (int)threadIdx.x, tx * kTile, ty * kTile, x, ly, y);
+        if (x < p.width && ly < p.frames[frame].local_rows)
             render_pixel<DEBUG, PROF, ORDERED, SPILL>(p, p.frames[frame], tx * kTile, ty * kTile, (lds_int*)lds_stack, column, &iters);
     }
     asm volatile("" : "+v"(column));
@@ -1186,14 +1186,18 @@ __global__ void resolve_ex_kernel(const RenderParams p, int count, int first, in
 template <class T>
 __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
                                 uint8_t* __restrict__ dst, size_t pitch, size_t dst_frame_stride, int row_units, int height,
-                                int stripe_rows, int num_ranks)
+                                int stripe_rows, int num_ranks, int rotate_first)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // unit i of the frame: row i / row_units
     const int y = (int)(i / (size_t)row_units), u = (int)(i % (size_t)row_units);
     if (y >= height) return;
     src += (size_t)blockIdx.z * src_frame_stride;               // blockIdx.z = frame of the batch
     dst += (size_t)blockIdx.z * dst_frame_stride;
-    const int stripe = y / stripe_rows, rank = stripe % num_ranks;
+    const int stripe = y / stripe_rows;
+    int rank = stripe % num_ranks;                              // the stripe's owner ...
+    // ... which, when ownership rotates with the frame index (rt_render_stripes_batch_rotating), rank r plays for frame index fi
+    // iff (r + fi) % num_ranks == owner
+    if (rotate_first >= 0) rank = (rank + num_ranks - (rotate_first + (int)blockIdx.z) % num_ranks) % num_ranks;
     const int ly = (stripe / num_ranks) * stripe_rows + y % stripe_rows;
     const T* s = (const T*)(src + (size_t)rank * rank_stride + (size_t)ly * local_pitch);
     T* d = (T*)(dst + (size_t)y * pitch);
@@ -1201,40 +1205,65 @@ __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pi
 }
 
 // Heavy-first dispatch order of the next single-frame launch: a counting sort of the tiles by the lifetime their workgroup
-// had in the last frame (its longest lane's iteration count, longest first), by one 256-thread workgroup.  Each cost is read ONCE (a render
-// on another stream may be rewriting the array): whatever the values, the result is a permutation of the tiles.
-constexpr int kSortKeys = 1024, kSortThreads = 256;           // (four waves: finds room on a CU while a render kernel fills the chip)
+// had in the last frame (its longest lane's iteration count, longest first), by ONE workgroup of 1024 threads.  Each cost is read
+// ONCE (a render on another stream may be rewriting the array): whatever the values, the result is a permutation of the tiles.
+// The sort runs on the scene's side stream, but a hipDeviceSynchronize waits for it like for everything else -- the
+// reference's loop synchronises the device every two frames (kernel.cu:279) -- so it has to be short: every thread loads
+// eight costs before it touches any of them (one memory latency per 8192 tiles instead of one per 256; round 4's 256-thread
+// form took 30-50 us for the 8160 tiles of a 1080p frame, this one a fifth of that).
+constexpr int kSortKeys = 1024, kSortThreads = 1024, kSortBatch = 8;
 __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int32_t* __restrict__ cost, int ntiles, int32_t* __restrict__ keys,
                                                                  int32_t* __restrict__ order)
 {
-    __shared__ int count[kSortKeys], start[kSortKeys], partial[kSortThreads];
+    static_assert(kSortKeys == kSortThreads, "one class per thread in the scan below");
+    __shared__ int count[kSortKeys], scan[kSortThreads];
     const int t = threadIdx.x;
-    for (int k = t; k < kSortKeys; k += kSortThreads) count[k] = 0;
+    count[t] = 0;
     __syncthreads();
-    for (int i = t; i < ntiles; i += kSortThreads) {
-        int k = cost[i];                                        // iterations of the tile's longest lane (a few hundred at most)
-        k = k < 0 ? 0 : (k > kSortKeys - 1 ? kSortKeys - 1 : k);
-        k = kSortKeys - 1 - k;                                  // longest first
-        keys[i] = k;
-        atomicAdd(&count[k], 1);
+    for (int base = 0; base < ntiles; base += kSortThreads * kSortBatch) {
+        int k[kSortBatch];
+#pragma unroll
+        for (int j = 0; j < kSortBatch; j++) {
+            const int i = base + j * kSortThreads + t;
+            k[j] = i < ntiles ? cost[i] : -1;                   // iterations of the tile's longest lane (a few hundred at most)
+        }
+#pragma unroll
+        for (int j = 0; j < kSortBatch; j++) {
+            const int i = base + j * kSortThreads + t;
+            if (i < ntiles) {
+                int c = k[j] < 0 ? 0 : (k[j] > kSortKeys - 1 ? kSortKeys - 1 : k[j]);
+                c = kSortKeys - 1 - c;                          // longest first
+                keys[i] = c;
+                atomicAdd(&count[c], 1);
+            }
+        }
     }
     __syncthreads();
-    // exclusive prefix over the classes: each thread owns kSortKeys / kSortThreads consecutive classes
-    constexpr int kPer = kSortKeys / kSortThreads;
-    int sum = 0;
-    for (int j = 0; j < kPer; j++) sum += count[t * kPer + j];
-    partial[t] = sum;
+    // exclusive prefix over the classes (Hillis-Steele on the inclusive sums): count[] becomes the running cursor of each class
+    const int mine = count[t];
+    scan[t] = mine;
     __syncthreads();
-    for (int o = 1; o < kSortThreads; o <<= 1) {                // inclusive scan (Hillis-Steele)
-        const int v = t >= o ? partial[t - o] : 0;
+    for (int o = 1; o < kSortThreads; o <<= 1) {
+        const int v = t >= o ? scan[t - o] : 0;
         __syncthreads();
-        partial[t] += v;
+        scan[t] += v;
         __syncthreads();
     }
-    int base = partial[t] - sum;
-    for (int j = 0; j < kPer; j++) { start[t * kPer + j] = base; base += count[t * kPer + j]; }     // running cursor of each class
+    count[t] = scan[t] - mine;
     __syncthreads();
-    for (int i = t; i < ntiles; i += kSortThreads) order[atomicAdd(&start[keys[i]], 1)] = i;
+    for (int base = 0; base < ntiles; base += kSortThreads * kSortBatch) {
+        int k[kSortBatch];
+#pragma unroll
+        for (int j = 0; j < kSortBatch; j++) {
+            const int i = base + j * kSortThreads + t;
+            k[j] = i < ntiles ? keys[i] : 0;                    // (this thread's own stores of the first pass)
+        }
+#pragma unroll
+        for (int j = 0; j < kSortBatch; j++) {
+            const int i = base + j * kSortThreads + t;
+            if (i < ntiles) order[atomicAdd(&count[k[j]], 1)] = i;
+        }
+    }
 }
 
 // ---- refit of a deforming mesh (rt_scene_refit_mesh): same topology, new vertex positions ----------------------------
@@ -1403,6 +1432,7 @@ int fill_params(RenderParams& p, const RtScene* s, const RtCameraParams* cams, u
         f.origin[0] = cam->camera_pose[0]; f.origin[1] = cam->camera_pose[1]; f.origin[2] = cam->camera_pose[2];
         f.q_cam = euler2quat(v3(cam->inv_camera_pose[3], cam->inv_camera_pose[4], cam->inv_camera_pose[5]));
         f.img = d_imgs[i];
+        f.rank = 0; f.local_rows = p.height;
     }
     p.records = s->d_records; p.tri_uv = s->d_tri_uv; p.tri_id = s->d_tri_id;
     p.leaf_count = s->d_leaf_count; p.mesh_flags = s->d_mesh_flags;
@@ -1474,7 +1504,7 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
             if (order_state_idle(*lru)) {
                 (void)hipFree(lru->d_cost);
                 lru->d_cost = lru->d_keys = lru->d_order[0] = lru->d_order[1] = nullptr;
-                lru->tiles_x = lru->tiles_y = lru->ntiles = 0; lru->cur = -1; lru->pending = false;
+                lru->tiles_x = lru->tiles_y = lru->ntiles = 0; lru->cur = -1; lru->pending = false; lru->launches = lru->sorted_at = 0;
                 for (auto& e : lru->seen) e.used = false;
                 o = lru;
             }
@@ -1509,7 +1539,13 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     else hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     RT_HIP(hipGetLastError());
     if (mine) RT_HIP(hipEventRecord(mine->done, stream));
-    if (mine && !o->pending) {
+    // A new order every kSortInterval-th ordered launch of this frame size (and for the first ones): the costs of a frame a few
+    // frames back order the tiles as well as the last frame's, and a device-wide synchronise right after a launch (the
+    // reference's loop: every two frames) then rarely finds a sort still queued behind the frame it waited for.
+    static const int interval = [] { const char* e = getenv("RT_TILE_SORT_INTERVAL"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+    o->launches++;
+    if (mine && !o->pending && (o->cur < 0 || o->launches - o->sorted_at >= (uint64_t)interval)) {
+        o->sorted_at = o->launches;
         o->target = o->cur < 0 ? 0 : o->cur ^ 1;
         for (auto& e : o->seen) if (e.used) RT_HIP(hipStreamWaitEvent(cache.sort_stream, e.done, 0));
         hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, cache.sort_stream, o->d_cost, ntiles, o->d_keys, o->d_order[o->target]);
@@ -1948,6 +1984,10 @@ int rt_scene_debug_read(RtScene* s, int32_t which, void* host_dst, size_t capaci
 int rt_scene_destroy(RtScene* s)
 {
     if (!s) return RT_OK;
+    for (int k = 0; k < 2; k++) {
+        if (s->overlap.stream[k]) { (void)hipStreamSynchronize(s->overlap.stream[k]); (void)hipStreamDestroy(s->overlap.stream[k]); }
+        if (s->overlap.done[k]) (void)hipEventDestroy(s->overlap.done[k]);
+    }
     if (s->order.sort_stream) (void)hipStreamSynchronize(s->order.sort_stream);
     for (auto& o : s->order.entry) {
         if (o.sort_done) { (void)hipEventDestroy(o.sort_done); for (auto& e : o.seen) (void)hipEventDestroy(e.done); }
@@ -1992,6 +2032,74 @@ int rt_render_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_im
 int rt_render(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, void* stream, int synchronize)
 {
     return rt_render_batch(s, cam, &d_img, pitch, 1, stream, synchronize);
+}
+
+// Camera::render_scene(scene, img, pitch, synchronize = false) on the default stream (Camera.cu:18-41) -- see rt_hip.h.
+int rt_render_overlapped(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch)
+{
+    RenderParams p;
+    int rc = fill_params(p, s, cam, &d_img, 1, pitch);
+    if (rc) return rc;
+    static const bool enabled = [] { const char* e = getenv("RT_RENDER_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (!enabled) return launch(p, false, nullptr, 0, s);
+    RtScene::Overlap& ov = s->overlap;
+    std::lock_guard<std::mutex> lock(ov.m);
+    if (!ov.stream[0]) {
+        // hipStreamDefault = a BLOCKING stream: work on the null stream waits for everything issued here before it, and
+        // everything issued here waits for earlier null-stream work -- the ordering a default-stream launch has with the
+        // caller's copies, memsets, instance updates and hipDeviceSynchronize
+        hipStream_t st[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipError_t e = hipStreamCreateWithFlags(&st[0], hipStreamDefault);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[1], hipStreamDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int k = 0; k < 2; k++) { if (st[k]) (void)hipStreamDestroy(st[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
+            return (int)e;
+        }
+        for (int k = 0; k < 2; k++) { ov.stream[k] = st[k]; ov.done[k] = ev[k]; }
+    }
+    const RtScene::Overlap::Range r{(uintptr_t)d_img, (uintptr_t)d_img + (size_t)(p.height - 1) * pitch + (size_t)p.width * 3};
+    auto meets = [&](const std::vector<RtScene::Overlap::Range>& v) {
+        for (const auto& w : v) if (w.lo < r.hi && r.lo < w.hi) return true;
+        return false;
+    };
+    int use = ov.next, other = use ^ 1;
+    const bool hit_other = meets(ov.written[other]);
+    if (hit_other && !meets(ov.written[use])) {
+        std::swap(use, other);                                  // same image as the frame in flight over there: stream order does it
+    } else if (hit_other) {
+        RT_HIP(hipEventRecord(ov.done[other], ov.stream[other]));          // (recorded when it is needed: after everything issued there so far)
+        RT_HIP(hipStreamWaitEvent(ov.stream[use], ov.done[other], 0));
+        ov.written[other].clear();                              // everything issued there so far is now ordered before this stream's next work
+        ov.waits++;
+    }
+    rc = launch(p, false, ov.stream[use], 0, s);
+    if (rc) return rc;
+    std::vector<RtScene::Overlap::Range>& mine = ov.written[use];
+    bool known = false;
+    for (const auto& w : mine) known = known || (w.lo == r.lo && w.hi == r.hi);
+    if (!known) {
+        if (mine.size() >= 8) {                                 // an application cycling through many images: one hull (may over-order, never under)
+            RtScene::Overlap::Range hull = r;
+            for (const auto& w : mine) { hull.lo = std::min(hull.lo, w.lo); hull.hi = std::max(hull.hi, w.hi); }
+            mine.assign(1, hull);
+        } else {
+            mine.push_back(r);
+        }
+    }
+    ov.launches++;
+    ov.next = use ^ 1;
+    return RT_OK;
+}
+
+int rt_render_overlapped_stats(const RtScene* s, uint64_t* launches, uint64_t* cross_stream_waits)
+{
+    if (!s) return RT_E_INVALID;
+    if (launches) *launches = s->overlap.launches;
+    if (cross_stream_waits) *cross_stream_waits = s->overlap.waits;
+    return RT_OK;
 }
 
 int rt_render_ids(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, int32_t* d_hit_instance,
@@ -2188,6 +2296,7 @@ int rt_render_ex_stripes(RtScene* s, const RtCameraParams* cam, const RtRenderOp
     int32_t rows = 0;
     if ((rc = rt_stripe_rows(p.height, stripe_rows, rank, num_ranks, &rows))) return rc;
     p.local_rows = rows; p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
+    p.frames[0].rank = rank; p.frames[0].local_rows = rows;
     return launch_ex(s, p, opts, nullptr, (hipStream_t)stream, synchronize);
 }
 
@@ -2201,16 +2310,39 @@ int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t nu
     return RT_OK;
 }
 
-int rt_render_stripes_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_locals, size_t local_pitch, int32_t count,
-                            int32_t stripe_rows, int32_t rank, int32_t num_ranks, void* stream, int synchronize)
+// frame i of the launch renders the stripes of owner (rank + first_frame + i) % num_ranks when first_frame >= 0, of `rank` otherwise
+static int render_stripes_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_locals, size_t local_pitch, int32_t count,
+                                int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t first_frame, void* stream, int synchronize)
 {
     RenderParams p;
     int rc = fill_params(p, s, cams, d_locals, count, local_pitch);
     if (rc) return rc;
     int32_t rows = 0;
     if ((rc = rt_stripe_rows(p.height, stripe_rows, rank, num_ranks, &rows))) return rc;
-    p.local_rows = rows; p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
+    p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
+    int32_t most = 0;
+    for (int i = 0; i < count; i++) {
+        FrameParams& f = p.frames[i];
+        f.rank = first_frame >= 0 ? (int32_t)(((int64_t)rank + first_frame + i) % num_ranks) : rank;
+        if (f.rank != rank) { if ((rc = rt_stripe_rows(p.height, stripe_rows, f.rank, num_ranks, &f.local_rows))) return rc; }
+        else f.local_rows = rows;
+        most = std::max(most, f.local_rows);
+    }
+    p.local_rows = most;                                        // the grid covers the tallest frame; shorter ones leave their last tiles empty
     return launch(p, false, (hipStream_t)stream, synchronize, s);
+}
+
+int rt_render_stripes_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_locals, size_t local_pitch, int32_t count,
+                            int32_t stripe_rows, int32_t rank, int32_t num_ranks, void* stream, int synchronize)
+{
+    return render_stripes_batch(s, cams, d_locals, local_pitch, count, stripe_rows, rank, num_ranks, -1, stream, synchronize);
+}
+
+int rt_render_stripes_batch_rotating(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_locals, size_t local_pitch, int32_t count,
+                                     int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t first_frame, void* stream, int synchronize)
+{
+    if (first_frame < 0) return RT_E_INVALID;
+    return render_stripes_batch(s, cams, d_locals, local_pitch, count, stripe_rows, rank, num_ranks, first_frame, stream, synchronize);
 }
 
 int rt_render_stripes(RtScene* s, const RtCameraParams* cam, uint8_t* d_local, size_t local_pitch,
@@ -2219,9 +2351,9 @@ int rt_render_stripes(RtScene* s, const RtCameraParams* cam, uint8_t* d_local, s
     return rt_render_stripes_batch(s, cam, &d_local, local_pitch, 1, stripe_rows, rank, num_ranks, stream, synchronize);
 }
 
-int rt_unstripe_batch(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
-                      uint8_t* d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
-                      int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void* stream)
+static int unstripe_batch(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
+                          uint8_t* d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
+                          int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, int32_t rotate_first, void* stream)
 {
     if (!d_gathered || !d_imgs || count < 1 || width <= 0 || height <= 0 || stripe_rows <= 0 || num_ranks <= 0 ||
         local_pitch < (size_t)width * 3 || pitch < (size_t)width * 3) return RT_E_INVALID;
@@ -2231,12 +2363,29 @@ int rt_unstripe_batch(const uint8_t* d_gathered, size_t local_pitch, size_t rank
     dim3 grid((unsigned)((row_units * (size_t)height + 255) / 256), 1, (unsigned)count), block(256);
     if (vec)
         hipLaunchKernelGGL(unstripe_kernel<uint4>, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride, src_frame_stride,
-                           d_imgs, pitch, dst_frame_stride, (int)row_units, height, stripe_rows, num_ranks);
+                           d_imgs, pitch, dst_frame_stride, (int)row_units, height, stripe_rows, num_ranks, rotate_first);
     else
         hipLaunchKernelGGL(unstripe_kernel<uint8_t>, grid, block, 0, (hipStream_t)stream, d_gathered, local_pitch, rank_stride, src_frame_stride,
-                           d_imgs, pitch, dst_frame_stride, (int)row_units, height, stripe_rows, num_ranks);
+                           d_imgs, pitch, dst_frame_stride, (int)row_units, height, stripe_rows, num_ranks, rotate_first);
     RT_HIP(hipGetLastError());
     return RT_OK;
+}
+
+int rt_unstripe_batch(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
+                      uint8_t* d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
+                      int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void* stream)
+{
+    return unstripe_batch(d_gathered, local_pitch, rank_stride, src_frame_stride, d_imgs, pitch, dst_frame_stride, count, width, height,
+                          stripe_rows, num_ranks, -1, stream);
+}
+
+int rt_unstripe_batch_rotating(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
+                               uint8_t* d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
+                               int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, int32_t first_frame, void* stream)
+{
+    if (first_frame < 0) return RT_E_INVALID;
+    return unstripe_batch(d_gathered, local_pitch, rank_stride, src_frame_stride, d_imgs, pitch, dst_frame_stride, count, width, height,
+                          stripe_rows, num_ranks, first_frame, stream);
 }
 
 int rt_unstripe(const uint8_t* d_gathered, size_t local_pitch, size_t rank_stride, uint8_t* d_img, size_t pitch,

@@ -56,9 +56,25 @@ struct RtScene {
         int target = 0;
         hipEvent_t sort_done = nullptr;
         uint64_t last_used = 0;
+        uint64_t launches = 0, sorted_at = 0;    // ordered launches of this size so far / at the last sort issued
         // the last ordered launch on each stream that uses this state (a sort waits for all of them)
         struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; uint64_t tick = 0; } seen[4];
     };
+    // rt_render_overlapped (Camera::render_scene's asynchronous default-stream form): two library-owned BLOCKING streams that
+    // consecutive frames alternate between, so that the next frame's costly tiles fill the chip while the previous frame's
+    // last workgroups drain (the reference's own loop issues two renders per synchronise, kernel.cu:277-279).  Blocking
+    // streams keep the default stream's ordering with everything the caller does on the null stream; two launches that write
+    // overlapping image memory are ordered here: written[k] = the images of launches on stream k that the OTHER stream
+    // has not been ordered after.
+    struct Overlap {
+        std::mutex m;
+        hipStream_t stream[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};             // recorded on stream k when the other stream has to wait for it
+        struct Range { uintptr_t lo, hi; };
+        std::vector<Range> written[2];
+        int next = 0;
+        uint64_t launches = 0, waits = 0;                    // (diagnostics: rt_render_overlapped_stats)
+    } overlap;
     struct TileOrderCache {
         std::mutex m;
         hipStream_t sort_stream = nullptr;

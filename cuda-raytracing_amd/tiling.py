@@ -27,11 +27,18 @@ def frame_rows_of(height, stripe, rank, world):
     return np.asarray(rows, np.int64)
 
 
-def unstripe_host(gathered, height, stripe, world):
-    """gathered[world, max_rows, pitch] (rank-major, padded) -> frame[height, pitch]; host mirror of rt_unstripe."""
+def owner_of(rank, frame_index, world, rotate=True):
+    """Whose stripes `rank` renders for the frame with index `frame_index` in its group: with rotation every rank plays every
+    owner in turn (mirror of rt_render_stripes_batch_rotating), so the ranks' shares of a group are equal."""
+    return (rank + frame_index) % world if rotate else rank
+
+
+def unstripe_host(gathered, height, stripe, world, frame_index=None):
+    """gathered[world, max_rows, pitch] (rank-major, padded) -> frame[height, pitch]; host mirror of rt_unstripe, and of
+    rt_unstripe_batch_rotating when frame_index (the frame's index in its group) is given."""
     out = np.zeros((height, gathered.shape[2]), gathered.dtype)
     for r in range(world):
-        fr = frame_rows_of(height, stripe, r, world)
+        fr = frame_rows_of(height, stripe, r if frame_index is None else owner_of(r, frame_index, world), world)
         out[fr] = gathered[r, :len(fr)]
     return out
 

@@ -187,6 +187,20 @@ int rt_bvh_build(const float *vertices, int32_t n, int32_t max_depth, float *nod
  *      bytes, 3 bytes per pixel in uchar3 .x .y .z order (raycast.cu:292-294).  Asynchronous on
  *      `stream` unless synchronize != 0 (Camera.cu:38-39). ------------------------------------- */
 int rt_render(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch, void *stream, int synchronize);
+/* Camera::render_scene(scene, img, pitch) with synchronize = false, as the reference's frame loop calls it: twice, into two
+ * images, before one cudaDeviceSynchronize (kernel.cu:277-279).  Ordered like a launch on the DEFAULT stream against
+ * everything the caller does on the default stream or device-wide -- copies and memsets of the image, rt_memcpy_*,
+ * rt_scene_update_instance[_async] / refit / rebuild with a NULL stream, rt_render* with a NULL stream, rt_device_synchronize:
+ * what was issued before is seen by the frame, what is issued after sees the frame -- but two consecutive calls that write
+ * DIFFERENT images may overlap: they alternate between two blocking streams the scene owns, so that one frame's costly tiles
+ * fill the chip while the previous frame's last workgroups drain (c2: 0.146 -> 0.13 ms per frame in the reference's loop).
+ * Calls whose images share memory run in call order (the later frame wins).  Not implied, unlike a real default-stream launch:
+ * ordering against work on OTHER blocking streams of the application; a caller with such streams passes its stream to
+ * rt_render instead.  RT_RENDER_OVERLAP=0 makes this call rt_render(.., NULL, 0). */
+int rt_render_overlapped(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch);
+/* how many frames went through rt_render_overlapped on this scene and how many of them had to wait for the other stream
+ * (an image overlapping one written there and one written here); either pointer may be NULL */
+int rt_render_overlapped_stats(const RtScene *scene, uint64_t *launches, uint64_t *cross_stream_waits);
 /* `count` (1..RT_MAX_BATCH) frames of the same size in ONE launch: cams[i] is rendered into d_imgs[i].  A frame
  * stream rendered this way keeps the GPU full while the last long rays of one frame finish (the reference's own
  * loop issues two renders before it synchronises, kernel.cu:277-279). */
@@ -229,6 +243,16 @@ int rt_render_stripes(RtScene *scene, const RtCameraParams *cam, uint8_t *d_loca
                       int32_t stripe_rows, int32_t rank, int32_t num_ranks, void *stream, int synchronize);
 int rt_render_stripes_batch(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_locals, size_t local_pitch,
                             int32_t count, int32_t stripe_rows, int32_t rank, int32_t num_ranks, void *stream, int synchronize);
+/* The same with the stripe owner ROTATING over the frames: frame i of the launch renders the stripes of owner
+ * (rank + first_frame + i) % num_ranks (first_frame >= 0: the index of cams[0] within its group of frames).  The owners' shares
+ * of a frame differ -- 1080 rows are 67.5 stripes of 16, so at 8 ranks three own 144 rows, four 128, and stripes near the
+ * object cost more than sky -- and the slowest rank sets the pace of every exchange; with rotation every rank renders every
+ * owner's share once per num_ranks frames, so the ranks' shares of a group are equal whatever the frames show (c2 at 8 ranks:
+ * max / mean of the render time 1.04 -> 1.00).  Frame i's rows are packed in d_locals[i] as that owner's; the buffer must hold
+ * the rows of the largest share (rt_stripe_rows of rank 0).  rt_unstripe_batch_rotating is the matching un-stripe pass. */
+int rt_render_stripes_batch_rotating(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_locals, size_t local_pitch,
+                                     int32_t count, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t first_frame,
+                                     void *stream, int synchronize);
 /* after a gather of every rank's local buffer (rank r's rows start at d_gathered + r * rank_stride bytes, rows
  * local_pitch bytes apart) place the rows back into frame order */
 int rt_unstripe(const uint8_t *d_gathered, size_t local_pitch, size_t rank_stride,
@@ -240,6 +264,12 @@ int rt_unstripe(const uint8_t *d_gathered, size_t local_pitch, size_t rank_strid
 int rt_unstripe_batch(const uint8_t *d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
                       uint8_t *d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
                       int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, void *stream);
+
+/* rt_unstripe_batch for frames rendered by rt_render_stripes_batch_rotating: frame f of the batch has index first_frame + f in its
+ * group, so the block of rank r (at d_gathered + r * rank_stride) holds the rows of owner (r + first_frame + f) % num_ranks */
+int rt_unstripe_batch_rotating(const uint8_t *d_gathered, size_t local_pitch, size_t rank_stride, size_t src_frame_stride,
+                               uint8_t *d_imgs, size_t pitch, size_t dst_frame_stride, int32_t count,
+                               int32_t width, int32_t height, int32_t stripe_rows, int32_t num_ranks, int32_t first_frame, void *stream);
 
 /* ---- the exchange step of frame tiling: an RCCL communicator over the GPUs of one node (no counterpart in the
  *      reference; BASELINE.json north_star: "the frame is tiled across the 8 GPUs of one node with a final RCCL gather

@@ -97,6 +97,11 @@ int rth_camera_render_scene_batch(RthCamera *c, RthScene *s, const float *poses6
 int rth_camera_render_scene_stripes_batch(RthCamera *c, RthScene *s, const float *poses6, void *const *d_locals,
                                           size_t local_pitch, int32_t count, int32_t stripe_rows, int32_t rank,
                                           int32_t num_ranks, int synchronize);
+/* the same with the stripe owner rotating over the frames: frame i renders the stripes of owner (rank + first_frame + i) % num_ranks
+ * (rt_render_stripes_batch_rotating) */
+int rth_camera_render_scene_stripes_batch_rotating(RthCamera *c, RthScene *s, const float *poses6, void *const *d_locals,
+                                                   size_t local_pitch, int32_t count, int32_t stripe_rows, int32_t rank,
+                                                   int32_t num_ranks, int32_t first_frame, int synchronize);
 /* the RtCameraParams (rt_hip.h) the camera would launch with: 1 + 1 + 9 + 4 + 6 + 6 words */
 void rth_camera_params(const RthCamera *c, void *out_RtCameraParams);
 

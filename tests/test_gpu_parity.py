@@ -741,6 +741,65 @@ def test_batched_stripes_layout(rt, scenes, blob5k):
         gathered.free()
 
 
+def test_rotating_stripe_owner(rt, scenes, blob5k):
+    """rt_render_stripes_batch_rotating / rt_unstripe_batch_rotating: frame i of a launch is rendered as owner
+    (rank + first_frame + i) % world, so every rank renders every owner's share in turn.  Every virtual rank renders its F buffers
+    into its slice of the gathered buffer; the un-stripe pass -- whole group, and a sub-range of it as a rank of the rotating-root
+    exchange sees it (first_frame > 0) -- must give the frames a single launch renders; the host mirror (tiling.unstripe_host)
+    agrees; the rows every rank renders over a group of `world` frames are the same number."""
+    import importlib
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    h = rt.libs()[0]
+    sp = sd.blob_scene(scenes, blob5k).build_product(rt)
+    sp.upload_to_device()
+    for (W, H, stripe, world, F) in ((210, 133, 16, 8, 11), (200, 120, 16, 3, 7), (128, 77, 8, 4, 8), (96, 50, 16, 5, 3)):
+        cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
+        poses = [(0.03 * i, -1.6 - 0.1 * i, 0.2, 0.0, 0.01 * i, 0.0) for i in range(F)]
+        full = []
+        for ps in poses:
+            cam.set_pose(ps)
+            full.append(rt.render(sp, cam))
+        pitch = W * 3
+        max_rows = max(tiling.stripe_rows(H, stripe, r, world) for r in range(world))
+        gathered = rt.DeviceBuffer(nbytes=world * F * max_rows * pitch)
+        g0 = gathered.ptr.value
+        rt.check(h.rt_memcpy_h2d(gathered.ptr, np.full(world * F * max_rows * pitch, 9, np.uint8).ctypes.data, world * F * max_rows * pitch, None))
+        for r in range(world):
+            # two launches per rank (frames [0, cut) and [cut, F)): the second starts at first_frame = cut
+            cut = F // 2
+            base = g0 + r * F * max_rows * pitch
+            ptrs = tiling.batch_local_ptrs(base, F, max_rows, pitch)
+            cam.render_scene_stripes_batch(sp, poses[:cut], ptrs[:cut], pitch, stripe, r, world, synchronize=True, rotate_first=0)
+            cam.render_scene_stripes_batch(sp, poses[cut:], ptrs[cut:], pitch, stripe, r, world, synchronize=True, rotate_first=cut)
+        outs = rt.DeviceBuffer(nbytes=F * H * pitch)
+        rt.check(h.rt_unstripe_batch_rotating(g0, pitch, F * max_rows * pitch, max_rows * pitch, outs.ptr, pitch, H * pitch, F, W, H, stripe, world, 0, None))
+        rt.check(h.rt_device_synchronize())
+        got = outs.to_host().reshape(F, H, W, 3)
+        for f in range(F):
+            assert np.array_equal(got[f], full[f]), "rotating owner: world %d frame %d" % (world, f)
+        # frames [2, F) only, as the rank that assembles them would un-stripe them
+        rt.check(h.rt_memcpy_h2d(outs.ptr, np.zeros(F * H * pitch, np.uint8).ctypes.data, F * H * pitch, None))
+        rt.check(h.rt_unstripe_batch_rotating(g0 + 2 * max_rows * pitch, pitch, F * max_rows * pitch, max_rows * pitch, outs.ptr, pitch, H * pitch,
+                                              F - 2, W, H, stripe, world, 2, None))
+        rt.check(h.rt_device_synchronize())
+        got = outs.to_host().reshape(F, H, W, 3)
+        for f in range(2, F):
+            assert np.array_equal(got[f - 2], full[f]), "rotating owner, sub-range: world %d frame %d" % (world, f)
+        # host mirror
+        host = gathered.to_host().reshape(world, F, max_rows, pitch)
+        for f in range(F):
+            assert np.array_equal(tiling.unstripe_host(host[:, f], H, stripe, world, frame_index=f).reshape(H, W, 3), full[f])
+        # equal shares: over `world` consecutive frames every rank renders H rows in all
+        for r in range(world):
+            assert sum(tiling.stripe_rows(H, stripe, tiling.owner_of(r, f, world), world) for f in range(world)) == H
+        # without rotation the same buffers would not un-stripe to the frames (the test can tell the two apart)
+        rt.check(h.rt_unstripe_batch(g0, pitch, F * max_rows * pitch, max_rows * pitch, outs.ptr, pitch, H * pitch, F, W, H, stripe, world, None))
+        rt.check(h.rt_device_synchronize())
+        assert not np.array_equal(outs.to_host().reshape(F, H, W, 3)[1], full[1])
+        outs.free()
+        gathered.free()
+
+
 def test_c4_atrium_quarter_res(rt, orc, scenes, atrium):
     """configs[3] scene (deep BVH, leaves up to 96 triangles, camera inside) at 960x540: all planes vs the oracle."""
     W, H = 960, 540

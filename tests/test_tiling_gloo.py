@@ -102,7 +102,7 @@ def _pipeline_worker(rank, world, port, blob, H, W, stripe, nframes, out_path):
     dist.barrier()
     dist.destroy_process_group()
 
-def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, out_path):
+def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, out_path, owner_rotation=False):
     """bench.py's default exchange: groups of F frames, frame f assembled on the rank frames_per_rank deals it to, one
     all-to-all per group; `last` = size of a shorter final group (0 = none).  Every frame has its own camera."""
     sys.path.insert(0, ROOT)
@@ -131,7 +131,9 @@ def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, ou
         g = group_of[b]
         for f in range(g[1]):
             img = s.render(W, H, K, D, poses[g[0] + f], planes=False)["img"].reshape(H, W * 3)
-            local[b][f * max_rows:f * max_rows + len(rows)] = torch.from_numpy(img[rows])
+            # owner rotation (bench.py's default): frame f of the group is rendered as owner (rank + f) % world
+            mine_rows = tiling.frame_rows_of(H, stripe, tiling.owner_of(rank, f, world), world) if owner_rotation else rows
+            local[b][f * max_rows:f * max_rows + len(mine_rows)] = torch.from_numpy(img[mine_rows])
 
     ex = tiling.TorchExchange(rank, world)
 
@@ -144,7 +146,8 @@ def _rotating_worker(rank, world, port, blob, H, W, stripe, F, ngroups, last, ou
         c = counts[rank]
         got = received[b][:world * c * max_rows].numpy().reshape(world, c, max_rows, W * 3)
         for k in range(real[rank]):
-            mine[first + offsets[rank] + k] = tiling.unstripe_host(got[:, k], H, stripe, world).copy()
+            mine[first + offsets[rank] + k] = tiling.unstripe_host(got[:, k], H, stripe, world,
+                                                                   frame_index=offsets[rank] + k if owner_rotation else None).copy()
 
     pipe = tiling.StripePipeline(render_fn, exchange_fn, unstripe_fn)
     first = 0
@@ -190,6 +193,31 @@ def test_rotating_root_pipeline(blob5k, tmp_path, world, F, ngroups, last):
     mp.spawn(_rotating_worker, args=(world, _free_port(), blob5k, 40, 64, 8, F, ngroups, last, out), nprocs=world, join=True)
     ok, n = np.load(out)
     assert ok == 1 and n == F * ngroups + last
+
+
+@pytest.mark.parametrize("world,F,ngroups,last", [(2, 4, 1, 3), (3, 5, 2, 1)])
+def test_rotating_root_pipeline_with_rotating_stripe_owner(blob5k, tmp_path, world, F, ngroups, last):
+    """The same pipeline with the stripe owner rotating over the frames of a group (rt_render_stripes_batch_rotating /
+    rt_unstripe_batch_rotating; here their host mirrors tiling.owner_of / unstripe_host(frame_index=)): the rank that assembles
+    frame f of a group must place rank r's block as owner (r + f) % world's rows."""
+    out = str(tmp_path / "rot_owner.npy")
+    mp.spawn(_rotating_worker, args=(world, _free_port(), blob5k, 41, 64, 8, F, ngroups, last, out, True), nprocs=world, join=True)
+    ok, n = np.load(out)
+    assert ok == 1 and n == F * ngroups + last
+
+
+def test_owner_rotation_gives_equal_shares():
+    import importlib
+    sys.path.insert(0, ROOT)
+    tiling = importlib.import_module("cuda-raytracing_amd.tiling")
+    for H, stripe, world in ((1080, 16, 8), (1080, 16, 4), (2160, 16, 8), (133, 16, 3), (50, 7, 5)):
+        own = [tiling.stripe_rows(H, stripe, r, world) for r in range(world)]
+        assert sum(own) == H
+        for r in range(world):
+            over_a_group = sum(tiling.stripe_rows(H, stripe, tiling.owner_of(r, f, world), world) for f in range(world))
+            assert over_a_group == H                                            # every rank: one frame's worth of rows per `world` frames
+        assert [tiling.owner_of(r, 0, world) for r in range(world)] == list(range(world))
+    assert max(tiling.stripe_rows(1080, 16, r, 8) for r in range(8)) == 144 and min(tiling.stripe_rows(1080, 16, r, 8) for r in range(8)) == 128
 
 
 @pytest.mark.parametrize("world,stripe,H", [(2, 16, 90), (2, 7, 45)])
