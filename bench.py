@@ -59,7 +59,23 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CLOCK_HZ = 2.4e9                 # max shader clock
 N_SIMD = 256 * 4
 VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 2 / 1e9     # wave64 VALU instructions per second: 2 cycles each on a SIMD-32 (MICROARCH "Wave scheduling")
-L1_PEAK_GBS = 256 * 64 * CLOCK_HZ / 1e9           # vector L1: one 64-B access per CU per clock
+L1_CALIBRATION_JSON = os.path.join(ROOT, "profiles", "r05_l1_calibration.json")
+
+
+def l1_peak_gaccess():
+    """The vector L1's ceiling in TCP_TOTAL_CACHE_ACCESSES per second, MEASURED for the traversal's fetch (tools/l1_calibration.hip:
+    four global_load_dwordx4 per lane from an L1-resident table, 8 waves per SIMD, every CU): 1 031 G accesses/s = 1.68 per clock and
+    CU once the lanes of a wave-instruction hold 4 or more different 64-B records (one access per lane then; 38 clocks per
+    wave-instruction), and the data path's 64 B per clock and CU (16 clocks per wave-instruction) when they all hold the same one.
+    Rounds 1-4 priced accesses at an ASSUMED 64 B per clock and CU (= 614 G accesses/s): the L1 fraction printed then was 1.68 x
+    too high."""
+    try:
+        return json.load(open(L1_CALIBRATION_JSON))["ceiling"]["tcp_accesses_per_second"] / 1e9, "measured (profiles/r05_l1_calibration.json)"
+    except Exception:
+        return 1031.4, "measured in round 5 (profiles/r05_l1_calibration.json not found: the constant)"
+
+
+L1_DATA_CLK_PER_WAVE_LOAD = 16.3                  # clocks a CU's L1 spends on one full-width global_load_dwordx4 even when every lane hits one line (same calibration)
 SALU_PEAK_GINST = 256 * CLOCK_HZ / 1e9            # one scalar unit per CU (MICROARCH glossary "CU"), one instruction per clock
 STRIPE_ROWS = 16
 MIN_WARM_FRAMES = 320            # 1-spp stream workloads: untimed frames before the timed region, whatever --warmup asks (see run_stream)
@@ -327,19 +343,20 @@ def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_fra
         out["profile_stale"] = False
         n = frames_per_launch * share
         valu = e["valu_insts_per_frame"] * n / sec / 1e9
-        l1 = e["tcp_accesses_per_frame"] * 64 * n / sec / 1e9 if e.get("tcp_accesses_per_frame") else None
+        l1_peak, l1_peak_from = l1_peak_gaccess()
+        l1 = e["tcp_accesses_per_frame"] * n / sec / 1e9 if e.get("tcp_accesses_per_frame") else None     # G accesses/s
         hbm = e["hbm_bytes_per_frame"] * n / sec / 1e9 if e.get("hbm_bytes_per_frame") is not None else None
         salu = e["per_frame"]["SQ_INSTS_SALU"] * n / sec / 1e9 if e.get("per_frame", {}).get("SQ_INSTS_SALU") else None
         # the bound = whichever unit is busiest (fractions of: VALU issue slots, L1 accesses, the CU's scalar unit, HBM bytes)
         fr = {"valu_issue": valu / VALU_PEAK_GINST}
         if l1 is not None:
-            fr["l1"] = l1 / L1_PEAK_GBS
+            fr["l1"] = l1 / l1_peak
         if salu is not None:
             fr["salu_issue"] = salu / SALU_PEAK_GINST
         if hbm is not None:
             fr["hbm"] = hbm / HBM_PEAK_GBS
         bound = max(fr, key=fr.get)
-        ach, peak, unit = {"valu_issue": (valu, VALU_PEAK_GINST, "G wave-instr/s"), "l1": (l1, L1_PEAK_GBS, "GB/s"),
+        ach, peak, unit = {"valu_issue": (valu, VALU_PEAK_GINST, "G wave-instr/s"), "l1": (l1, l1_peak, "G TCP accesses/s"),
                            "salu_issue": (salu, SALU_PEAK_GINST, "G instr/s"), "hbm": (hbm, HBM_PEAK_GBS, "GB/s")}[bound]
         out.update({"bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
                     "traffic": int(e["hbm_bytes_per_frame"] * n) if e.get("hbm_bytes_per_frame") is not None else None,
@@ -347,10 +364,15 @@ def roofline(kernel, key, kernel_ms, frames_per_launch, share, alg_bytes_per_fra
                     "lanes_active_per_valu": e.get("lanes_active_per_valu"),
                     "useful_lane_slot_frac": round(valu / VALU_PEAK_GINST * e["lanes_active_per_valu"] / 64.0, 4) if e.get("lanes_active_per_valu") else None,
                     "valu_issue_frac": round(valu / VALU_PEAK_GINST, 4),
-                    "l1_bw_frac": round(l1 / L1_PEAK_GBS, 4) if l1 is not None else None,
+                    "l1_access_frac": round(l1 / l1_peak, 4) if l1 is not None else None,
+                    # the other limit of the same unit: every vector load instruction occupies the L1's data path for at least 16 clocks
+                    # (all 64 lanes active); the truth lies between the two figures
+                    "l1_data_path_upper_bound": round(e["per_frame"]["SQ_INSTS_VMEM_RD"] * n / sec * L1_DATA_CLK_PER_WAVE_LOAD / (256 * CLOCK_HZ), 4)
+                                                if e.get("per_frame", {}).get("SQ_INSTS_VMEM_RD") else None,
                     "hbm_physical_frac": round(hbm / HBM_PEAK_GBS, 5) if hbm is not None else None,
                     "profile": e.get("tag"),
-                    "peaks": "VALU: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; L1: 256 CUs x 64 B/clk; SALU: 256 CUs x 1 instruction/clk; HBM 8 TB/s"})
+                    "peaks": "VALU: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; L1: %.0f G TCP accesses/s, %s; SALU: 256 CUs x 1 instruction/clk; HBM 8 TB/s"
+                             % (l1_peak, l1_peak_from)})
         if hbm is not None:
             # FETCH_SIZE / WRITE_SIZE count what leaves the L2s (Infinity Cache hits included): an upper bound on HBM bytes.
             # No x2 on FETCH_SIZE here: tools/fetch_calibration.sh measures 0.99 bytes reported per byte for this kernel's

@@ -42,6 +42,13 @@ using namespace rt;
 #ifndef RT_LEAF_FLAT
 #define RT_LEAF_FLAT 1          // leaf step without the empty-leaf region; the wave's "any accept" asked inside the leaf region
 #endif
+#ifndef RT_EX_RECOMPUTE
+#define RT_EX_RECOMPUTE 0       // 1: render_ex_kernel derives base colour, normal and cosine of a shaded hit again after its shadow cast instead of keeping
+                                // them across it (measured +1.1 % on c3: profiles/r05_experiments/ex_spill_variants.md)
+#endif
+#ifndef RT_EX_PEEL
+#define RT_EX_PEEL 1            // render_ex_kernel: the primary ray's depth written out before the bounce loop (measured -0.7 % on c3, same log)
+#endif
 #ifndef RT_NEED_POP_VALUE
 #define RT_NEED_POP_VALUE 1     // "this lane must pop" is a value of `cur` (kNeedPop), not a flag merged across the loop's branches
 #endif
@@ -823,29 +830,49 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
             sample = sample + weight * (local * (1.0f - 0.0f));
         }
     } else
-    for (int depth = 0; depth <= p.bounces; depth++) {
-        const Hit hit = cast_ray_ex(p, org, dir, stack, pops);
-        if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); break; }
+    {
+    // one depth of the path: cast, shade, reflect; false = the path has ended
+    auto step = [&](const int depth) __attribute__((always_inline)) -> bool {
+        Hit hit = cast_ray_ex(p, org, dir, stack, pops);
+        if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); return false; }
+        float illum = 1.0f;
+#if RT_EX_RECOMPUTE
+        // What is shaded is a function of the accepted hit -- (slot, instance, u, v) -- and the scene: base colour, normal and
+        // cosine are NOT carried across the shadow cast (seven registers of a kernel that spills), they are derived again from
+        // those four words after it: the same operations on the same inputs, so the same bits.  (The empty asm makes the slot
+        // opaque: the optimiser would otherwise recognise the second derivation and keep the first results alive.)
+        if (p.lighting) {                                   // raycast.cu:249-287 with the commented lines active
+            const float cos_illum = dot(hit_normal(p, hit), sun);
+            illum = (float)(0.4 * (double)cos_illum);
+            if (cos_illum > 0) {
+                // (only hit-or-miss survives a shadow cast: no hit location to keep.  Octant loops at either cast of this
+                // kernel: within +-0.6 %, profiles/r04_experiments/octants_in_extension_kernels.log)
+                const Hit sh = cast_ray_ex<false, false, true>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
+                asm volatile("" : "+v"(hit.slot));
+                if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)dot(hit_normal(p, hit), sun));
+            }
+        }
         const V3 base = base_colour(p, hit);
         const V3 n = hit_normal(p, hit);
-        float illum = 1.0f;
+#else
+        const V3 base = base_colour(p, hit);
+        const V3 n = hit_normal(p, hit);
         if (p.lighting) {                                   // raycast.cu:249-287 with the commented lines active
             const float cos_illum = dot(n, sun);
             illum = (float)(0.4 * (double)cos_illum);
             if (dot(n, sun) > 0) {
-                // (only hit-or-miss survives a shadow cast: no hit location to keep.  Octant loops at either cast of this
-                // kernel: within +-0.6 %, profiles/r04_experiments/octants_in_extension_kernels.log)
                 const Hit sh = cast_ray_ex<false, false, true>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
                 if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);
             }
         }
+#endif
         illum = fminf(1.0f, illum);                         // raycast.cu:289-290
         illum = fmaxf(0.4f, illum);
         const V3 local = v3(illum * base.x, illum * base.y, illum * base.z);
         const DevMaterial& mat = p.materials[p.instances[hit.instance].material_index];
         const float m = depth < p.bounces ? mat.metallic : 0.0f;
         sample = sample + weight * (local * (1.0f - m));
-        if (!(m > 0.0f)) break;
+        if (!(m > 0.0f)) return false;
         weight = weight * (base * m);
         const float k = 2.0f * dot(dir, n);
         V3 r = dir - n * k;
@@ -860,6 +887,15 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
         r = normalize(r);
         org = hit.loc + r * (float)1e-4;
         dir = r;
+        return true;
+    };
+#if RT_EX_PEEL
+    // the primary ray's depth written out: weight = 1 and sample = 0 are constants across its cast, not registers to keep
+    if (step(0))
+        for (int depth = 1; depth <= p.bounces; depth++) if (!step(depth)) break;
+#else
+    for (int depth = 0; depth <= p.bounces; depth++) if (!step(depth)) break;
+#endif
     }
     }
     where(x, ly, y, s, valid);

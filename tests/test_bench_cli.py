@@ -61,3 +61,35 @@ def test_multi_rank_report_fields():
     r = bench.multi_rank_report(ranks, None)
     assert r["per_rank"] == ranks and r["stripe_share_imbalance"] == 1.2
     assert set(r["rccl"]) >= {"version", "through", "NCCL_MAX_NCHANNELS"} and r["rccl"]["through"] == "torch.distributed"
+
+
+def test_scaling_prediction_fields():
+    """bench.py --predict-scaling: one N of the prediction from the one-GPU time and the virtual ranks' times (the slowest rank
+    sets the pace of a real run)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ranks = [0.50, 0.45, 0.47, 0.46, 0.45, 0.46, 0.47, 0.44]
+    p = bench.scaling_prediction(3.6, ranks)
+    assert p["n_gpus"] == 8 and p["one_gpu_ms"] == 3.6 and p["ideal_ms"] == 0.45 and p["render_ms_per_rank"] == ranks
+    assert p["predicted_render_speedup"] == 7.2 and p["predicted_render_efficiency"] == 0.9
+    assert p["stripe_share_imbalance"] == round(0.50 / (sum(ranks) / 8), 4)
+    q = bench.scaling_prediction(2.0, [1.0, 1.0])
+    assert q["predicted_render_speedup"] == 2.0 and q["stripe_share_imbalance"] == 1.0
+
+
+def test_committed_scaling_prediction():
+    """profiles/r05_predicted_scaling.json = `python bench.py --predict-scaling 2,4,8` on one MI355X with this round's kernels:
+    every virtual rank of N timed through the entry points a real rank uses.  north_star asks for >= 7 x at 8 GPUs; the render
+    side must leave room for the exchange."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_predicted_scaling.json")))
+    assert d["mode"] == "predict-scaling" and d["n_gpus"] == 1 and len(d["code_hash"]) == 16 and d["stripe_owner_rotates_over_frames"] is True
+    per_n = {p["n_gpus"]: p for p in d["stream"]["per_n"]}
+    assert sorted(per_n) == [2, 4, 8]
+    for n, p in per_n.items():
+        assert len(p["render_ms_per_rank"]) == n and all(v > 0 for v in p["render_ms_per_rank"])
+        assert abs(p["predicted_render_speedup"] - p["one_gpu_ms"] / max(p["render_ms_per_rank"])) < 2e-3
+        assert 1.0 <= p["stripe_share_imbalance"] < 1.02                       # the stripe owner rotates over the frames: equal shares
+        assert p["predicted_render_speedup"] <= n
+    assert per_n[8]["predicted_render_speedup"] >= 7.3
+    assert {p["n_gpus"] for p in d["stream"]["driver_shape_per_n"]} == {2, 4, 8}
