@@ -726,7 +726,8 @@ def run_stream(args, env):
         step_group(i, c)
     sync()
     if pipe is not None:
-        pipe.stage_timing(True)                                  # per group: wait for buffer / render / exchange / un-stripe (events, no waits)
+        # per group: wait for buffer / render / exchange / un-stripe (events created here, only recorded inside the timed region)
+        pipe.stage_timing(True, expect_groups=len(groups) * (REPEATS_SHORT if len(groups) == 1 else 1))
     g["phase"]("timed loop", 4.0)
     # The timed region = the K steps between two barrier + synchronise pairs.  When K fits ONE launch (the driver's
     # --steps 20) that region is a single 2.7 ms sample: it is then measured REPEATS_SHORT times back to back and the line
@@ -812,6 +813,7 @@ def run_stream(args, env):
                              % (STRIPE_ROWS, world, (", the stripe owner rotating over the frames of a group" if dist_on and not args.no_owner_rotation else ""),
                                 (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames) through %s" % (F, "rt_all_to_all" if g["comm"] is not None else "torch.distributed") if rotate
                                                   else ", one RCCL gather to rank 0 per %d frames through %s" % (F, "rt_gather" if g["comm"] is not None else "torch.distributed")) if dist_on else ""),
+              "mesh_on_octant_loops": scene.mesh_flags(0) == 0,      # (false: an unordered or NaN child box keeps the mesh on the generic slab loop)
               "frames_per_launch": F, "host_issue_ms_per_launch": round(t_issue / max(len(groups), 1) * 1e3, 3),
               "single_frame_launch_ms": None if latency is None else latency["f1_kernel_ms"], "latency": latency,
               "coverage": round(st["hits"] / st["rays"], 4),
@@ -1195,6 +1197,7 @@ def run_frames(args, env):
               "key": g["key"], "width": W, "height": H, "spp": spp, "bounces": bounces, "lighting": lighting,
               "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s"
                              % (STRIPE_ROWS, world, (", one RCCL gather to rank 0 per frame (Camera::render_scene_tiled -> rt_render_tiled)" if comm is not None else ", one gather to rank 0 per frame through torch.distributed") if dist_on else ""),
+              "mesh_on_octant_loops": scene.mesh_flags(0) == 0,
               "frames_per_launch": 1, "primary_rays_per_frame": W * H * spp,
               "node_pops_per_pixel": round(pops / (W * H), 1), "G_node_pops_per_s_kernel": round(pops / max(world, 1) / (kernel_ms * 1e-3) / 1e9, 1)}
     roof = roofline("render_ex_kernel", g["key"], kernel_ms, 1, 1.0 / world)

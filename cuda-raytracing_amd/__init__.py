@@ -62,7 +62,7 @@ class RtSceneDesc(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_build_info", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_render", "rt_render_overlapped", "rt_render_overlapped_stats", "rt_render_batch",
+    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_scene_mesh_flags", "rt_render", "rt_render_overlapped", "rt_render_overlapped_stats", "rt_render_batch",
     "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_render_stripes_batch_rotating", "rt_unstripe", "rt_unstripe_batch", "rt_unstripe_batch_rotating",
     "rt_comm_available", "rt_comm_last_error", "rt_comm_last_error_any", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_info", "rt_comm_destroy",
     "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
@@ -152,6 +152,7 @@ def _declare(h, s):
     h.rt_scene_upload.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(_vp)]
     h.rt_scene_info.argtypes = [_vp, C.POINTER(C.c_size_t), _i]
     h.rt_scene_mesh_capacity.argtypes = [_vp, C.c_int32, _i]
+    h.rt_scene_mesh_flags.argtypes = [_vp, C.c_int32, _i]
     h.rt_scene_update_instance.argtypes = [_vp, C.c_int32, _vp]
     h.rt_scene_update_instance_async.argtypes = [_vp, C.c_int32, _vp, _vp]
     h.rt_scene_refit_mesh.argtypes = [_vp, C.c_int32, _f, _f, C.c_int32, _vp]
@@ -414,6 +415,12 @@ class Scene:
     @property
     def device_handle(self):
         return libs()[1].rth_scene_device_handle(self.h)
+
+    def mesh_flags(self, mesh_index):
+        """rt_scene_mesh_flags: bit 0 = the mesh is traversed with the generic slab loop (an unordered or NaN child box)"""
+        v = C.c_int32(0)
+        check(libs()[0].rt_scene_mesh_flags(self.device_handle, mesh_index, C.byref(v)), "rt_scene_mesh_flags")
+        return v.value
 
     def overlap_stats(self):
         """(frames that went through rt_render_overlapped, those that had to wait for the other stream)"""

@@ -37,15 +37,18 @@ public:
     void refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream = nullptr);
     // A mesh changes beyond what a refit can follow (large motion, or other triangles): the device copy gets a NEW tree, built on
     // the GPU straight into the scene's arrays (rt_scene_rebuild_mesh_device), the host copy rebuilds its tree when it is next
-    // needed.  More triangles than the mesh was uploaded with do not fit its part of the arrays: the whole scene is uploaded
-    // again then (upload_to_device).  The host mesh changes only once the device call has succeeded: on an error (last_error)
-    // host and device still describe the old mesh.  Returns when the new tree is in place.
+    // needed.  More triangles than the mesh was uploaded with do not fit its part of the arrays: a new device scene is uploaded
+    // then (the GPU builds the mesh's tree during the upload) and takes the old one's place once it is complete; that path waits
+    // for the whole device, whatever `stream` is.  On EVERY path the host mesh and the device scene change only after the device
+    // call has succeeded: on an error (last_error) host and device still describe the old mesh and the old scene still renders.
+    // Returns when the new tree is in place.
     void rebuild_mesh(int mesh_index, std::vector<TrianglePrimitive> triangles, void* stream = nullptr);
     RtScene* d_scene = nullptr;
     int num_mesh_instances = 0;
     int last_error = 0;                             // rt_hip.h status of the last device call (the reference ignores errors)
 
 private:
+    int upload_as(const std::vector<MeshPrimitive*>& meshes_now, RtScene** out);   // a new device scene from these meshes; touches nothing else
     std::vector<MeshPrimitive> meshes;
     std::vector<Material> materials;
     std::vector<MeshInstance> mesh_instances;

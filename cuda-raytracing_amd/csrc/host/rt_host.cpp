@@ -410,16 +410,17 @@ static RtInstanceDesc to_desc(const MeshInstance& in)
     return d;
 }
 
-void Scene::upload_to_device()
+// Flatten `meshes_now` (the scene's meshes, one of them possibly replaced by a candidate) with the scene's materials and instances
+// and upload them as a NEW device scene.  Nothing the Scene owns is touched: the caller swaps on success.
+int Scene::upload_as(const std::vector<MeshPrimitive*>& meshes_now, RtScene** out)
 {
-    if (d_scene) { rt_scene_destroy(d_scene); d_scene = nullptr; }     // Scene.cpp:28-39
     struct Flat { std::vector<float> v, n, uv; BVHTree::DeviceCompatible tree; };
-    std::vector<Flat> flat(meshes.size());
-    std::vector<RtMeshDesc> md(meshes.size());
-    for (size_t i = 0; i < meshes.size(); i++) {
-        const bool device_build = meshes[i].builds_at_upload();  // no host tree wanted: the GPU builds it inside the scene's arrays
-        if (!device_build) meshes[i].sync_tree();                // (a mesh refitted on the device only: its host tree catches up now)
-        const MeshPrimitive& m = meshes[i];
+    std::vector<Flat> flat(meshes_now.size());
+    std::vector<RtMeshDesc> md(meshes_now.size());
+    for (size_t i = 0; i < meshes_now.size(); i++) {
+        const bool device_build = meshes_now[i]->builds_at_upload();  // no host tree wanted: the GPU builds it inside the scene's arrays
+        if (!device_build) meshes_now[i]->sync_tree();                // (a mesh refitted on the device only: its host tree catches up now)
+        const MeshPrimitive& m = *meshes_now[i];
         Flat& f = flat[i];
         const auto& tris = m.triangle_array();
         f.v.resize(tris.size() * 9); f.n.resize(tris.size() * 3); f.uv.resize(tris.size() * 6);
@@ -462,7 +463,15 @@ void Scene::upload_to_device()
     sd.num_meshes = (int32_t)md.size(); sd.meshes = md.data();
     sd.num_materials = (int32_t)mat.size(); sd.materials = mat.data();
     sd.num_instances = (int32_t)inst.size(); sd.instances = inst.data();
-    last_error = rt_scene_upload(&sd, &d_scene);
+    return rt_scene_upload(&sd, out);
+}
+
+void Scene::upload_to_device()
+{
+    if (d_scene) { rt_scene_destroy(d_scene); d_scene = nullptr; }     // Scene.cpp:28-39
+    std::vector<MeshPrimitive*> all;
+    for (auto& m : meshes) all.push_back(&m);
+    last_error = upload_as(all, &d_scene);
     num_mesh_instances = (int)mesh_instances.size();
     if (last_error) std::cerr << "Scene::upload_to_device: " << rt_error_string(last_error) << std::endl;
 }
@@ -508,9 +517,25 @@ void Scene::rebuild_mesh(int mesh_index, std::vector<TrianglePrimitive> tris, vo
     last_error = rt_scene_mesh_capacity(d_scene, mesh_index, &capacity);
     if (last_error) return;
     if (n > (size_t)capacity) {
-        // more triangles than the mesh's part of the device arrays has room for: the whole scene is uploaded again
-        m.replace(std::move(tris), false);
-        upload_to_device();
+        // More triangles than the mesh's part of the device arrays has room for: the whole scene is uploaded again -- as a NEW device
+        // scene built from a candidate mesh, while host and device still describe the old one.  Only when that upload has succeeded
+        // is the old device scene released and the host mesh replaced; on an error both stay as they were (last_error says why).
+        // The candidate has no host tree: the GPU builds the tree during the upload (byte-identical to the host builder's, and
+        // without its seconds for a large mesh); the host copy is built when something next reads it (sync_tree).
+        // `stream`: this path replaces every device array of the scene, so it waits for the whole device first (frames in flight on
+        // any stream still read the old arrays) -- the one case in which this call is not merely ordered on `stream`.
+        MeshPrimitive candidate = MeshPrimitive::for_device_build(std::move(tris));
+        std::vector<MeshPrimitive*> all;
+        for (auto& each : meshes) all.push_back(&each == &m ? &candidate : &each);
+        RtScene* fresh = nullptr;
+        last_error = upload_as(all, &fresh);
+        if (last_error) return;                                 // (rt_scene_upload releases what it had allocated)
+        last_error = rt_device_synchronize();
+        if (last_error) { (void)rt_scene_destroy(fresh); return; }
+        (void)rt_scene_destroy(d_scene);
+        d_scene = fresh;
+        m = std::move(candidate);
+        num_mesh_instances = (int)mesh_instances.size();
         return;
     }
     std::vector<float> host(n * 18);                            // vertices [n][9], normals [n][3], uvs [n][6]

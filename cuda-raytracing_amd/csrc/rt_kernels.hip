@@ -345,7 +345,6 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     // "this lane must pop" as a value of `cur` instead of the flag `have`: -1.5 % on the primary kernel, +0.8 % on the bounce
     // casts of the extension kernel (EX: they keep the flag) -- profiles/r04_experiments/sentinel_loop_ab.log
     constexpr bool kNeedPopValue = RT_SENTINEL && RT_NEED_POP_VALUE && !EX;
-    static_assert(!ANYHIT || kNeedPopValue, "the early return ends a lane by handing it the sentinel: needs the value form of the pop decision");
     int rem = -1;                                               // triangles left in the leaf being walked, -1 = not in a leaf
     unsigned long long c_pop = 0, c_mem = 0, c_int = 0, c_leaf = 0, n_it = 0, n_int = 0, n_leaf = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     unsigned long long n_g1 = 0, n_g2 = 0, n_g34 = 0;
@@ -457,7 +456,17 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
             if constexpr (EX) { hit.loc.x = accept ? c.loc.x : hit.loc.x; hit.loc.y = accept ? c.loc.y : hit.loc.y; hit.loc.z = accept ? c.loc.z : hit.loc.z; }
             // raycast.cu:129-133: `if (lighting_pass && distance < light_distance) return hit_info;` -- the lane is done with
             // this cast: it takes the sentinel, which ends its loop at the bottom test (and cast_ray_ex skips its other instances)
-            if constexpr (ANYHIT) cur = (accept & (c.dist < FLT_MAX)) ? kSentinel : cur;
+            if constexpr (ANYHIT) {
+                const bool done = accept & (c.dist < FLT_MAX);
+                if constexpr (kNeedPopValue) cur = done ? kSentinel : cur;
+                else {
+                    // (the flag forms of the A/B switches RT_SENTINEL=0 / RT_NEED_POP_VALUE=0: the lane leaves its leaf and finds
+                    // nothing left but the sentinel -- or nothing at all -- when it pops next)
+                    have = done ? false : have;
+                    rem = done ? -1 : rem;
+                    stack.sp = done ? RT_SENTINEL : stack.sp;
+                }
+            }
         }
         if constexpr (PROF) { __builtin_amdgcn_s_waitcnt(0); t0 = __builtin_amdgcn_s_memtime(); }
 #if RT_SENTINEL
@@ -1364,7 +1373,7 @@ __global__ void refit_level_kernel(float4* records, const int32_t* __restrict__ 
     q[1] = make_float4(amx[1], amx[2], bmn[0], bmn[1]);
     q[2] = make_float4(bmn[2], bmx[0], bmx[1], bmx[2]);
     const float w[12] = {amn[0], amn[1], amn[2], amx[0], amx[1], amx[2], bmn[0], bmn[1], bmn[2], bmx[0], bmx[1], bmx[2]};
-    if (!boxes_ordered(w)) *mesh_flag = kBoxUnordered;          // (only ever set here: a refit never makes a mesh eligible again)
+    if (!boxes_ordered(w)) *mesh_flag = kBoxUnordered;          // (cleared by refit_mesh before the first level: a refit rewrites every interior record)
 }
 
 // A run of consecutive NARROW levels (the top of every tree, and the thin bottom of a deep one: each a launch of a few dozen
@@ -1516,8 +1525,9 @@ bool order_state_idle(RtScene::TileOrder& o)
 }
 }  // namespace
 
-// a tree of L levels never holds more than L - 1 postponed nodes (see StackT): the kernels without the private overflow
-// RT_STACK_SPILL=1 forces the general kernels (tests: both forms on every scene)
+// a tree of L levels never holds more than L - 1 postponed nodes (see StackT): the kernels without the private overflow.
+// RT_STACK_SPILL=1 forces the general kernels (read once per process: tests/test_gpu_parity.py runs a parity scene in a child
+// process with it; test_stack_depth_at_the_lds_boundary renders chains of 15..20 levels through whichever form their depth selects)
 bool lds_stack_suffices(const RenderParams& p)
 {
     static const bool forced = [] { const char* e = getenv("RT_STACK_SPILL"); return e && e[0] == '1'; }();
@@ -1692,6 +1702,8 @@ const char* rt_error_string(int code)
 
 int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
 {
+    // tests of the callers' error paths: while RT_TEST_FAIL_UPLOAD=1 is in the environment every upload fails before it touches anything
+    if (const char* e = getenv("RT_TEST_FAIL_UPLOAD")) if (e[0] == '1') return RT_E_NOMEM;
     if (!desc || !out || desc->num_meshes < 0 || desc->num_materials < 0 || desc->num_instances < 0) return RT_E_INVALID;
     if ((desc->num_meshes && !desc->meshes) || (desc->num_materials && !desc->materials) ||
         (desc->num_instances && !desc->instances)) return RT_E_INVALID;
@@ -1956,6 +1968,9 @@ int refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, const floa
     // already on the device the call is launch-bound)
     int begin = 0;
     int32_t* mesh_flag = s->d_mesh_flags + mesh_index;
+    // every interior record of the mesh is rewritten below, so the flag is decided anew: one frame with a NaN vertex in a deforming
+    // mesh no longer keeps the mesh on the generic slab loop (4-7 % slower on c2) until its next rebuild
+    RT_HIP(hipMemsetAsync(mesh_flag, 0, sizeof(int32_t), st));
     RefitRun run;
     run.levels = 0;
     auto flush = [&] {
@@ -2045,6 +2060,13 @@ int rt_scene_info(const RtScene* s, size_t* device_bytes, int32_t* max_stack)
     if (!s) return RT_E_INVALID;
     if (device_bytes) *device_bytes = s->device_bytes;
     if (max_stack) *max_stack = s->max_stack;
+    return RT_OK;
+}
+
+int rt_scene_mesh_flags(RtScene* s, int32_t mesh_index, int32_t* flags)
+{
+    if (!s || !flags || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size()) return RT_E_INVALID;
+    RT_HIP(hipMemcpy(flags, s->d_mesh_flags + mesh_index, sizeof(int32_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -161,18 +161,25 @@ class StripePipeline:
         self.used = [False, False]
         self.timing = False                                     # stage_timing(True): every group records its stage boundaries
         self._marks = []                                        # per timed group: five events (streams) or five clock readings (inline)
+        self._pool = []                                         # events created ahead of the timed region (stage_timing)
         if comm_stream is not None:
             import torch
             self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
 
-    def stage_timing(self, on):
+    def stage_timing(self, on, expect_groups=0):
         """Per-group stage times for stage_times(): with streams, timing events at the five boundaries of a group (before the
         wait for its buffer set, render start, render end = exchange may start, exchange end, un-stripe end); inline, the
-        host clock at the same places.  Events cost a few microseconds per group and nothing waits for them."""
+        host clock at the same places.  Nothing waits for the events.  expect_groups: that many groups' events are created
+        HERE, before the timed region, so that the region itself only records them (event creation is a runtime call of
+        several microseconds; a group of one short launch is not much longer)."""
         self.timing = bool(on)
         if on:
             self._marks = []
+            self._pool = []
+            if self.comm is not None and expect_groups > 0:
+                import torch
+                self._pool = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(expect_groups)]
 
     def step(self, i):
         b = i & 1
@@ -191,7 +198,7 @@ class StripePipeline:
         else:
             import torch
             cs = self.compute[b] if self.compute is not None else torch.cuda.current_stream()
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.timing else None
+            ev = (self._pool.pop() if self._pool else [torch.cuda.Event(enable_timing=True) for _ in range(5)]) if self.timing else None
             if ev:
                 ev[0].record(cs)                                # completes when the stream has nothing left but this group
             if self.used[b]:

@@ -18,7 +18,10 @@
  * rt_bvh_build use the partition path of meshes above 1 M triangles; RT_BVH_DEBUG=1 prints its phase timings;
  * RT_BVH_SMALL=k (0..64) lowers the size of the subtrees one wave finishes on its own (0: level loop only; tests);
  * RT_RCCL_LIBRARY=<path> makes rt_comm_* load that library instead of librccl.so.1 (tests: an in-process mock); if it cannot
- * be loaded or lacks an entry point, rt_comm_* fail with RT_E_COMM (rt_comm_last_error() has the loader's message).
+ * be loaded or lacks an entry point, rt_comm_* fail with RT_E_COMM (rt_comm_last_error() has the loader's message);
+ * RT_RENDER_OVERLAP=0 makes rt_render_overlapped a plain default-stream launch; RT_TILE_SORT_INTERVAL=<n> sorts a new heavy-first
+ * order every n-th single-frame launch (default 4); while RT_TEST_FAIL_UPLOAD=1 is set every rt_scene_upload fails with
+ * RT_E_NOMEM before it touches anything (tests of the callers' error paths).
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -153,6 +156,11 @@ int rt_scene_refit_mesh_device(RtScene *scene, int32_t mesh_index, const float *
 int rt_scene_destroy(RtScene *scene);
 /* bytes of device memory the scene holds, and the traversal-stack depth it needs */
 int rt_scene_info(const RtScene *scene, size_t *device_bytes, int32_t *max_stack);
+/* per-mesh state bits kept on the device (a small synchronous copy).  Bit 0 (1): some interior record of the mesh holds a child box
+ * with min > max or a NaN (an empty leaf of a degenerate split, non-finite vertices): the mesh is traversed with the generic slab
+ * test instead of the octant-specialised loops (4-7 % slower on c2, same results).  Decided at upload and by every rebuild and
+ * refit of the mesh. */
+int rt_scene_mesh_flags(RtScene *scene, int32_t mesh_index, int32_t *flags);
 /* the largest triangle count rt_scene_rebuild_mesh_device accepts for this mesh (= the count it was uploaded with: its part of
  * the record arrays has room for any tree over that many triangles) */
 int rt_scene_mesh_capacity(const RtScene *scene, int32_t mesh_index, int32_t *max_triangles);

@@ -236,6 +236,29 @@ def test_non_finite_vertices_and_the_octant_preconditions(rt, orc, scenes, gpu_b
     for n in ("img",) + PLANES:
         assert np.array_equal(dbg[n], ref[n]), ("refit with NaNs", n)
     assert np.array_equal(rt.render(sp, cam), ref["img"])
+    # ... and the flag is not sticky: whether the four NaN triangles left a child box unordered or not, a refit back to
+    # finite vertices decides it anew -- the mesh is on the octant loops again, and still equal to the oracle
+    flagged = sp.mesh_flags(0)
+    moved2 = clean.copy()
+    moved2[:, 0] += np.float32(0.03); moved2[:, 3] += np.float32(0.03); moved2[:, 6] += np.float32(0.03)
+    for i in range(len(moved2)):
+        moved2[i, :12] = o.tri_from_vertices(moved2[i, :9])[:12]
+    sp.refit_mesh(0, moved2)
+    o.mesh_refit(om, moved2)
+    assert sp.mesh_flags(0) == 0, flagged
+    ref = so.render(W, H, K, scenes.D_REF, (0.0, -3.0, 0.0, 0, 0, 0), threads=4)
+    dbg = rt.render_debug(sp, cam)
+    for n in ("img",) + PLANES:
+        assert np.array_equal(dbg[n], ref[n]), ("clean refit after the NaNs", n)
+    # a mesh whose every triangle lacks an axis does leave unordered boxes: flagged at upload and by the refit
+    allnan = clean.copy()
+    allnan[:, 2] = nan; allnan[:, 5] = nan; allnan[:, 8] = nan
+    for i in range(len(allnan)):
+        allnan[i, :12] = o.tri_from_vertices(allnan[i, :9])[:12]
+    sp.refit_mesh(0, allnan)
+    assert sp.mesh_flags(0) == 1
+    sp.refit_mesh(0, clean)
+    assert sp.mesh_flags(0) == 0
     so.close()
 
 
@@ -635,6 +658,32 @@ def test_device_resident_rebuild_of_a_mesh(rt, orc, scenes, blob5k):
     sp.rebuild_mesh(0, rest)                                    # and back: the first frame again
     so, om = oracle_scene(rest)
     check(sp, so, "back to rest")
+    # A re-upload that FAILS (the growing path used to replace the host mesh and destroy the device scene before
+    # rt_scene_upload had run): host and device must still describe the old mesh -- it still renders, a refit with the OLD
+    # triangle count is still accepted, and a later attempt with the same triangles succeeds.
+    cap_before = C.c_int32(0)
+    assert h.rt_scene_mesh_capacity(sp.device_handle, 0, C.byref(cap_before)) == 0
+    even_bigger = np.concatenate([bigger, scrambled(1)[:500]])
+    assert len(even_bigger) > cap_before.value
+    handle_before = sp.device_handle
+    os.environ["RT_TEST_FAIL_UPLOAD"] = "1"
+    try:
+        with pytest.raises(rt.RtError):
+            sp.rebuild_mesh(0, even_bigger)
+    finally:
+        del os.environ["RT_TEST_FAIL_UPLOAD"]
+    assert sp.device_handle == handle_before                    # the old device scene is still the scene
+    check(sp, so, "after a failed re-upload")
+    sp.refit_mesh(0, rest)                                      # the host still holds the old mesh: its count is accepted
+    check(sp, so, "refit after a failed re-upload")
+    so.close()
+    sp.rebuild_mesh(0, even_bigger)                             # the same request without the injected failure
+    so, om = oracle_scene(even_bigger)
+    check(sp, so, "grown after the failed attempt")
+    assert h.rt_scene_mesh_capacity(sp.device_handle, 0, C.byref(cap)) == 0 and cap.value == len(even_bigger)
+    # the grown mesh is still a device-built one: growing it again needs no host tree (a re-upload through upload_to_device works too)
+    sp.upload_to_device()
+    check(sp, so, "re-upload of the grown mesh")
     so.close()
 
 
@@ -915,6 +964,51 @@ def test_deep_traversal_stack_spills(rt, orc, scenes):
     img, ref = _compare(rt, orc, desc, W, H, scenes.scaled_K(W), scenes.D_REF, (0.0, -1.0, 0.0, 0, 0, 0))
     assert ref["stats"]["max_stack"] >= 24, ref["stats"]           # the scene really is deep (the reference stack holds 32)
     assert ref["stats"]["hits"] > 0
+
+
+def test_stack_depth_at_the_lds_boundary(rt, orc, scenes):
+    """the kernels without the private overflow of the traversal stack (render_kernel<.., SPILL = false>) are chosen
+    for trees of at most 17 levels -- 16 postponed nodes plus the sentinel fill exactly the 17 LDS rows.  Chains of 15 .. 20
+    levels, whose central rays hold a postponed node on every level, cross that boundary: 16, 17 (the last LDS-only depth) and 18
+    (the first with the overflow) must all be among them, and every plane must equal the oracle's."""
+    W, H = 96, 64
+    K, pose = scenes.scaled_K(W), (0.0, -1.0, 0.0, 0, 0, 0)
+    levels, deepest = set(), {}
+    for n in range(14, 22):
+        desc = sd.deep_stack_scene(n)
+        so = desc.build_oracle(orc)
+        ref = so.render(W, H, K, scenes.D_REF, pose, threads=4)
+        sp = desc.build_product(rt)
+        sp.upload_to_device()
+        cam = rt.Camera(W, H, K, scenes.D_REF)
+        cam.set_pose(pose)
+        depth = sp.info()["max_stack"]
+        levels.add(depth)
+        deepest[depth] = int(ref["stats"]["max_stack"])
+        dbg, ids, img = rt.render_debug(sp, cam), rt.render_ids(sp, cam), rt.render(sp, cam)
+        assert np.array_equal(img, ref["img"]) and np.array_equal(ids["img"], ref["img"]), n
+        for name in PLANES:
+            assert np.array_equal(dbg[name], ref[name]), (n, name)
+        for name in ("hit_inst", "hit_tri"):
+            assert np.array_equal(ids[name], ref[name]), (n, name)
+        # the extension kernels share the stack
+        cam.set_options(4, 1, 1)
+        exr = so.render_ex(W, H, K, scenes.D_REF, pose, 4, 1, 1, threads=4)
+        assert np.array_equal(rt.render_ex(sp, cam)["img"], exr["img"]), n
+        so.close()
+    assert {16, 17, 18} <= levels, levels
+    assert deepest[17] >= 15 and deepest[18] >= 16, deepest      # the rays really fill the stack to (about) the tree's depth
+
+
+def test_forced_overflow_stack_kernels_in_a_child_process():
+    """RT_STACK_SPILL=1 selects the kernels WITH the private overflow for every scene (it is read once per process): the
+    smoke scenes -- shallow trees that otherwise run the LDS-only kernels -- against the oracle in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=dict(os.environ, RT_STACK_SPILL="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stderr[-2000:]
 
 
 # ---- extension (SURVEY 8(f) item 1): spp / bounces / sun+shadow; semantics defined by the oracle (parity unpinned) ------
