@@ -79,7 +79,7 @@ L1_DATA_CLK_PER_WAVE_LOAD = 16.3                  # clocks a CU's L1 spends on o
 SALU_PEAK_GINST = 256 * CLOCK_HZ / 1e9            # one scalar unit per CU (MICROARCH glossary "CU"), one instruction per clock
 STRIPE_ROWS = 16
 MIN_WARM_FRAMES = 320            # 1-spp stream workloads: untimed frames before the timed region, whatever --warmup asks (see run_stream)
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r04_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r05_counters.json")
 _build = importlib.import_module("cuda-raytracing_amd._build")
 
 
@@ -497,6 +497,11 @@ def main():
     bounces = args.bounces if args.bounces >= 0 else wl.get("bounces", 0)
     lighting = args.lighting if args.lighting >= 0 else wl.get("lighting", 0)
     stream_mode = (spp, bounces, lighting) == (1, 0, 0)           # the primary kernel, frames in groups; else one frame per step
+    if not stream_mode and spp >= 4 and args.stripe_rows <= 0:
+        # From 4 samples per pixel on a wave of the extension kernel is 2 x 2 pixels x 16 samples or 1 pixel x 64 samples and a
+        # workgroup tile 4 or 2 rows high: stripes can be that thin at no cost in coherence, and thin stripes deal every rank
+        # the same mix of rows (c5 at 8 ranks, predicted on one GPU: 7.77 x with 16-row stripes, 7.87 x with 4, 7.94 x with 2)
+        STRIPE_ROWS = 4
     K, D = scenes.scaled_K(W), scenes.D_REF
     atrium = args.workload in ("c4", "c6")
     base_pose = wl["cam_pose"] if atrium else scenes.C2_CAMERAS[args.camera]

@@ -1616,9 +1616,18 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     // hiding.  Batches do not use it: the tail of one frame already overlaps the bulk of the next, and measured with the
     // order applied across all frames of a batch (workgroup b -> frame b % F of the tile with rank b / F) whole-frame batches ran -2 % (far) to +4 %
     // (near), a rank's stripes of 32 frames -6 % on one stream but no better than the two alternating streams bench.py uses.
-    if (scene && !debug && !trace_file && !p.hit_instance && !p.hit_triangle && grid.x >= 256 && (size_t)grid.x * grid.y <= ((size_t)1 << 30)) {
+    // (RT_TRACE_ORDERED=1 with RT_TRACE_FILE: the stamps of the heavy-first launch itself, for tools/trace_one.py)
+    const bool trace_ordered = trace_file && getenv("RT_TRACE_ORDERED");
+    if (scene && !debug && (!trace_file || trace_ordered) && !p.hit_instance && !p.hit_triangle && grid.x >= 256 && (size_t)grid.x * grid.y <= ((size_t)1 << 30)) {
         static const bool enabled = [] { const char* e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
-        if (enabled && p.num_frames == 1 && grid.x >= 2048) return launch_ordered(scene, p, stream, synchronize);
+        if (enabled && p.num_frames == 1 && grid.x >= 2048) {
+            if (!trace_ordered) return launch_ordered(scene, p, stream, synchronize);
+            const size_t n = (size_t)grid.x * (kBlock / 64) * 16;
+            RT_HIP(trace_begin(p, n));
+            const int rc = launch_ordered(scene, p, stream, 1);
+            const hipError_t e = trace_end(p, n, trace_file, stream);
+            return rc ? rc : (int)e;
+        }
     }
     const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
     if (trace_file) RT_HIP(trace_begin(p, trace_n));

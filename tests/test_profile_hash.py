@@ -1,4 +1,4 @@
-"""bench.py prices `roofline.frac` with instruction counts from a committed rocprofv3 PMC pass (profiles/r04_counters.json).
+"""bench.py prices `roofline.frac` with instruction counts from a committed rocprofv3 PMC pass (profiles/r05_counters.json).
 Those counts describe one build of the kernels: every entry carries the hash of the kernel source + build flags it was taken
 from, and a line printed by other code says `profile_stale` instead of a fraction (CPU-only: no kernel runs here)."""
 import glob
@@ -40,14 +40,14 @@ def test_one_character_kernel_edit_marks_profile_stale(tmp_path, monkeypatch):
 
 
 def test_committed_counters_carry_their_code_hash():
-    path = os.path.join(ROOT, "profiles", "r04_counters.json")
+    path = os.path.join(ROOT, "profiles", "r05_counters.json")
     table = json.load(open(path))
     assert table, "no committed PMC profile"
     for key, e in table.items():
         assert isinstance(e.get("code_hash"), str) and len(e["code_hash"]) == 16, key
         assert e.get("valu_insts_per_frame", 0) > 0, key
     # every bench line committed beside the counters was priced (tools/summarize_profile.py fills the block from the same run)
-    for f in glob.glob(os.path.join(ROOT, "profiles", "r04_*_bench_line.json")):
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r05_*_bench_line.json")):
         roof = json.load(open(f))["roofline"]
         assert roof["frac"] is not None and roof["profile_stale"] is False, f
 
@@ -57,7 +57,7 @@ def test_headline_profile_is_of_the_code_in_the_tree():
     """The driver runs bench.py on this tree: the committed PMC profile of the headline workload (c2, mid camera) must have been
     taken from the kernels as they are now, or the line would say `profile_stale` and carry no roofline fraction.  A kernel
     edit therefore fails here until tools/profile_bench.sh + tools/summarize_profile.py have been run on the new code."""
-    table = json.load(open(os.path.join(ROOT, "profiles", "r04_counters.json")))
+    table = json.load(open(os.path.join(ROOT, "profiles", "r05_counters.json")))
     assert table["c2_mid_1920x1080_1_0_0"]["code_hash"] == build.kernel_code_hash()
 
 

@@ -2,7 +2,7 @@
 """Turns a tools/profile_bench.sh output directory into the committed summaries under profiles/:
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
   profiles/<tag>_bench_line.json    the line bench.py printed under the profiler
-  profiles/r04_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
+  profiles/r05_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
                                     hash of the kernel source + build flags they were taken from (bench.py checks it)
 A frame = width x height x spp primary rays.  A dispatch of G work-items renders G / (tiles * 256 * spp) frames (one 256-thread
 workgroup per 16x16 tile per frame of the batch, or per sample of the frame), so counters are summed over every dispatch of
@@ -14,7 +14,10 @@ import importlib
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-code_hash = importlib.import_module("cuda-raytracing_amd._build").kernel_code_hash()
+_b = importlib.import_module("cuda-raytracing_amd._build")
+# the hash COMPILED INTO the library that travelled to the GPU box and ran (rt_build_info); it must be the build of this tree
+code_hash = _b.library_code_hash()
+assert code_hash == _b.kernel_code_hash(), "librt_hip.so (%s) is not the build of the sources in the tree (%s)" % (code_hash, _b.kernel_code_hash())
 dst = os.path.join(ROOT, "profiles")
 bench_line = None
 for line in open(os.path.join(src, "stats.log"), errors="ignore"):
@@ -59,7 +62,7 @@ if "TCP_TOTAL_CACHE_ACCESSES_sum" in pf:
     entry["tcp_accesses_per_frame"] = pf["TCP_TOTAL_CACHE_ACCESSES_sum"]
 if "FETCH_SIZE" in pf and "WRITE_SIZE" in pf:
     # KiB units.  No x2 on FETCH_SIZE: the render kernels read 64-B records at unrelated addresses (four 16-B loads per lane),
-    # and for that pattern tools/fetch_calibration.sh measures 0.99 bytes reported per byte read (profiles/r04_fetch_calibration.json);
+    # and for that pattern tools/fetch_calibration.sh measures 0.99 bytes reported per byte read (profiles/r04_fetch_calibration.json, round 4);
     # the x2 of MI355X_MICROARCH.md "HBM" is for 16 B-per-lane streaming reads (0.50 measured with the same tool).  Both
     # counters sit on the fabric side of the L2s: Infinity Cache hits are included.
     entry.update({"hbm_bytes_per_frame": (pf["FETCH_SIZE"] + pf["WRITE_SIZE"]) * 1024, "fetch_bytes_per_frame": pf["FETCH_SIZE"] * 1024,
@@ -82,7 +85,7 @@ if kt:
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-tp = os.path.join(dst, "r04_counters.json")
+tp = os.path.join(dst, "r05_counters.json")
 out = json.load(open(tp)) if os.path.exists(tp) else {}
 out[key] = entry
 json.dump(out, open(tp, "w"), indent=1, sort_keys=True)
