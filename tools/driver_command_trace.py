@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""rocprofv3 --kernel-trace --stats of the driver's exact command (`python3 bench.py --gpus 1 --steps 20 --warmup 5`, run by
+tools/profile_campaign.sh <out> aux) -> profiles/<tag>_driver_command_kernel_stats.csv and _kernel_trace.json: the durations of
+the command's 20-frame launches beside the kernel time the line itself reports.   python tools/driver_command_trace.py <out>/driver r05"""
+import collections, csv, glob, json, os, shutil, statistics, sys
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+line = json.loads([l for l in open(os.path.join(src, "driver_line.json")) if l.startswith("{")][-1])
+kt = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
+ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+groups = collections.defaultdict(list)
+for r in csv.DictReader(open(kt)):
+    if "render_kernel<false, false, false" in r["Kernel_Name"]:
+        grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        groups[grid].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+per_frame = ((line["config"]["width"] + 15) // 16) * ((line["config"]["height"] + 15) // 16) * 256
+out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5",
+       "line": {k: line.get(k) for k in ("value", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repeats")},
+       "line_kernel_ms_per_launch": line["roofline"]["kernel_ms"], "line_frames_per_launch": line["roofline"]["frames_per_launch"],
+       "code_hash": line["roofline"]["code_hash"], "launch_shapes": []}
+for grid, v in sorted(groups.items(), key=lambda kv: -len(kv[1])):
+    out["launch_shapes"].append({"frames_per_launch": round(grid / per_frame, 3), "launches": len(v), "avg_ms": round(sum(v) / len(v), 4),
+                                 "median_ms": round(statistics.median(v), 4), "min_ms": round(min(v), 4), "max_ms": round(max(v), 4)})
+out["note"] = ("the command's 20-frame launches are: the warm-up, the nine timed repeats, the hipEvent probe (what the line's kernel_ms averages) and the "
+               "PCIe-inclusive measurement, whose launches run beside a device-to-host copy of the previous batch (the slow ones); the median is the figure to compare with the line")
+shutil.copy(ks, os.path.join(ROOT, "profiles", "%s_driver_command_kernel_stats.csv" % tag))
+json.dump(out, open(os.path.join(ROOT, "profiles", "%s_driver_command_kernel_trace.json" % tag), "w"), indent=1)
+json.dump(line, open(os.path.join(ROOT, "profiles", "%s_final_bench_driver.json" % tag), "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
