@@ -11,7 +11,8 @@ until enough lanes of its wave have arrived too.  This script replays the per-ra
    park(T)         lanes at a triangle step wait unless at least T lanes are at one, or no lane is at an interior node
 and prices a wave iteration as  C_fetch + C_int * [any interior lane] + C_tri * [any triangle lane]  (VALU instructions, from
 the ISA of the shipped loop: 22 / 33 / 100).
-   python tests/sim_leaf_parking.py [tiles] [camera]
+   python tools/sim_leaf_parking.py [tiles] [camera]
+(An analysis script like tools/fuzz_campaign.py: it reads the CHECKER's per-ray step sequences through tests/orc.py; nothing in the product imports it.)
 """
 import importlib, os, sys
 import ctypes as C
