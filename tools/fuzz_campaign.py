@@ -19,7 +19,7 @@ cases = list(ET.parse(xml).getroot().iter("testcase"))
 bad = [c.get("name") for c in cases if any(ch.tag in ("failure", "error") for ch in c)]
 skipped = [c.get("name") for c in cases if any(ch.tag == "skipped" for ch in c)]
 res = {"campaign": "differential fuzz, HIP path vs CPU oracle, all parity planes", "date": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
-       "kernel_code_hash": importlib.import_module("cuda-raytracing_amd._build").kernel_code_hash(),
+       "kernel_code_hash": importlib.import_module("cuda-raytracing_amd").library_hash(),
        "test_fuzz_random_scenes": {"seeds": [first, first + n], "rng": "numpy.random.default_rng(1000 + seed)", "gpu_built_tree": "seed % 3 == 2"},
        "test_fuzz_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(7000 + seed)", "forms": ["per-lane", "wavefront"]},
        "cases": len(cases), "passed": len(cases) - len(bad) - len(skipped), "failed": bad, "skipped": skipped,
