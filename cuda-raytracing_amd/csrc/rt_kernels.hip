@@ -1584,13 +1584,16 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     if (lds_stack_suffices(p)) hipLaunchKernelGGL((render_kernel<false, false, true, false>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     else hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     RT_HIP(hipGetLastError());
-    if (mine) RT_HIP(hipEventRecord(mine->done, stream));
-    // A new order every kSortInterval-th ordered launch of this frame size (and for the first ones): the costs of a frame a few
-    // frames back order the tiles as well as the last frame's, and a device-wide synchronise right after a launch (the
-    // reference's loop: every two frames) then rarely finds a sort still queued behind the frame it waited for.
-    static const int interval = [] { const char* e = getenv("RT_TILE_SORT_INTERVAL"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+    // The next order is sorted from the costs of EARLIER launches: the sort waits for the launches issued before this one (their
+    // events; this launch's own is recorded below, after the sort has been queued), so it runs on the side stream WHILE this frame
+    // renders.  A device-wide synchronise after a frame -- the reference's loop synchronises every two frames, an interactive
+    // application every frame -- waits for the side stream too, and used to find the sort of the frame it had just waited for
+    // still to be run (round 4: 30-50 us; a quarter of that since the 1024-thread sort, every fourth launch).  Costs one frame
+    // older order the tiles as well.  (This launch writes the cost array while the sort reads it: every cost is read once and
+    // whatever the values, the result is a permutation.  This launch reads d_order[cur], the sort writes the other buffer.)
+    static const int interval = [] { const char* e = getenv("RT_TILE_SORT_INTERVAL"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
     o->launches++;
-    if (mine && !o->pending && (o->cur < 0 || o->launches - o->sorted_at >= (uint64_t)interval)) {
+    if (mine && !o->pending && o->launches > 1 && (o->cur < 0 || o->launches - o->sorted_at >= (uint64_t)interval)) {
         o->sorted_at = o->launches;
         o->target = o->cur < 0 ? 0 : o->cur ^ 1;
         for (auto& e : o->seen) if (e.used) RT_HIP(hipStreamWaitEvent(cache.sort_stream, e.done, 0));
@@ -1599,6 +1602,7 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
         RT_HIP(hipEventRecord(o->sort_done, cache.sort_stream));
         o->pending = true;
     }
+    if (mine) RT_HIP(hipEventRecord(mine->done, stream));
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
 }

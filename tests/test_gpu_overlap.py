@@ -179,3 +179,48 @@ def test_synchronous_and_explicit_stream_calls_keep_their_path(rt, scenes, blob5
         cam.render_scene(sp, img.ptr, img.pitch, synchronize=True)
         assert np.array_equal(img.to_host().reshape(H, W, 3), want)
     assert sp.overlap_stats()[0] - n0 == 5
+
+
+def test_refit_and_rebuild_between_two_frames(rt, orc, scenes, blob5k):
+    """render A -> Scene::refit_mesh / Scene::rebuild_mesh on the default stream -> render B into the other image, no synchronise
+    by the caller in between: A shows the mesh as it was, B as it is now (both calls order their kernels on the NULL stream, which
+    waits for the frames in flight on the scene's two blocking streams and holds back the frames issued after it)."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    W, H = 1280, 720
+    K, pose = scenes.scaled_K(W), scenes.C2_CAMERAS["mid"]
+    rest = rt.Mesh.load_obj(blob5k).dump()["tris"].copy()
+
+    def deformed(step):
+        m = rest.copy()
+        v = m[:, :9].reshape(-1, 3, 3)
+        v[..., 2] += np.float32(0.08 * step) * np.sin(4.0 * v[..., 0] + step)
+        for i in range(len(m)):
+            m[i, :12] = o.tri_from_vertices(m[i, :9])[:12]
+        return m
+
+    sp = rt.Scene()
+    sp.add_material(scenes.C2["albedo"])
+    sp.add_mesh(rt.Mesh.from_triangles(rest, gpu_build=True))
+    sp.add_mesh_instance(0, 0)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose(pose)
+    imgs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(2)]
+    shapes = [rest] + [deformed(k) for k in range(1, 5)]
+    want = []
+    for k, m in enumerate(shapes):                               # reference frames: each shape rendered on its own, synchronously
+        (sp.refit_mesh if k % 2 else sp.rebuild_mesh)(0, m)
+        want.append(rt.render_debug(sp, cam)["img"])
+    assert not np.array_equal(want[0], want[1])
+    sp.rebuild_mesh(0, shapes[0])
+    for k in range(1, len(shapes)):
+        a, b = imgs[k & 1], imgs[(k & 1) ^ 1]
+        cam.render_scene(sp, a.ptr, a.pitch)                                    # the mesh as it was
+        (sp.refit_mesh if k % 2 else sp.rebuild_mesh)(0, shapes[k])             # refit: same topology; rebuild: a new tree
+        cam.render_scene(sp, b.ptr, b.pitch)                                    # the mesh as it is now
+        assert np.array_equal(a.to_host().reshape(H, W, 3), want[k - 1]), ("before", k)
+        assert np.array_equal(b.to_host().reshape(H, W, 3), want[k]), ("after", k)
+    so = sd.SceneDesc([(scenes.C2["albedo"], None)], [("tris", shapes[-1])], [(0, 0, (0,) * 6, (1, 1, 1))]).build_oracle(orc)
+    assert np.array_equal(want[-1], so.render(W, H, K, scenes.D_REF, pose, threads=8, planes=False)["img"])
+    so.close()
