@@ -801,7 +801,12 @@ def test_rotating_stripe_owner(rt, scenes, blob5k):
     h = rt.libs()[0]
     sp = sd.blob_scene(scenes, blob5k).build_product(rt)
     sp.upload_to_device()
-    for (W, H, stripe, world, F) in ((210, 133, 16, 8, 11), (200, 120, 16, 3, 7), (128, 77, 8, 4, 8), (96, 50, 16, 5, 3)):
+    rng = np.random.default_rng(77)
+    shapes = [(210, 133, 16, 8, 11), (200, 120, 16, 3, 7), (128, 77, 8, 4, 8), (96, 50, 16, 5, 3)]
+    for _ in range(12):                                         # and a dozen drawn ones: odd sizes, stripes of 1 .. 33 rows, up to 9 ranks
+        shapes.append((int(rng.integers(17, 230)), int(rng.integers(9, 170)), int(rng.choice([1, 2, 3, 4, 7, 8, 16, 33])),
+                       int(rng.integers(2, 10)), int(rng.integers(3, 13))))
+    for (W, H, stripe, world, F) in shapes:
         cam = rt.Camera(W, H, scenes.scaled_K(W), scenes.D_REF)
         poses = [(0.03 * i, -1.6 - 0.1 * i, 0.2, 0.0, 0.01 * i, 0.0) for i in range(F)]
         full = []
@@ -844,7 +849,8 @@ def test_rotating_stripe_owner(rt, scenes, blob5k):
         # without rotation the same buffers would not un-stripe to the frames (the test can tell the two apart)
         rt.check(h.rt_unstripe_batch(g0, pitch, F * max_rows * pitch, max_rows * pitch, outs.ptr, pitch, H * pitch, F, W, H, stripe, world, None))
         rt.check(h.rt_device_synchronize())
-        assert not np.array_equal(outs.to_host().reshape(F, H, W, 3)[1], full[1])
+        if (W, H, stripe, world, F) in shapes[:4]:
+            assert not np.array_equal(outs.to_host().reshape(F, H, W, 3)[1], full[1])
         outs.free()
         gathered.free()
 
