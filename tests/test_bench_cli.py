@@ -93,3 +93,45 @@ def test_committed_scaling_prediction():
         assert p["predicted_render_speedup"] <= n
     assert per_n[8]["predicted_render_speedup"] >= 7.3
     assert {p["n_gpus"] for p in d["stream"]["driver_shape_per_n"]} == {2, 4, 8}
+
+
+def _barrier_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
+    import time
+    import numpy as np
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = bench.NodeBarrier(rank, world, on_cpu=True)
+    assert b.slots is not None and "shared-memory" in b.kind
+    # every round: one rank is late; nobody may leave the barrier before it has arrived
+    log = []
+    for rnd in range(20):
+        if rank == rnd % world:
+            time.sleep(0.01)
+        arrived = time.monotonic()
+        b.wait()
+        log.append((arrived, time.monotonic()))
+    np.save(os.path.join(out_dir, "b%d.npy" % rank), np.asarray(log))
+    dist.barrier()
+    b.close()
+    dist.destroy_process_group()
+
+
+def test_node_barrier_is_a_barrier(tmp_path):
+    """bench.NodeBarrier (the shared-memory rendezvous that brackets the timed region of an N-rank run on one node): in every round
+    every rank leaves the barrier after the LAST rank has arrived at it."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    world = 3
+    mp.spawn(_barrier_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    logs = np.stack([np.load(str(tmp_path / ("b%d.npy" % r))) for r in range(world)])     # [rank][round][arrived, left]
+    last_arrival = logs[:, :, 0].max(axis=0)
+    assert (logs[:, :, 1] >= last_arrival[None, :]).all()
+    assert not any(n.startswith("rt_bench_barrier_") for n in os.listdir("/dev/shm"))      # rank 0 removed the page

@@ -211,6 +211,9 @@ def _check_per_rank_report(line, world):
     assert any(r["unstripe_ms_per_group"] > 0 for r in ranks)          # somebody assembles frames
     assert line["stripe_share_imbalance"] >= 1.0
     assert set(line["rccl"]) >= {"version", "through", "NCCL_MAX_NCHANNELS"} and line["rccl"]["through"].startswith("rt_comm")
+    # the ranks of one node meet at a shared-memory barrier around the timed region (bench.NodeBarrier), not at an all-reduce
+    assert line["barrier"].startswith("shared-memory rendezvous of the node's %d ranks" % world), line["barrier"]
+    assert "stripe owner rotating" in line["config"]["parallelism"]
 
 
 def test_bench_rank_that_never_joins_ends_the_run_inside_the_deadline(mock_rccl):

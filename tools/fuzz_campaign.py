@@ -13,8 +13,26 @@ xml = out + ".junit.xml"
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 env = dict(os.environ, RT_FUZZ_SEEDS=str(n), RT_FUZZ_FIRST=str(first))
 t0 = time.time()
-r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-k", "fuzz",
-                    "--junitxml", xml, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True)
+# (a line a minute while the cases run: the GPU box's watchdog takes seven silent minutes for a hang)
+proc = subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-k", "fuzz",
+                         "--junitxml", xml, "-p", "no:cacheprovider"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+import threading
+chunks = []
+reader = threading.Thread(target=lambda: chunks.extend(iter(lambda: proc.stdout.read(4096), "")), daemon=True)
+reader.start()
+while proc.poll() is None:
+    try:
+        proc.wait(timeout=60)
+    except subprocess.TimeoutExpired:
+        print("fuzz campaign: %d s, %d bytes of pytest output so far" % (time.time() - t0, sum(len(c) for c in chunks)), flush=True)
+reader.join(timeout=10)
+
+
+class _R:
+    returncode, stdout = proc.returncode, "".join(chunks)
+
+
+r = _R
 cases = list(ET.parse(xml).getroot().iter("testcase"))
 bad = [c.get("name") for c in cases if any(ch.tag in ("failure", "error") for ch in c)]
 skipped = [c.get("name") for c in cases if any(ch.tag == "skipped" for ch in c)]
