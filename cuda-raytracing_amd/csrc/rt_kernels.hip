@@ -1726,10 +1726,18 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     int rc = RT_OK;
     // One record array and one index space for the whole scene: per mesh its interior nodes, then its triangles in
     // leaf order.  The per-triangle side arrays use the same index (their entries at interior records are unused).
+    // The host vectors hold only the parts of meshes that arrive WITH a tree; the part of a mesh the device builds (num_nodes == 0) is
+    // a hole of `skipped` records in them: it is never materialised on the host nor copied (the device arrays start from a memset,
+    // and the build clears and fills the mesh's part itself) -- for the 260 k-triangle atrium that was 50 MB of zeros written,
+    // then copied from pageable memory: a third of the time from file to renderable scene.  A record's index in the device
+    // arrays = its index in the vectors + the holes before it; `segments` says which vector ranges go where.
     std::vector<float4> records;
     std::vector<float> tri_uv;
     std::vector<int32_t> tri_id, leaf_count, mesh_flags;
     std::vector<int> build_on_device;               // meshes that arrive without a tree (num_nodes == 0)
+    struct Segment { size_t dev_first, vec_first, count; };        // in records
+    std::vector<Segment> segments;
+    size_t skipped = 0;                             // records of device-built meshes so far
     try {
         for (int mi = 0; mi < desc->num_meshes && rc == RT_OK; mi++) {
             const RtMeshDesc& m = desc->meshes[mi];
@@ -1738,12 +1746,9 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                 // no tree given: the mesh's part of the arrays is reserved here and the tree is built on the device, in place,
                 // once the arrays are uploaded (the kernels of rt_scene_rebuild_mesh_device) -- no host tree, no host re-layout
                 const int64_t n = m.num_triangles, int_cap = std::max<int64_t>(n - 1, 0);
-                const int64_t node_base = (int64_t)records.size() / 4, slot_base = node_base + int_cap;
+                const int64_t node_base = (int64_t)(records.size() / 4 + skipped), slot_base = node_base + int_cap;
                 if (slot_base + n + 1 > kSlotMask) { rc = RT_E_INVALID; break; }
-                records.resize(records.size() + (size_t)(int_cap + n) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                tri_uv.resize(tri_uv.size() + (size_t)(int_cap + n) * 6, 0.0f);
-                tri_id.resize(tri_id.size() + (size_t)(int_cap + n), -1);
-                leaf_count.resize(leaf_count.size() + (size_t)(int_cap + n), 0);
+                skipped += (size_t)(int_cap + n);                // (a hole in the host vectors: see above)
                 s->mesh_root_ref.push_back(leaf_ref(slot_base, 0));
                 s->mesh_exact_uv.push_back(0);
                 RtScene::MeshRefit rf;
@@ -1762,7 +1767,8 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             for (int i = 0; i < m.num_nodes; i++) mesh_interior += m.node_children[2 * i] > 0 ? 1 : 0;
             // (room for any tree over these triangles: rt_scene_rebuild_mesh_device writes a new one in place)
             const int64_t int_cap = std::max<int64_t>(mesh_interior, (int64_t)m.num_triangles - 1);
-            const int64_t node_base = (int64_t)records.size() / 4, slot_base = node_base + int_cap;
+            const size_t vec_first = records.size() / 4;         // where this mesh's part starts in the host vectors ...
+            const int64_t node_base = (int64_t)(vec_first + skipped), slot_base = node_base + int_cap;      // ... and in the device arrays
             if (slot_base + std::max<int64_t>(m.num_leaf_indices, m.num_triangles) + 1 > kSlotMask) { rc = RT_E_INVALID; break; }
             // pass 1: entry of every node (interior -> running interior index, leaf -> slot range), levels
             std::vector<int32_t> entry((size_t)m.num_nodes), level((size_t)m.num_nodes, 0);
@@ -1806,7 +1812,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
                 if (a > 0) {
                     const float* A = m.node_bounds + 6 * (size_t)a;
                     const float* B = m.node_bounds + 6 * (size_t)b;
-                    float4* q = &records[(size_t)entry[i] * 4];
+                    float4* q = &records[((size_t)entry[i] - skipped) * 4];
                     q[0] = make_float4(A[0], A[1], A[2], A[3]);
                     q[1] = make_float4(A[4], A[5], B[0], B[1]);
                     q[2] = make_float4(B[2], B[3], B[4], B[5]);
@@ -1840,10 +1846,12 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             }
             if (rc != RT_OK) break;
             // unused slots of the mesh's part
-            records.resize(((size_t)slot_base + (size_t)slot_cap) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-            tri_uv.resize(((size_t)slot_base + (size_t)slot_cap) * 6, 0.0f);
-            tri_id.resize((size_t)slot_base + (size_t)slot_cap, -1);
-            leaf_count.resize((size_t)slot_base + (size_t)slot_cap, 0);
+            const size_t vec_end = (size_t)slot_base + (size_t)slot_cap - skipped;
+            records.resize(vec_end * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            tri_uv.resize(vec_end * 6, 0.0f);
+            tri_id.resize(vec_end, -1);
+            leaf_count.resize(vec_end, 0);
+            segments.push_back({(size_t)node_base, vec_first, vec_end - vec_first});
             s->mesh_root_ref.push_back(entry[0]);
             s->mesh_exact_uv.push_back(exact_uv ? 1 : 0);
             mesh_flags.push_back(unordered ? kBoxUnordered : 0);
@@ -1880,11 +1888,29 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     auto fail = [&](int code) { rt_scene_destroy(s); return code; };
     hipError_t he = hipGetDevice(&s->device);
     if (he != hipSuccess) return fail(he == hipErrorNoDevice ? RT_E_NODEVICE : (int)he);
-    for (int k = 0; k < 4; k++) records.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));  // padding: a leaf's last iteration looks one record ahead
-    if ((rc = upload(&s->d_records, records, s->device_bytes))) return fail(rc);
-    if ((rc = upload(&s->d_tri_uv, tri_uv, s->device_bytes))) return fail(rc);
-    if ((rc = upload(&s->d_tri_id, tri_id, s->device_bytes))) return fail(rc);
-    if ((rc = upload(&s->d_leaf_count, leaf_count, s->device_bytes))) return fail(rc);
+    {
+        // the arrays start as what unused records hold -- zeros, triangle id -1 -- plus four padding records (a leaf's last iteration
+        // looks one record ahead); the parts of meshes that came with a tree are copied over that
+        const size_t total = records.size() / 4 + skipped;
+        auto make = [&](void** d, size_t bytes, int byte_value) -> hipError_t {
+            hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 1));
+            if (e == hipSuccess && bytes) e = hipMemset(*d, byte_value, bytes);
+            if (e == hipSuccess) s->device_bytes += std::max<size_t>(bytes, 1);
+            return e;
+        };
+        if ((he = make((void**)&s->d_records, (total + 1) * 4 * sizeof(float4), 0)) != hipSuccess) return fail((int)he);
+        if ((he = make((void**)&s->d_tri_uv, total * 6 * sizeof(float), 0)) != hipSuccess) return fail((int)he);
+        if ((he = make((void**)&s->d_tri_id, total * sizeof(int32_t), 0xff)) != hipSuccess) return fail((int)he);
+        if ((he = make((void**)&s->d_leaf_count, total * sizeof(int32_t), 0)) != hipSuccess) return fail((int)he);
+        for (const Segment& g : segments) {
+            if (g.count == 0) continue;
+            he = hipMemcpy(s->d_records + g.dev_first * 4, records.data() + g.vec_first * 4, g.count * 4 * sizeof(float4), hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(s->d_tri_uv + g.dev_first * 6, tri_uv.data() + g.vec_first * 6, g.count * 6 * sizeof(float), hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(s->d_tri_id + g.dev_first, tri_id.data() + g.vec_first, g.count * sizeof(int32_t), hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(s->d_leaf_count + g.dev_first, leaf_count.data() + g.vec_first, g.count * sizeof(int32_t), hipMemcpyHostToDevice);
+            if (he != hipSuccess) return fail((int)he);
+        }
+    }
     if ((rc = upload(&s->d_mesh_flags, mesh_flags, s->device_bytes))) return fail(rc);
     for (auto& rf : s->mesh_refit) {
         std::vector<int32_t> sched(rf.sched);
