@@ -3,6 +3,7 @@
 // include/rt_hip.h.  Built with -ffp-contract=off like every file that touches rt_math.h.
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cctype>
@@ -16,7 +17,9 @@
 #include <sstream>
 #include <atomic>
 #include <stdexcept>
+#include <chrono>
 #include <thread>
+#include <type_traits>
 
 #include "../../../include/rt_hip.h"
 #include "Camera.h"
@@ -968,11 +971,24 @@ void obj_pass1(ObjPiece& pc)
     }
 }
 
+// A vector of tens of megabytes that is about to be filled: ask for transparent huge pages for its (page-aligned) inside, so that
+// filling it takes a handful of page faults instead of one per 4 KB -- the first touch of fresh memory was half of the second
+// pass's time, and page faults of several threads of one process queue on the same lock.  A hint: ignored where THP is off.
+template <class T>
+void advise_huge_pages(std::vector<T>& v)
+{
+    const size_t bytes = v.capacity() * sizeof(T);
+    if (bytes < ((size_t)4 << 20)) return;
+    const uintptr_t a = ((uintptr_t)v.data() + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)v.data() + bytes) & ~(uintptr_t)4095;
+    if (b > a) (void)madvise((void*)a, (size_t)(b - a), MADV_HUGEPAGE);
+}
+
 // faces [f0, f1) -> fan triangles (OBJLoader.hpp:90-171)
 void obj_pass2(const std::vector<ObjFace>& faces, size_t f0, size_t f1, const std::vector<float3>& vertices,
                const std::vector<float2>& tex_coords, bool lenient, std::vector<TrianglePrimitive>& triangles, std::string& error)
 {
     triangles.reserve(triangles.size() + (f1 - f0) + (f1 - f0) / 8);
+    advise_huge_pages(triangles);
     std::vector<int> vi, ti;
     const int nv = (int)vertices.size(), nt = (int)tex_coords.size();
     for (size_t fi = f0; fi < f1; fi++) {
@@ -1038,8 +1054,17 @@ void run_pieces(int threads, int n, F&& body)       // body(k) for k in [0, n): 
 bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& triangles, std::string* error, bool lenient)
 {
     auto fail = [&](const std::string& msg) { if (error) *error = msg; return false; };
+    const bool dbg = getenv("RT_OBJ_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_last = t_begin;
+    long f_last = 0;
+    auto faults = [] { struct rusage ru; getrusage(RUSAGE_SELF, &ru); return ru.ru_minflt; };
+    if (dbg) f_last = faults();
+    auto lap = [&](const char* what) { if (dbg) { const double t = now(); const long f = faults(); fprintf(stderr, "  obj parse: %-28s %7.2f ms  %6ld page faults\n", what, t - t_last, f - f_last); t_last = t; f_last = f; } };
     MappedFile file(fp.c_str());
     if (!file.ok) return fail("Could not open file " + fp);
+    lap("map");
     const char* const data = file.data;
     const char* const fend = data + file.size;
     int threads = 1;
@@ -1063,27 +1088,42 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
     }
     // pass 1: v / vt records (vn is accepted and unused, OBJLoader.hpp:55-62); remember face lines
     // (an exception must not leave a worker thread: out of memory becomes this piece's error)
+    // (a worker fills a piece of its OWN and moves it into the shared array at the end: the headers of neighbouring pieces'
+    // vectors -- whose end pointers every push_back moves -- share cache lines, and with two threads on neighbouring pieces
+    // that false sharing made the passes SLOWER than on one thread)
     run_pieces(threads, npieces, [&](int k) {
-        try { obj_pass1(pieces[(size_t)k]); } catch (const std::exception&) { pieces[(size_t)k].error = "out of memory while reading the file"; }
+        ObjPiece mine;
+        mine.begin = pieces[(size_t)k].begin; mine.end = pieces[(size_t)k].end;
+        try { obj_pass1(mine); } catch (const std::exception&) { mine.error = "out of memory while reading the file"; }
+        pieces[(size_t)k] = std::move(mine);
     });
     for (const ObjPiece& pc : pieces) if (!pc.error.empty()) return fail(pc.error);
+    lap("pass 1 (records)");
     std::vector<float3> vertices;
     std::vector<float2> tex_coords;
     std::vector<ObjFace> faces;
     if (threads == 1) {
         vertices.swap(pieces[0].vertices); tex_coords.swap(pieces[0].tex_coords); faces.swap(pieces[0].faces);
     } else {
-        size_t nv = 0, nt = 0, nf = 0;
-        for (const ObjPiece& pc : pieces) { nv += pc.vertices.size(); nt += pc.tex_coords.size(); nf += pc.faces.size(); }
-        vertices.reserve(nv); tex_coords.reserve(nt); faces.reserve(nf);
-        for (ObjPiece& pc : pieces) {
-            const int bv = (int)vertices.size(), bt = (int)tex_coords.size();
-            for (ObjFace& f : pc.faces) { f.nv += bv; f.nt += bt; }
-            vertices.insert(vertices.end(), pc.vertices.begin(), pc.vertices.end());
-            tex_coords.insert(tex_coords.end(), pc.tex_coords.begin(), pc.tex_coords.end());
-            faces.insert(faces.end(), pc.faces.begin(), pc.faces.end());
+        // the pieces' records joined in file order -- by all threads: every piece knows where its records start once the counts
+        // are summed (the join and the concatenation of the triangles below were the serial third of a large file's parse)
+        std::vector<size_t> bv((size_t)npieces + 1, 0), bt((size_t)npieces + 1, 0), bf((size_t)npieces + 1, 0);
+        for (int k = 0; k < npieces; k++) {
+            bv[(size_t)k + 1] = bv[(size_t)k] + pieces[(size_t)k].vertices.size();
+            bt[(size_t)k + 1] = bt[(size_t)k] + pieces[(size_t)k].tex_coords.size();
+            bf[(size_t)k + 1] = bf[(size_t)k] + pieces[(size_t)k].faces.size();
         }
+        vertices.resize(bv.back()); tex_coords.resize(bt.back()); faces.resize(bf.back());
+        run_pieces(threads, npieces, [&](int k) {
+            ObjPiece& pc = pieces[(size_t)k];
+            for (ObjFace& f : pc.faces) { f.nv += (int)bv[(size_t)k]; f.nt += (int)bt[(size_t)k]; }
+            if (!pc.vertices.empty()) memcpy(&vertices[bv[(size_t)k]], pc.vertices.data(), pc.vertices.size() * sizeof(float3));
+            if (!pc.tex_coords.empty()) memcpy(&tex_coords[bt[(size_t)k]], pc.tex_coords.data(), pc.tex_coords.size() * sizeof(float2));
+            if (!pc.faces.empty()) memcpy(&faces[bf[(size_t)k]], pc.faces.data(), pc.faces.size() * sizeof(ObjFace));
+            std::vector<float3>().swap(pc.vertices); std::vector<float2>().swap(pc.tex_coords); std::vector<ObjFace>().swap(pc.faces);
+        });
     }
+    lap("join records");
     // pass 2
     if (threads == 1) {
         std::string err;
@@ -1093,16 +1133,28 @@ bool OBJLoader::parse(const std::string& fp, std::vector<TrianglePrimitive>& tri
     std::vector<std::vector<TrianglePrimitive>> part((size_t)npieces);
     std::vector<std::string> errs((size_t)npieces);
     run_pieces(threads, npieces, [&](int k) {
+        std::vector<TrianglePrimitive> mine;
+        std::string err;
         try {
             obj_pass2(faces, faces.size() * (size_t)k / (size_t)npieces, faces.size() * (size_t)(k + 1) / (size_t)npieces, vertices, tex_coords,
-                      lenient, part[(size_t)k], errs[(size_t)k]);
-        } catch (const std::exception&) { errs[(size_t)k] = "out of memory while building the triangles"; }
+                      lenient, mine, err);
+        } catch (const std::exception&) { err = "out of memory while building the triangles"; }
+        part[(size_t)k] = std::move(mine);
+        errs[(size_t)k] = std::move(err);
     });
     for (const std::string& e : errs) if (!e.empty()) return fail(e);
-    size_t total = triangles.size();
-    for (const auto& v : part) total += v.size();
-    triangles.reserve(total);
-    for (const auto& v : part) triangles.insert(triangles.end(), v.begin(), v.end());
+    lap("pass 2 (triangles)");
+    std::vector<size_t> at((size_t)npieces + 1, triangles.size());
+    for (int k = 0; k < npieces; k++) at[(size_t)k + 1] = at[(size_t)k] + part[(size_t)k].size();
+    triangles.reserve(at.back());
+    advise_huge_pages(triangles);
+    triangles.resize(at.back());
+    static_assert(std::is_trivially_copyable<TrianglePrimitive>::value, "the parts are placed with memcpy");
+    run_pieces(threads, npieces, [&](int k) {
+        if (!part[(size_t)k].empty()) memcpy((void*)&triangles[at[(size_t)k]], (const void*)part[(size_t)k].data(), part[(size_t)k].size() * sizeof(TrianglePrimitive));
+        std::vector<TrianglePrimitive>().swap(part[(size_t)k]);
+    });
+    lap("concatenate");
     return true;
 }
 
