@@ -49,6 +49,10 @@ using namespace rt;
 #ifndef RT_EX_PEEL
 #define RT_EX_PEEL 1            // render_ex_kernel: the primary ray's depth written out before the bounce loop (measured -0.7 % on c3, same log)
 #endif
+#ifndef RT_OPTIMISTIC_STACK
+#define RT_OPTIMISTIC_STACK 1   // deep trees: the timed kernels run the LDS-only stack and a lane whose stack would outgrow it starts again on the
+                                // general stack afterwards (render_pixel), instead of every push and pop asking "which memory"
+#endif
 #ifndef RT_NEED_POP_VALUE
 #define RT_NEED_POP_VALUE 1     // "this lane must pop" is a value of `cur` (kNeedPop), not a flag merged across the loop's branches
 #endif
@@ -159,8 +163,15 @@ typedef __attribute__((address_space(3))) int lds_int;      // typed LDS pointer
 // SPILL = false: the tree is shallow enough for the LDS part alone (a tree of L levels never holds more than L - 1 postponed
 // nodes: the entries of a stack sit at strictly increasing levels below the root) -- no private array, and neither push
 // nor pop carries the "which memory" branch (5 + 4 scalar instructions of exec-mask bookkeeping per iteration).
-template <int STRIDE, bool SPILL = true>                    // STRIDE = threads per workgroup (ints between two entries of a lane)
+// OPTIMISTIC (with SPILL = false, for trees that ARE deeper than the LDS part): the block has one more row, which takes the
+// push that does not fit; interior_apply then hands the lane the sentinel, the lane leaves its loop with sp != 0, and the
+// caller traces that ray again from the start on a SPILL stack.  Which rays need more than 16 postponed nodes depends on the
+// view (none of the three c2 cameras has one in a 28-level tree), so the common case pays two vector instructions per push
+// instead of nine scalar ones per iteration.
+template <int STRIDE, bool SPILL = true, bool OPTIMISTIC = false>   // STRIDE = threads per workgroup (ints between two entries of a lane)
 struct StackT {
+    static constexpr bool kOptimistic = OPTIMISTIC;
+    static_assert(!(SPILL && OPTIMISTIC), "the optimistic stack is the LDS-only one");
     lds_int* lds;               // this lane's LDS column
     int* spill;                 // this lane's private overflow, kMaxStack - kLdsStack entries
     int lds_depth;              // entries kept in LDS: lds_rows(stack_depth)
@@ -237,6 +248,8 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     if (pa && pb) {
         stack.push(a_near ? rb : ra);                           // the only entry that really goes through the stack
         next = a_near ? ra : rb;
+        // (optimistic stack: that push went to the spare row -- this lane is done here and will be traced again, see StackT)
+        if constexpr (STK::kOptimistic) next = stack.sp > stack.lds_depth ? kSentinel : next;
     }
     cur = NEED_POP ? ((pa | pb) ? next : kNeedPop) : next;      // (without NEED_POP: not used when neither passed, the caller pops)
     return pa || pb;
@@ -599,6 +612,12 @@ __device__ __forceinline__ void pixel_of(const RenderParams& p, const FrameParam
     if (p.num_ranks != 1) y = ((ly / p.stripe_rows) * p.num_ranks + f.rank) * p.stripe_rows + ly % p.stripe_rows;
 }
 
+// whether render_kernel<DEBUG, PROF, ., SPILL> runs the optimistic stack (StackT), and the rows of its LDS block
+template <bool DEBUG, bool PROF, bool SPILL>
+__host__ __device__ constexpr bool optimistic_stack() { return RT_OPTIMISTIC_STACK && RT_SENTINEL && SPILL && !DEBUG && !PROF; }
+template <bool DEBUG, bool PROF, bool SPILL>
+__host__ __device__ inline int lds_block_rows(int stack_depth) { return lds_rows(stack_depth) + (optimistic_stack<DEBUG, PROF, SPILL>() ? 1 : 0); }
+
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
 template <bool DEBUG, bool PROF, bool COUNT = false, bool SPILL = true>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x0, int y0, lds_int* lds_base, lds_int*& lds_column,
@@ -612,11 +631,32 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
     Counters<DEBUG> cnt;
-    int spill[SPILL ? kMaxStack - kLdsStack : 1];
-    StackT<kBlock, SPILL> stack;
-    stack.lds = lds_column; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
-    for (int i = 0; i < p.num_instances; i++)                   // raycast.cu:26
-        trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, SPILL>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
+    if constexpr (optimistic_stack<DEBUG, PROF, SPILL>()) {
+        // A tree deeper than the LDS part of the stack, a ray that (almost always) is not: the LDS-only loops, and the general
+        // stack only for the lanes that turn out to need it -- from the start of the ray, so the hit is the one the general kernel
+        // finds (the instrumented kernel keeps the general stack throughout: its counts are per ray, not per attempt).
+        StackT<kBlock, false, true> stack;
+        stack.lds = lds_column; stack.spill = nullptr; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
+        int outgrown = 0;                                       // a loop left through the spare row ends with sp != 0
+        for (int i = 0; i < p.num_instances; i++) {             // raycast.cu:26
+            trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, false, true>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
+            outgrown |= stack.sp;
+        }
+        if (outgrown != 0) {
+            int spill[kMaxStack - kLdsStack];
+            StackT<kBlock, true> deep;
+            deep.lds = lds_column; deep.spill = spill; deep.lds_depth = lds_rows(p.stack_depth); deep.sp = 0;
+            hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
+            for (int i = 0; i < p.num_instances; i++)
+                trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, true>, false, false>(p, p.instances[i], i, org, dir, deep, hit, cnt, iters);
+        }
+    } else {
+        int spill[SPILL ? kMaxStack - kLdsStack : 1];
+        StackT<kBlock, SPILL> stack;
+        stack.lds = lds_column; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
+        for (int i = 0; i < p.num_instances; i++)               // raycast.cu:26
+            trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, SPILL>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
+    }
 
     // The pixel's coordinates are not kept across the traversal (three registers in a kernel that has none to spare: they
     // were spilled to scratch): they are derived again from the one per-thread value the loop keeps anyway, the address of
@@ -653,7 +693,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
 template <bool DEBUG, bool PROF, bool ORDERED = false, bool SPILL = true>
 __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
 {
-    extern __shared__ int lds_stack[];                          // [lds_rows(stack_depth)][kBlock] (+ 2 ints when ORDERED)
+    extern __shared__ int lds_stack[];                          // [lds_block_rows(stack_depth)][kBlock] (+ 2 ints when ORDERED)
 
     // Workgroup b renders tile b (row-major).  Consecutive workgroups are dealt round-robin to the 8 XCDs, so every
     // XCD sees tiles from the whole frame: measured faster than giving each XCD one contiguous band (better load
@@ -667,7 +707,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
         frame = tile % p.num_frames;
         tile = tile / p.num_frames;
         if (p.tile_order) tile = p.tile_order[tile];
-        group = (lds_int*)lds_stack + lds_rows(p.stack_depth) * kBlock;
+        group = (lds_int*)lds_stack + lds_block_rows<DEBUG, PROF, SPILL>(p.stack_depth) * kBlock;
         if (threadIdx.x == 0) { group[0] = 0; group[1] = 0; }
         __syncthreads();                                        // (at the very start: the four waves arrive together)
     }
@@ -1580,7 +1620,8 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     }
     p.tile_order = (mine && o->cur >= 0) ? o->d_order[o->cur] : nullptr;
     p.tile_cost = mine ? o->d_cost : nullptr;
-    const size_t lds = (size_t)lds_rows(p.stack_depth) * kBlock * sizeof(int) + 2 * sizeof(int);
+    const size_t lds = (size_t)(lds_stack_suffices(p) ? lds_block_rows<false, false, false>(p.stack_depth) : lds_block_rows<false, false, true>(p.stack_depth)) *
+                       kBlock * sizeof(int) + 2 * sizeof(int);
     if (lds_stack_suffices(p)) hipLaunchKernelGGL((render_kernel<false, false, true, false>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     else hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
     RT_HIP(hipGetLastError());
@@ -1613,7 +1654,8 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     if (p.local_rows == 0) return RT_OK;
     p.tiles_x = (p.width + kTile - 1) / kTile;
     p.tiles_y = (p.local_rows + kTile - 1) / kTile;
-    const size_t lds = (size_t)lds_rows(p.stack_depth) * kBlock * sizeof(int);
+    // (one size for whichever kernel is launched below: the spare row of the optimistic stack costs the instrumented kernels nothing)
+    const size_t lds = (size_t)(lds_stack_suffices(p) ? lds_rows(p.stack_depth) : lds_block_rows<false, false, true>(p.stack_depth)) * kBlock * sizeof(int);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kBlock);
     const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
     // Heavy-first dispatch (RT_TILE_ORDER=0 turns it off): for one frame per launch with enough tiles to have a tail worth
