@@ -66,6 +66,7 @@ struct DevMaterial {            // Material.hpp:6-16
 constexpr int kExMaxGroup = 32;
 constexpr int kExPlanesA = 5, kExPlanesS = 7;
 
+constexpr int kMaxViewInstances = 8;    // scenes of more instances render without view records (RenderParams::view_inst_off)
 constexpr int kMaxBatch = 32;   // frames per launch (rt_render_batch); 32 x 96 B of per-frame parameters keep the kernel
                                 // arguments under the 4 KB limit
 
@@ -125,6 +126,10 @@ struct RenderParams {
     int32_t depth;              // depth of the rays this launch casts
     int32_t gen_samples;        // primary launch: sample indices in this chunk
     int32_t gen_spw;            // primary launch: sample indices per workgroup (4, 2 or 1: one, two or four 8x8 quads)
+    // render_kernel<.., VIEW>: the view record of interior record `e` of instance i in frame f is at byte offset
+    // view_base + f * view_frame_stride + view_inst_off[i] + e * 64 from `records` (32-bit arithmetic; RtScene::ViewPool)
+    uint32_t view_base, view_frame_stride;
+    int32_t view_inst_off[kMaxViewInstances];
     // parity planes (tight [height][width], frame coordinates), any may be null
     int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;
 };

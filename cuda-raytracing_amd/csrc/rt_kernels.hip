@@ -63,8 +63,15 @@ using namespace rt;
 
 namespace {
 
-constexpr int kBlock = 256;     // 4 waves: one 16x16-pixel tile = 2x2 wave tiles of 8x8 pixels (64-thread groups measured +-2 %)
+constexpr int kBlock = 256;     // the extension kernels' workgroup: one 16x16-pixel tile = 2x2 wave tiles of 8x8 pixels
 constexpr int kTile = 16;
+// The primary kernels' workgroup is ONE wave = one 8x8-pixel tile (round 5).  A 256-thread workgroup keeps its LDS block until its
+// last wave has finished, and no new workgroup fits a CU whose LDS is taken by eight of them: the slots of waves that finished
+// early stood empty -- SQ_WAVE_CYCLES put the average residency at 6.7 of 8 waves per SIMD.  With one wave per workgroup a slot is
+// refilled the moment its wave ends: c2 far / mid / near -7.7 % / -3.4 % / -4.2 % (profiles/r05_experiments/asm_loop_ab.log).
+// (Round 2 measured this form at +-2 %: the kernel of that round was bound by its instruction count, not by waves waiting.)
+constexpr int kPrimBlock = 64;
+constexpr int kPrimTile = 8;
 
 struct Hit {
     float min;                  // HitInfo::min, raycast.cu:12
@@ -171,6 +178,8 @@ typedef __attribute__((address_space(3))) int lds_int;      // typed LDS pointer
 template <int STRIDE, bool SPILL = true, bool OPTIMISTIC = false>   // STRIDE = threads per workgroup (ints between two entries of a lane)
 struct StackT {
     static constexpr bool kOptimistic = OPTIMISTIC;
+    static constexpr bool kSpill = SPILL;
+    static constexpr int kStride = STRIDE;
     static_assert(!(SPILL && OPTIMISTIC), "the optimistic stack is the LDS-only one");
     lds_int* lds;               // this lane's LDS column
     int* spill;                 // this lane's private overflow, kMaxStack - kLdsStack entries
@@ -223,19 +232,22 @@ __device__ __forceinline__ MeshRay to_mesh_space(const DevInstance& in, V3 org, 
 // One interior node (raycast.cu:66-79) from its already fetched 64-B record: tests both children, pushes the
 // far one if it passes `dist < hit.min`, and leaves in `cur` the entry the reference would pop next (the entry
 // pushed last never goes through the stack).  Returns false when nothing was pushed.
-template <bool DEBUG, class STK, int OCT = -1, bool NEED_POP = false>
-__device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, float4 q3, const MeshRay& r, float hit_min,
-                                               int32_t& cur, STK& stack, Counters<DEBUG>& cnt)
+// W: the record's first fourteen words, box words already as box - origin: an array of the lane's registers, or the scalar-register
+// vector of a wave-uniform fetch of a VIEW record (the products of the slab test then take their box operand from the scalar
+// register: no copy, no subtraction).
+template <bool DEBUG, class STK, int OCT = -1, bool NEED_POP = false, class W>
+__device__ __forceinline__ bool interior_apply_words(const W& w, const MeshRay& r, float hit_min,
+                                                     int32_t& cur, STK& stack, Counters<DEBUG>& cnt)
 {
-    float da, db;                                                       // q0..q2: box - origin (box_differences)
+    float da, db;                                                       // w[0..11]: box - origin (box_differences, or a view record)
     if constexpr (OCT < 0) {
-        da = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.dinv);
-        db = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.dinv);
+        da = slab(w[0], w[1], w[2], w[3], w[4], w[5], r.dinv);
+        db = slab(w[6], w[7], w[8], w[9], w[10], w[11], r.dinv);
     } else {
-        da = slab_oct<OCT>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.dinv);
-        db = slab_oct<OCT>(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.dinv);
+        da = slab_oct<OCT>(w[0], w[1], w[2], w[3], w[4], w[5], r.dinv);
+        db = slab_oct<OCT>(w[6], w[7], w[8], w[9], w[10], w[11], r.dinv);
     }
-    int32_t ra = __float_as_int(q3.x), rb = __float_as_int(q3.y);
+    int32_t ra = __float_as_int(w[12]), rb = __float_as_int(w[13]);
     if constexpr (DEBUG) cnt.aabb += 2;
     // push order of raycast.cu:72-79: the farther child is pushed first, the nearer one last (= popped next); each only if
     // its distance passes `dist < hit.min`.  With pa / pb = "child a / b passes": both pass -> push the far one (b when
@@ -253,6 +265,14 @@ __device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, 
     }
     cur = NEED_POP ? ((pa | pb) ? next : kNeedPop) : next;      // (without NEED_POP: not used when neither passed, the caller pops)
     return pa || pb;
+}
+
+template <bool DEBUG, class STK, int OCT = -1, bool NEED_POP = false>
+__device__ __forceinline__ bool interior_apply(float4 q0, float4 q1, float4 q2, float4 q3, const MeshRay& r, float hit_min,
+                                               int32_t& cur, STK& stack, Counters<DEBUG>& cnt)
+{
+    const float w[14] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+    return interior_apply_words<DEBUG, STK, OCT, NEED_POP>(w, r, hit_min, cur, stack, cnt);
 }
 
 // What a triangle test proposes as the new closest hit.  Deliberately left uninitialised by the callers: it is only
@@ -341,10 +361,15 @@ __device__ __forceinline__ bool triangle_test(const RenderParams& p, const DevIn
 // OCT >= 0: every lane of the wave is known to hold a ray of sign octant OCT that meets slab_oct's preconditions.
 // ANYHIT (the extension's shadow rays): raycast.cu:129-133 restored -- cast_ray(..., lighting_pass = true, light_distance =
 // FLT_MAX) returns at the first accepted hit whose distance is below light_distance.
-template <bool DEBUG, bool PROF, bool EX, bool COUNT, class STK, bool POPS, int OCT, bool ANYHIT = false>
+// VIEW (primary rays of render_kernel<.., VIEW>): interior records are read from the frame's view records, `vdelta` bytes behind the
+// record itself, whose box words already are box - r.ro (view_records_kernel: the same subtraction, done once per frame and
+// instance instead of per visit and lane); an iteration in which the whole wave holds the same interior node takes them as
+// scalar operands and skips the leaf half of the loop altogether.
+template <bool DEBUG, bool PROF, bool EX, bool COUNT, class STK, bool POPS, int OCT, bool ANYHIT = false, bool VIEW = false>
 __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInstance& in, int inst_index, const MeshRay& r,
-                                           V3 org, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters, int* pops)
+                                           V3 org, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters, int* pops, uint32_t vdelta = 0)
 {
+    static_assert(!VIEW || (!DEBUG && !PROF && !EX && RT_SENTINEL && RT_LEAF_FLAT), "view records: the timed primary kernels only");
     stack.sp = 0;
 #if RT_SENTINEL
     // The stack starts with a sentinel (raycast.cu:58 starts it with the root, which here stays in a register): "pop from an
@@ -380,8 +405,40 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
         // path, which is otherwise the busiest unit of the kernel (-9..-13 % frame time).
         float4 r0, r1, r2, r3;          // the record; for interior lanes r0..r2 become child boxes - ray origin
         const int32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        if constexpr (VIEW) {
+            const bool one_entry = __ballot(cur != cur0) == 0ull;   // (wave-uniform) every lane holds the same entry
+            if (one_entry && cur0 >= 0) {
+                // The whole wave at one interior node: its VIEW record (box words = box - r.ro already) through the scalar cache,
+                // used where it arrives -- as scalar operands of the slab products.  The iteration closes itself: no lane is at a leaf.
+                f16v w;
+                const uint32_t off = ((uint32_t)cur0 << 6) + vdelta;
+                asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p.records), "s"(off));
+                have = interior_apply_words<DEBUG, STK, OCT, kNeedPopValue>(w, r, hit.min, cur, stack, cnt);
+                if (kNeedPopValue ? cur == kNeedPop : !have) cur = stack.pop();
+                __builtin_amdgcn_wave_barrier();
+                continue;                                       // (to the bottom test: the sentinel may have been popped)
+            }
+            if (one_entry) {
+                // the whole wave at one triangle record: copied for the code the per-lane fetch shares (through an OR with a zero
+                // the optimiser cannot see through: plain copies are hoisted above the branch and run in every iteration)
+                f16v w;
+                const uint32_t off = (uint32_t)cur0 << 6;
+                asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p.records), "s"(off));
+                int z;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                auto keep = [z](float f) { return __int_as_float(__float_as_int(f) | z); };
+                r0 = make_float4(keep(w[0]), keep(w[1]), keep(w[2]), keep(w[3]));
+                r1 = make_float4(keep(w[4]), keep(w[5]), keep(w[6]), keep(w[7]));
+                r2 = make_float4(keep(w[8]), keep(w[9]), keep(w[10]), keep(w[11]));
+                r3 = make_float4(keep(w[12]), keep(w[13]), keep(w[14]), keep(w[15]));
+            } else {
+                const uint32_t boff = ((uint32_t)cur << 6) + (interior ? vdelta : 0u);
+                const float4* rec = (const float4*)((const char*)p.records + boff);
+                r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3];
+            }
+        } else
         if (!PROF && __ballot(cur != cur0) == 0ull) {
-            typedef float f16v __attribute__((ext_vector_type(16)));
             f16v w;
             // inline asm: hipcc would otherwise merge this load with the per-lane one below into a single vector load.
             // No "memory" clobber: the records are read-only, and a clobber makes every other load in the loop
@@ -508,11 +565,352 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
             for (int o = 32; o > 0; o >>= 1) { unsigned long long x = __shfl_xor(best, o); best = x > best ? x : best; }
             const unsigned long long owner = __ballot(n_it == best);
             if ((int)(threadIdx.x & 63) == __ffsll((long long)owner) - 1) {
-                unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)) * 16 + 4;
+                unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kPrimBlock / 64) + (threadIdx.x >> 6)) * 16 + 4;
                 for (int k = 0; k < 10; k++) t[k] += v[k];
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The traversal loop of the timed primary kernels, written in gfx950 assembly (RT_ASM_LOOP; the C++ loop above stays the
+// reference form, the instrumented kernels' loop and the loop of every case this one does not take).
+//
+// Why: on this kernel every instruction costs the same, whatever unit executes it -- measured over four rounds of variants
+// the frame time follows the TOTAL of instructions issued (vector + scalar + branch) at 0.67 us per million and frame
+// (profiles/r05_experiments/instruction_issue_model.md) -- and a third of the compiler's loop is control flow: its structurizer
+// wraps every condition in save / restore / skip sequences and keeps wave-uniform decisions in lane masks.  Written by hand an
+// iteration needs two exec regions (the lanes at an interior node, the lanes at a triangle) with the push and the accepted
+// hit as sub-regions, scalar branches for what is wave-uniform, and no flags.
+// Scope: production primary rays (no counters), the LDS-only stack (plain or optimistic, see StackT), an instance without
+// exact-uv mode whose mesh -> world transform is the identity, a wave with a known sign octant (trace_instance's conditions
+// for slab_oct).  Same arithmetic, instruction for instruction, as the C++ loop compiles to: the operations, their order and
+// the IEEE division / square-root expansions are taken from the compiler's own output, so every bit of every result is
+// the same (the parity tests compare this loop's frames and hit ids with the instrumented kernel's and the oracle's).
+//
+// Registers: v0..v15 the record, v16..v27 temporaries, s[48:63] the record of a wave-uniform fetch, s[30:45] masks and
+// scalars, s[46:47] the exec mask the loop was entered with; the ray, the hit and the stack state are operands.
+// Hazards (gfx940 family): a VALU-written SGPR / VCC needs two wait states before a VALU reads it (none before a SALU read),
+// four before v_div_fmas reads VCC; a transcendental result one before a non-transcendental VALU uses it.
+#ifndef RT_ASM_LOOP
+#define RT_ASM_LOOP 1
+#endif
+#ifndef RT_ASM_GUARD
+#define RT_ASM_GUARD 0
+#endif
+
+// one interior node: v0..v11 hold box - origin, v12 / v13 the two child entries; exec = the lanes at this node.
+// N* / F* = the registers holding the near / far plane of the axis for this octant (slab_oct's operand choice).
+#define RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+    "v_mul_f32 v16, " AXN ", %[dix]\n\t"  "v_mul_f32 v17, " AYN ", %[diy]\n\t"  "v_mul_f32 v18, " AZN ", %[diz]\n\t" \
+    "v_mul_f32 v19, " AXF ", %[dix]\n\t"  "v_mul_f32 v20, " AYF ", %[diy]\n\t"  "v_mul_f32 v21, " AZF ", %[diz]\n\t" \
+    "v_max3_f32 v16, v16, v17, v18\n\t"                 /* near of a */ \
+    "v_min3_f32 v19, v19, v20, v21\n\t"                 /* far of a */ \
+    "v_mul_f32 v22, " BXN ", %[dix]\n\t"  "v_mul_f32 v23, " BYN ", %[diy]\n\t"  "v_mul_f32 v24, " BZN ", %[diz]\n\t" \
+    "v_mul_f32 v25, " BXF ", %[dix]\n\t"  "v_mul_f32 v26, " BYF ", %[diy]\n\t"  "v_mul_f32 v27, " BZF ", %[diz]\n\t" \
+    "v_max3_f32 v22, v22, v23, v24\n\t"                 /* near of b */ \
+    "v_min3_f32 v25, v25, v26, v27\n\t"                 /* far of b */ \
+    "v_cmp_ge_f32_e32 vcc, v19, v16\n\t" \
+    "v_cmp_lt_f32_e64 s[38:39], 0, v19\n\t" \
+    "v_cmp_ge_f32_e64 s[40:41], v25, v22\n\t" \
+    "v_cmp_lt_f32_e64 s[42:43], 0, v25\n\t" \
+    "v_mov_b32_e32 v17, 0x7f7fffff\n\t" \
+    "s_and_b64 vcc, vcc, s[38:39]\n\t" \
+    "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t" \
+    "v_cndmask_b32_e32 v16, v17, v16, vcc\n\t"          /* da = hit ? near : FLT_MAX */ \
+    "v_cndmask_b32_e64 v22, v17, v22, s[40:41]\n\t"     /* db */ \
+    "v_cmp_lt_f32_e64 s[38:39], v16, %[hmin]\n\t"       /* pa */ \
+    "v_cmp_lt_f32_e64 s[40:41], v22, %[hmin]\n\t"       /* pb */ \
+    "v_cmp_lt_f32_e64 s[42:43], v16, v22\n\t"           /* a is the nearer */ \
+    "s_and_b64 s[44:45], s[38:39], s[40:41]\n\t"        /* both pass: one is pushed */ \
+    "s_or_b64 vcc, s[38:39], s[40:41]\n\t"              /* any passes */ \
+    "v_cndmask_b32_e64 v18, v13, v12, s[38:39]\n\t"     /* next = pa ? a : b */ \
+    "s_and_saveexec_b64 s[38:39], s[44:45]\n\t" \
+    "v_lshl_add_u32 v20, %[sp], %[shift], %[col]\n\t" \
+    "v_cmp_gt_i32_e64 s[44:45], %[depth], %[sp]\n\t"    /* the push fits (else it lands in the spare row and the lane stops, see StackT) */ \
+    "v_cndmask_b32_e64 v18, v13, v12, s[42:43]\n\t"     /* the nearer child is next */ \
+    "ds_write_b32 v20, %[tos]\n\t"                     /* the stack's top lives in a register: the one below it goes to LDS ... */ \
+    "v_add_u32_e32 %[sp], 1, %[sp]\n\t" \
+    "v_cndmask_b32_e64 %[tos], v12, v13, s[42:43]\n\t"  /* ... and the farther child becomes the top */ \
+    "v_cndmask_b32_e64 v18, -2, v18, s[44:45]\n\t" \
+    "s_or_b64 exec, exec, s[38:39]\n\t" \
+    "v_cndmask_b32_e32 %[cur], -1, v18, vcc\n\t"        /* nothing passes: this lane pops */
+
+#define RT_ASM_LOOP_TEXT(COUNT_TEXT, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+    "s_mov_b64 s[46:47], exec\n\t" \
+    ".Lrt_top%=:\n\t" \
+    COUNT_TEXT \
+    "v_readfirstlane_b32 s30, %[cur]\n\t" \
+    "v_cmp_lt_i32_e64 s[64:65], -1, %[cur]\n\t"         /* lanes at an interior node */ \
+    "v_cmp_gt_i32_e64 s[34:35], 0, %[cur]\n\t"          /* lanes at a triangle */ \
+    "v_cmp_ne_u32_e32 vcc, s30, %[cur]\n\t" \
+    "s_cbranch_vccnz .Lrt_vector%=\n\t" \
+    /* ---- every lane holds the same entry: the record comes through the scalar cache */ \
+    "s_lshl_b32 s31, s30, 6\n\t" \
+    "s_load_dwordx16 s[48:63], %[rec], s31\n\t" \
+    "s_cmp_lt_i32 s30, 0\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "s_cbranch_scc1 .Lrt_one_leaf%=\n\t" \
+    "v_sub_f32_e32 v0, s48, %[rox]\n\t"  "v_sub_f32_e32 v1, s49, %[roy]\n\t"  "v_sub_f32_e32 v2, s50, %[roz]\n\t" \
+    "v_sub_f32_e32 v3, s51, %[rox]\n\t"  "v_sub_f32_e32 v4, s52, %[roy]\n\t"  "v_sub_f32_e32 v5, s53, %[roz]\n\t" \
+    "v_sub_f32_e32 v6, s54, %[rox]\n\t"  "v_sub_f32_e32 v7, s55, %[roy]\n\t"  "v_sub_f32_e32 v8, s56, %[roz]\n\t" \
+    "v_sub_f32_e32 v9, s57, %[rox]\n\t"  "v_sub_f32_e32 v10, s58, %[roy]\n\t" "v_sub_f32_e32 v11, s59, %[roz]\n\t" \
+    "v_mov_b32_e32 v12, s60\n\t" \
+    "v_mov_b32_e32 v13, s61\n\t" \
+    RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+    "s_branch .Lrt_pop%=\n\t" \
+    ".Lrt_one_leaf%=:\n\t" \
+    "v_mov_b32_e32 v0, s48\n\t"  "v_mov_b32_e32 v1, s49\n\t"  "v_mov_b32_e32 v2, s50\n\t"  "v_mov_b32_e32 v3, s51\n\t" \
+    "v_mov_b32_e32 v4, s52\n\t"  "v_mov_b32_e32 v5, s53\n\t"  "v_mov_b32_e32 v6, s54\n\t"  "v_mov_b32_e32 v7, s55\n\t" \
+    "v_mov_b32_e32 v8, s56\n\t"  "v_mov_b32_e32 v9, s57\n\t"  "v_mov_b32_e32 v10, s58\n\t" "v_mov_b32_e32 v11, s59\n\t" \
+    "v_mov_b32_e32 v12, s60\n\t" "v_mov_b32_e32 v13, s61\n\t" "v_mov_b32_e32 v14, s62\n\t" "v_mov_b32_e32 v15, s63\n\t" \
+    "s_mov_b64 s[36:37], exec\n\t" \
+    "s_branch .Lrt_leaf%=\n\t" \
+    /* ---- lanes hold different entries: one 64-byte record per lane, node or triangle, from one array */ \
+    ".Lrt_vector%=:\n\t" \
+    "v_lshlrev_b32_e32 v16, 6, %[cur]\n\t" \
+    "global_load_dwordx4 v[0:3], v16, %[rec]\n\t" \
+    "global_load_dwordx4 v[4:7], v16, %[rec] offset:16\n\t" \
+    "global_load_dwordx4 v[8:11], v16, %[rec] offset:32\n\t" \
+    "global_load_dwordx4 v[12:15], v16, %[rec] offset:48\n\t" \
+    "s_and_saveexec_b64 s[36:37], s[64:65]\n\t" \
+    "s_cbranch_execz .Lrt_leaf_lanes%=\n\t" \
+    "s_waitcnt vmcnt(3)\n\t" \
+    "v_sub_f32_e32 v0, v0, %[rox]\n\t"  "v_sub_f32_e32 v1, v1, %[roy]\n\t"  "v_sub_f32_e32 v2, v2, %[roz]\n\t" \
+    "v_sub_f32_e32 v3, v3, %[rox]\n\t" \
+    "s_waitcnt vmcnt(2)\n\t" \
+    "v_sub_f32_e32 v4, v4, %[roy]\n\t"  "v_sub_f32_e32 v5, v5, %[roz]\n\t" \
+    "v_sub_f32_e32 v6, v6, %[rox]\n\t"  "v_sub_f32_e32 v7, v7, %[roy]\n\t" \
+    "s_waitcnt vmcnt(1)\n\t" \
+    "v_sub_f32_e32 v8, v8, %[roz]\n\t" \
+    "v_sub_f32_e32 v9, v9, %[rox]\n\t"  "v_sub_f32_e32 v10, v10, %[roy]\n\t" "v_sub_f32_e32 v11, v11, %[roz]\n\t" \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+    RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+    ".Lrt_leaf_lanes%=:\n\t" \
+    "s_or_b64 exec, exec, s[36:37]\n\t" \
+    "s_and_saveexec_b64 s[36:37], s[34:35]\n\t" \
+    "s_cbranch_execz .Lrt_leaf_done%=\n\t" \
+    /* ---- one triangle of a leaf (exec = the lanes at one; s[36:37] = the mask to return to) */ \
+    ".Lrt_leaf%=:\n\t" \
+    "v_bfe_u32 v16, %[cur], 26, 5\n\t"                  /* the count coded in the entry */ \
+    "v_cmp_gt_i32_e32 vcc, 0, %[rem]\n\t"               /* first triangle of this leaf */ \
+    "v_cmp_eq_u32_e64 s[38:39], 31, v16\n\t" \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "v_cndmask_b32_e32 %[rem], %[rem], v16, vcc\n\t" \
+    "s_and_b64 s[38:39], s[38:39], vcc\n\t"             /* a leaf of more than 30 triangles: its count is in leaf_count */ \
+    "s_cbranch_scc0 .Lrt_short%=\n\t" \
+    "s_and_saveexec_b64 s[40:41], s[38:39]\n\t" \
+    "v_and_b32_e32 v17, 0x3ffffff, %[cur]\n\t" \
+    "v_lshlrev_b32_e32 v17, 2, v17\n\t" \
+    "global_load_dword %[rem], v17, %[lc]\n\t" \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "s_or_b64 exec, exec, s[40:41]\n\t" \
+    ".Lrt_short%=:\n\t" \
+    /* TrianglePrimitive::ray_intersect: denom = rd . n, tt = ((v0 - ro) . n) / denom */ \
+    "v_mul_f32_e32 v16, %[rdx], v3\n\t" \
+    "v_mul_f32_e32 v17, %[rdy], v4\n\t" \
+    "v_add_f32_e32 v16, v16, v17\n\t" \
+    "v_mul_f32_e32 v17, %[rdz], v5\n\t" \
+    "v_add_f32_e32 v16, v16, v17\n\t"                   /* denom */ \
+    "v_sub_f32_e32 v17, v0, %[rox]\n\t" \
+    "v_sub_f32_e32 v18, v1, %[roy]\n\t" \
+    "v_sub_f32_e32 v19, v2, %[roz]\n\t" \
+    "v_mul_f32_e32 v17, v17, v3\n\t" \
+    "v_mul_f32_e32 v18, v18, v4\n\t" \
+    "v_add_f32_e32 v17, v17, v18\n\t" \
+    "v_mul_f32_e32 v18, v19, v5\n\t" \
+    "v_add_f32_e32 v17, v17, v18\n\t"                   /* numerator */ \
+    "v_div_scale_f32 v18, s[38:39], v16, v16, v17\n\t" \
+    "v_rcp_f32_e32 v19, v18\n\t" \
+    "v_cmp_nlt_f32_e64 s[40:41], |v16|, %[eps]\n\t"     /* !(|denom| < 1e-6) */ \
+    "v_cmp_gt_f32_e64 s[42:43], 0, v16\n\t"             /* denom < 0: the only candidates that can be accepted */ \
+    "v_fma_f32 v20, -v18, v19, 1.0\n\t" \
+    "v_fmac_f32_e32 v19, v20, v19\n\t" \
+    "v_div_scale_f32 v20, vcc, v17, v16, v17\n\t" \
+    "v_mul_f32_e32 v21, v20, v19\n\t" \
+    "v_fma_f32 v22, -v18, v21, v20\n\t" \
+    "v_fmac_f32_e32 v21, v22, v19\n\t" \
+    "v_fma_f32 v18, -v18, v21, v20\n\t" \
+    "v_div_fmas_f32 v18, v18, v19, v21\n\t" \
+    "v_div_fixup_f32 v17, v18, v16, v17\n\t"            /* tt */ \
+    "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t" \
+    "v_mul_f32_e32 v18, %[rdx], v17\n\t" \
+    "v_mul_f32_e32 v19, %[rdy], v17\n\t" \
+    "v_mul_f32_e32 v20, %[rdz], v17\n\t" \
+    "v_cmp_nlt_f32_e64 s[42:43], v17, 0\n\t"            /* !(tt < 0) */ \
+    "v_add_f32_e32 v18, %[rox], v18\n\t"                /* the point on the plane */ \
+    "v_add_f32_e32 v19, %[roy], v19\n\t" \
+    "v_add_f32_e32 v20, %[roz], v20\n\t" \
+    "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t" \
+    "v_cmp_neq_f32_e32 vcc, 0x7f7fffff, v18\n\t"        /* raycast.cu:91 */ \
+    /* TrianglePrimitive::point_inside */ \
+    "v_sub_f32_e32 v21, v18, v0\n\t" \
+    "v_sub_f32_e32 v22, v19, v1\n\t" \
+    "v_sub_f32_e32 v23, v20, v2\n\t" \
+    "s_and_b64 s[40:41], s[40:41], vcc\n\t" \
+    "v_mul_f32_e32 v24, v6, v21\n\t" \
+    "v_mul_f32_e32 v25, v7, v22\n\t" \
+    "v_add_f32_e32 v24, v24, v25\n\t" \
+    "v_mul_f32_e32 v25, v8, v23\n\t" \
+    "v_add_f32_e32 v24, v24, v25\n\t"                   /* dot02 */ \
+    "v_mul_f32_e32 v25, v9, v21\n\t" \
+    "v_mul_f32_e32 v26, v10, v22\n\t" \
+    "v_add_f32_e32 v25, v25, v26\n\t" \
+    "v_mul_f32_e32 v26, v11, v23\n\t" \
+    "v_add_f32_e32 v25, v25, v26\n\t"                   /* dot12 */ \
+    "v_mul_f32_e32 v26, v14, v24\n\t" \
+    "v_mul_f32_e32 v27, v13, v25\n\t" \
+    "v_sub_f32_e32 v26, v26, v27\n\t" \
+    "v_mul_f32_e32 v26, v26, v15\n\t"                   /* u */ \
+    "v_mul_f32_e32 v27, v12, v25\n\t" \
+    "v_mul_f32_e32 v21, v13, v24\n\t" \
+    "v_sub_f32_e32 v27, v27, v21\n\t" \
+    "v_mul_f32_e32 v27, v27, v15\n\t"                   /* v */ \
+    "v_cmp_le_f32_e32 vcc, 0, v26\n\t" \
+    "v_cmp_le_f32_e64 s[42:43], 0, v27\n\t" \
+    "v_add_f32_e32 v21, v26, v27\n\t" \
+    "s_and_b64 s[40:41], s[40:41], vcc\n\t" \
+    "v_cmp_ge_f32_e32 vcc, 1.0, v21\n\t" \
+    "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t" \
+    "s_and_b64 s[40:41], s[40:41], vcc\n\t"             /* a candidate inside its triangle */ \
+    "s_and_saveexec_b64 s[44:45], s[40:41]\n\t" \
+    "s_cbranch_execz .Lrt_no_candidate%=\n\t" \
+    /* its distance from the ray's world origin (mesh -> world is the identity here), raycast.cu:98-104 */ \
+    "v_subrev_f32_e32 v21, %[orgx], v18\n\t" \
+    "v_subrev_f32_e32 v22, %[orgy], v19\n\t" \
+    "v_subrev_f32_e32 v23, %[orgz], v20\n\t" \
+    "v_mul_f32_e32 v21, v21, v21\n\t" \
+    "v_mul_f32_e32 v22, v22, v22\n\t" \
+    "v_add_f32_e32 v21, v21, v22\n\t" \
+    "v_mul_f32_e32 v22, v23, v23\n\t" \
+    "v_add_f32_e32 v21, v21, v22\n\t" \
+    "s_mov_b32 s31, 0xf800000\n\t"                      /* sqrtf, as the compiler expands it */ \
+    "s_movk_i32 s30, 0x260\n\t" \
+    "v_mul_f32_e32 v22, 0x4f800000, v21\n\t" \
+    "v_cmp_gt_f32_e32 vcc, s31, v21\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_e32 v21, v21, v22, vcc\n\t" \
+    "v_sqrt_f32_e32 v22, v21\n\t" \
+    "s_nop 0\n\t" \
+    "v_add_u32_e32 v23, -1, v22\n\t" \
+    "v_fma_f32 v24, -v23, v22, v21\n\t" \
+    "v_cmp_ge_f32_e64 s[38:39], 0, v24\n\t" \
+    "v_add_u32_e32 v24, 1, v22\n\t" \
+    "s_nop 0\n\t" \
+    "v_cndmask_b32_e64 v23, v22, v23, s[38:39]\n\t" \
+    "v_fma_f32 v22, -v24, v22, v21\n\t" \
+    "v_cmp_lt_f32_e64 s[38:39], 0, v22\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_e64 v22, v23, v24, s[38:39]\n\t" \
+    "v_mul_f32_e32 v23, 0x37800000, v22\n\t" \
+    "v_cndmask_b32_e32 v22, v22, v23, vcc\n\t" \
+    "v_cmp_class_f32_e64 vcc, v21, s30\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_e32 v21, v22, v21, vcc\n\t"          /* distance */ \
+    /* raycast.cu:107-109: accepted when nothing was hit yet or this is closer (denom < 0 is part of the candidate mask) */ \
+    "v_cmp_eq_f32_e32 vcc, 0x7f7fffff, %[hmin]\n\t" \
+    "v_cmp_lt_f32_e64 s[38:39], v21, %[hmin]\n\t" \
+    "v_cmp_lt_i32_e64 s[42:43], 0, %[rem]\n\t"          /* (an empty leaf holds no triangle) */ \
+    "s_or_b64 vcc, vcc, s[38:39]\n\t" \
+    "s_and_b64 vcc, vcc, s[42:43]\n\t" \
+    "s_and_b64 exec, exec, vcc\n\t" \
+    "v_mov_b32_e32 %[hmin], v21\n\t" \
+    "v_and_b32_e32 %[hslot], 0x3ffffff, %[cur]\n\t" \
+    "v_mov_b32_e32 %[hinst], %[inst]\n\t" \
+    "v_mov_b32_e32 %[hu], v26\n\t" \
+    "v_mov_b32_e32 %[hv], v27\n\t" \
+    ".Lrt_no_candidate%=:\n\t" \
+    "s_or_b64 exec, exec, s[44:45]\n\t" \
+    /* next triangle of the leaf, or a pop */ \
+    "v_add_u32_e32 %[rem], -1, %[rem]\n\t" \
+    "v_add_u32_e32 v16, 1, %[cur]\n\t" \
+    "v_cmp_lt_i32_e32 vcc, 0, %[rem]\n\t" \
+    "s_nop 1\n\t" \
+    "v_cndmask_b32_e32 %[cur], -1, v16, vcc\n\t" \
+    "v_cndmask_b32_e32 %[rem], -1, %[rem], vcc\n\t" \
+    ".Lrt_leaf_done%=:\n\t" \
+    "s_or_b64 exec, exec, s[36:37]\n\t" \
+    /* ---- raycast.cu:60-61: lanes with nothing to go on with pop (the sentinel when nothing is left) */ \
+    ".Lrt_pop%=:\n\t" \
+    "v_cmp_eq_u32_e32 vcc, -1, %[cur]\n\t" \
+    "s_and_saveexec_b64 s[36:37], vcc\n\t" \
+    "s_cbranch_execz .Lrt_latch%=\n\t" \
+    "v_add_u32_e32 %[sp], -1, %[sp]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"                         /* (the top's reload of an earlier pop: long done) */ \
+    "v_lshl_add_u32 v16, %[sp], %[shift], %[col]\n\t" \
+    "v_mov_b32_e32 %[cur], %[tos]\n\t"                 /* the popped entry is in a register: the lane goes on at once ... */ \
+    "ds_read_b32 %[tos], v16\n\t"                      /* ... and the new top arrives while it works on it */ \
+    ".Lrt_latch%=:\n\t" \
+    "s_or_b64 exec, exec, s[36:37]\n\t" \
+    "v_cmp_ne_u32_e32 vcc, -2, %[cur]\n\t" \
+    "s_and_b64 exec, exec, vcc\n\t"                     /* lanes that popped the sentinel are done */ \
+    "s_cbranch_execnz .Lrt_top%=\n\t" \
+    ".Lrt_exit%=:\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"                         /* (the last pop's reload of the top) */ \
+    "s_mov_b64 exec, s[46:47]\n\t"
+
+struct AsmLoopState { int32_t cur, sp, rem; };
+
+template <int OCT, bool COUNT, int ROW_SHIFT>        // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
+__device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_index, const MeshRay& r, V3 org, lds_int* column, int lds_depth,
+                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters)
+{
+    int32_t rem = -1;
+    int32_t tos = kSentinel;                                    // the stack's top entry (row 0 of the LDS column holds a second sentinel, so
+                                                                // that the last pop's reload reads a row that exists and leaves sp == 0)
+    const float eps = __int_as_float(0x358637be);
+    // near / far plane registers per axis: bit k of OCT set = direction component k negative = the box's max plane is the near one
+#define RT_ASM_PICK(bit, lo, hi) ((OCT & bit) ? hi : lo)
+#define RT_ASM_GO(COUNT_TEXT, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+    asm volatile(RT_ASM_LOOP_TEXT(COUNT_TEXT, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+                 : [cur] "+v"(cur), [sp] "+v"(sp), [rem] "+v"(rem), [tos] "+v"(tos), [hmin] "+v"(hit.min), [hslot] "+v"(hit.slot), [hinst] "+v"(hit.instance), \
+                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters) \
+                 : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
+                   [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), [col] "v"(column), \
+                   [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
+                   [depth] "s"(lds_depth), [inst] "s"(inst_index), [eps] "s"(eps), [shift] "n"(ROW_SHIFT) \
+                 : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
+                   "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+                   "s30", "s31", "s64", "s65", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", \
+                   "vcc", "scc", "memory")
+#define RT_ASM_OCT(COUNT_TEXT, X0, X1, Y0, Y1, Z0, Z1, BX0, BX1, BY0, BY1, BZ0, BZ1) \
+    RT_ASM_GO(COUNT_TEXT, X0, X1, Y0, Y1, Z0, Z1, BX0, BX1, BY0, BY1, BZ0, BZ1)
+// (experiments: -DRT_ASM_PAD_KIND=1|2|3 adds eight scalar / vector / no-op instructions to every iteration, to price an instruction of each kind)
+#define RT_ASM_X8(t) t t t t t t t t
+#if RT_ASM_PAD_KIND == 1
+#define RT_ASM_PAD RT_ASM_X8("s_mov_b32 s31, s30\n\t")
+#elif RT_ASM_PAD_KIND == 2
+#define RT_ASM_PAD RT_ASM_X8("v_mov_b32 v27, v26\n\t")
+#elif RT_ASM_PAD_KIND == 3
+#define RT_ASM_PAD RT_ASM_X8("s_nop 0\n\t")
+#else
+#define RT_ASM_PAD ""
+#endif
+#if RT_ASM_GUARD    // (bring-up only: a loop that does not end leaves after a million iterations instead of hanging the GPU)
+#define RT_ASM_COUNT "s_add_u32 %[iters], %[iters], 1\n\ts_cmp_gt_u32 %[iters], 0x100000\n\ts_cbranch_scc1 .Lrt_exit%=\n\t"
+#define RT_ASM_NOCOUNT RT_ASM_COUNT
+#else
+#define RT_ASM_COUNT "s_add_u32 %[iters], %[iters], 1\n\t" RT_ASM_PAD
+#define RT_ASM_NOCOUNT RT_ASM_PAD
+#endif
+    // x: v0 / v3 (box a), v6 / v9 (box b); y: v1 / v4, v7 / v10; z: v2 / v5, v8 / v11 -- (min, max) planes
+#define RT_ASM_CASE(N, XA, XB, YA, YB, ZA, ZB, XC, XD, YC, YD, ZC, ZD) \
+    if constexpr (OCT == N) { if constexpr (COUNT) RT_ASM_OCT(RT_ASM_COUNT, XA, XB, YA, YB, ZA, ZB, XC, XD, YC, YD, ZC, ZD); \
+                              else RT_ASM_OCT(RT_ASM_NOCOUNT, XA, XB, YA, YB, ZA, ZB, XC, XD, YC, YD, ZC, ZD); }
+    RT_ASM_CASE(0, "v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11")
+    RT_ASM_CASE(1, "v3", "v0", "v1", "v4", "v2", "v5", "v9", "v6", "v7", "v10", "v8", "v11")
+    RT_ASM_CASE(2, "v0", "v3", "v4", "v1", "v2", "v5", "v6", "v9", "v10", "v7", "v8", "v11")
+    RT_ASM_CASE(3, "v3", "v0", "v4", "v1", "v2", "v5", "v9", "v6", "v10", "v7", "v8", "v11")
+    RT_ASM_CASE(4, "v0", "v3", "v1", "v4", "v5", "v2", "v6", "v9", "v7", "v10", "v11", "v8")
+    RT_ASM_CASE(5, "v3", "v0", "v1", "v4", "v5", "v2", "v9", "v6", "v7", "v10", "v11", "v8")
+    RT_ASM_CASE(6, "v0", "v3", "v4", "v1", "v5", "v2", "v6", "v9", "v10", "v7", "v11", "v8")
+    RT_ASM_CASE(7, "v3", "v0", "v4", "v1", "v5", "v2", "v9", "v6", "v10", "v7", "v11", "v8")
+#undef RT_ASM_CASE
+#undef RT_ASM_COUNT
+#undef RT_ASM_NOCOUNT
+#undef RT_ASM_OCT
+#undef RT_ASM_GO
+#undef RT_ASM_PICK
 }
 
 // Octant-specialised loops (RT_OCTANTS=0 at compile time keeps only the generic one).  The rays of a wave -- an 8x8-pixel
@@ -525,12 +923,15 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 // cast in registers they do not have (spilled to scratch); nine loops per cast site made that worse (c3 24.9 ms against
 // 23.7 ms with the generic loop alone, profiles/r04_experiments/octants_in_extension_kernels.log), while the samples-only
 // kernel, which carries nothing, gains like the primary kernel (c4 at 16 spp: 8.27 against 8.50 ms).
-template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true, bool ANYHIT = false>
+// VIEW: `view_off` = byte offset of the frame's view records from p.records (see trace_loop).
+template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true, bool ANYHIT = false,
+          bool VIEW = false>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
-                                               int* pops = nullptr)
+                                               int* pops = nullptr, uint32_t view_off = 0)
 {
     const MeshRay r = to_mesh_space(in, org, dir);
+    const uint32_t vdelta = VIEW ? view_off + (uint32_t)p.view_inst_off[inst_index] : 0u;
     int oct = -1;
     if constexpr (RT_OCTANTS && !PROF && OCTANTS) {
         const float inf = __int_as_float(0x7f800000);
@@ -541,7 +942,32 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         const int first = __builtin_amdgcn_readfirstlane(mine);
         if ((p.mesh_flags[in.mesh_index] & 1) == 0 && __ballot(!usable || mine != first) == 0ull) oct = first;
     }
-#define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O, ANYHIT>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops)
+    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && !EX && !POPS && !ANYHIT && !VIEW && !STK::kSpill) {
+        // the hand-written loop (trace_loop_asm) for what it covers; everything else takes the C++ loops below
+        if (oct >= 0 && in.exact_uv == 0 && in.identity_inv != 0) {
+            stack.sp = 0;
+            stack.push(kSentinel);
+            int32_t cur = in.root_ref, sp = stack.sp;
+            int wave_iters = 0;
+            static_assert(STK::kStride == 64 || STK::kStride == 256, "the stack column's row pitch as a shift");
+#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10)>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters)
+            switch (oct) {
+            case 0: RT_TRACE_ASM(0); break;
+            case 1: RT_TRACE_ASM(1); break;
+            case 2: RT_TRACE_ASM(2); break;
+            case 3: RT_TRACE_ASM(3); break;
+            case 4: RT_TRACE_ASM(4); break;
+            case 5: RT_TRACE_ASM(5); break;
+            case 6: RT_TRACE_ASM(6); break;
+            default: RT_TRACE_ASM(7); break;
+            }
+#undef RT_TRACE_ASM
+            stack.sp = sp;
+            if constexpr (COUNT) *iters += wave_iters;          // (the wave's iterations = those of its longest lane, which is what the tile cost is)
+            return;
+        }
+    }
+#define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O, ANYHIT, VIEW>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops, vdelta)
     switch (oct) {                                              // (wave-uniform: a scalar branch)
     case 0: RT_TRACE_LOOP(0); break;
     case 1: RT_TRACE_LOOP(1); break;
@@ -619,9 +1045,9 @@ template <bool DEBUG, bool PROF, bool SPILL>
 __host__ __device__ inline int lds_block_rows(int stack_depth) { return lds_rows(stack_depth) + (optimistic_stack<DEBUG, PROF, SPILL>() ? 1 : 0); }
 
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
-template <bool DEBUG, bool PROF, bool COUNT = false, bool SPILL = true>
+template <bool DEBUG, bool PROF, bool COUNT = false, bool SPILL = true, bool VIEW = false>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x0, int y0, lds_int* lds_base, lds_int*& lds_column,
-                                             int* iters = nullptr)
+                                             int* iters = nullptr, uint32_t view_off = 0)
 {
     int x, ly, y;
     pixel_of(p, f, (int)(lds_column - lds_base), x0, y0, x, ly, y);
@@ -635,27 +1061,29 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
         // A tree deeper than the LDS part of the stack, a ray that (almost always) is not: the LDS-only loops, and the general
         // stack only for the lanes that turn out to need it -- from the start of the ray, so the hit is the one the general kernel
         // finds (the instrumented kernel keeps the general stack throughout: its counts are per ray, not per attempt).
-        StackT<kBlock, false, true> stack;
+        StackT<kPrimBlock, false, true> stack;
         stack.lds = lds_column; stack.spill = nullptr; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
         int outgrown = 0;                                       // a loop left through the spare row ends with sp != 0
         for (int i = 0; i < p.num_instances; i++) {             // raycast.cu:26
-            trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, false, true>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
+            trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, false, true>, false, true, false, VIEW>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters,
+                                                                                                            nullptr, view_off);
             outgrown |= stack.sp;
         }
         if (outgrown != 0) {
             int spill[kMaxStack - kLdsStack];
-            StackT<kBlock, true> deep;
+            StackT<kPrimBlock, true> deep;
             deep.lds = lds_column; deep.spill = spill; deep.lds_depth = lds_rows(p.stack_depth); deep.sp = 0;
             hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
             for (int i = 0; i < p.num_instances; i++)
-                trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, true>, false, false>(p, p.instances[i], i, org, dir, deep, hit, cnt, iters);
+                trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, true>, false, false>(p, p.instances[i], i, org, dir, deep, hit, cnt, iters);
         }
     } else {
         int spill[SPILL ? kMaxStack - kLdsStack : 1];
-        StackT<kBlock, SPILL> stack;
+        StackT<kPrimBlock, SPILL> stack;
         stack.lds = lds_column; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
         for (int i = 0; i < p.num_instances; i++)               // raycast.cu:26
-            trace_instance<DEBUG, PROF, false, COUNT, StackT<kBlock, SPILL>>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters);
+            trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, SPILL>, false, true, false, VIEW>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters,
+                                                                                                  nullptr, view_off);
     }
 
     // The pixel's coordinates are not kept across the traversal (three registers in a kernel that has none to spare: they
@@ -690,10 +1118,10 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
 // otherwise idle chip; started first, those waves run beside the bulk of the frame instead of after it
 // (measured: -22 % / -12 % / 0 % frame time for the far / mid / near camera).  Which tile a workgroup renders does not
 // change what a pixel computes.
-template <bool DEBUG, bool PROF, bool ORDERED = false, bool SPILL = true>
-__global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
+template <bool DEBUG, bool PROF, bool ORDERED = false, bool SPILL = true, bool VIEW = false>
+__global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParams p)
 {
-    extern __shared__ int lds_stack[];                          // [lds_block_rows(stack_depth)][kBlock] (+ 2 ints when ORDERED)
+    extern __shared__ int lds_stack[];                          // [lds_block_rows(stack_depth)][kPrimBlock] (+ 2 ints when ORDERED)
 
     // Workgroup b renders tile b (row-major).  Consecutive workgroups are dealt round-robin to the 8 XCDs, so every
     // XCD sees tiles from the whole frame: measured faster than giving each XCD one contiguous band (better load
@@ -707,7 +1135,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
         frame = tile % p.num_frames;
         tile = tile / p.num_frames;
         if (p.tile_order) tile = p.tile_order[tile];
-        group = (lds_int*)lds_stack + lds_block_rows<DEBUG, PROF, SPILL>(p.stack_depth) * kBlock;
+        group = (lds_int*)lds_stack + lds_block_rows<DEBUG, PROF, SPILL>(p.stack_depth) * kPrimBlock;
         if (threadIdx.x == 0) { group[0] = 0; group[1] = 0; }
         __syncthreads();                                        // (at the very start: the four waves arrive together)
     }
@@ -719,9 +1147,10 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
     lds_int* column = (lds_int*)lds_stack + threadIdx.x;
     {
         int x, ly, y;
-        pixel_of(p, p.frames[frame], (int)threadIdx.x, tx * kTile, ty * kTile, x, ly, y);
+        pixel_of(p, p.frames[frame], (int)threadIdx.x, tx * kPrimTile, ty * kPrimTile, x, ly, y);
         if (x < p.width && ly < p.frames[frame].local_rows)
-            render_pixel<DEBUG, PROF, ORDERED, SPILL>(p, p.frames[frame], tx * kTile, ty * kTile, (lds_int*)lds_stack, column, &iters);
+            render_pixel<DEBUG, PROF, ORDERED, SPILL, VIEW>(p, p.frames[frame], tx * kPrimTile, ty * kPrimTile, (lds_int*)lds_stack, column, &iters,
+                                                            VIEW ? p.view_base + (uint32_t)frame * p.view_frame_stride : 0u);
     }
     asm volatile("" : "+v"(column));
     const int tid = (int)(column - (lds_int*)lds_stack), wave = tid >> 6, lane = tid & 63;
@@ -732,12 +1161,12 @@ __global__ __launch_bounds__(kBlock, 8) void render_kernel(const RenderParams p)
         if (p.tile_cost && lane == 0) {
             __hip_atomic_fetch_max((int*)&group[1], iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int before = __hip_atomic_fetch_add((int*)&group[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (before == kBlock / 64 - 1)                      // this wave is the last of its workgroup
+            if (before == kPrimBlock / 64 - 1)                  // this wave is the last of its workgroup
                 p.tile_cost[tile] = __hip_atomic_load((int*)&group[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     if (p.trace && lane == 0) {                                 // diagnostic: per-wave lifetime (RT_TRACE_FILE)
-        unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave) * 16;
+        unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kPrimBlock / 64) + wave) * 16;
         t[0] = t_start; t[1] = wall_clock64();
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1447,6 +1876,36 @@ __global__ __launch_bounds__(kRefitRunThreads) void refit_run_kernel(float4* rec
 // like any launch and needs no host buffer that outlives the call
 __global__ void set_instance_kernel(DevInstance* dst, const DevInstance value) { *dst = value; }
 
+// View records of the frames of one launch (RtScene::ViewPool, trace_loop<.., VIEW>): for every frame (blockIdx.y) and every
+// instance, the instance's interior records with `box - origin` in place of the twelve box words -- origin = the frame's camera
+// position in the instance's mesh space, computed by the function the traversal uses (to_mesh_space), the subtraction being
+// the one box_differences does per visit: the same fp32 operation on the same operands, done once.  One thread per 16 bytes.
+struct ViewJob {
+    int32_t n;                                  // instances
+    int32_t first[kMaxViewInstances];           // first record of the instance's part of a frame's view
+    int32_t node_base[kMaxViewInstances];       // first interior record of the instance's mesh
+    int32_t count[kMaxViewInstances];           // interior-record capacity of that mesh
+    int32_t total;                              // records to write per frame (sum of count)
+};
+
+__global__ __launch_bounds__(256) void view_records_kernel(const RenderParams p, const ViewJob job)
+{
+    const int t = (int)(blockIdx.x * 256 + threadIdx.x), frame = (int)blockIdx.y;
+    int rec = t >> 2;
+    const int quarter = t & 3;
+    if (rec >= job.total) return;
+    int i = 0;
+    while (i + 1 < job.n && rec >= job.count[i]) { rec -= job.count[i]; i++; }
+    const FrameParams& f = p.frames[frame];
+    const V3 o = to_mesh_space(p.instances[i], v3(f.origin[0], f.origin[1], f.origin[2]), v3(0.0f, 0.0f, 1.0f)).ro;
+    float4 v = p.records[(size_t)(job.node_base[i] + rec) * 4 + quarter];
+    if (quarter == 0) v = make_float4(v.x - o.x, v.y - o.y, v.z - o.z, v.w - o.x);          // the operand order of box_differences
+    else if (quarter == 1) v = make_float4(v.x - o.y, v.y - o.z, v.z - o.x, v.w - o.y);
+    else if (quarter == 2) v = make_float4(v.x - o.z, v.y - o.x, v.z - o.y, v.w - o.z);
+    char* view = (char*)p.records + p.view_base + (size_t)frame * p.view_frame_stride;
+    ((float4*)view)[(size_t)(job.first[i] + rec) * 4 + quarter] = v;
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -1574,7 +2033,94 @@ bool lds_stack_suffices(const RenderParams& p)
     return !forced && p.stack_depth - 1 <= kLdsStack;
 }
 
-int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchronize)
+// ---- view records (RtScene::ViewPool; view_records_kernel; render_kernel<.., VIEW>) -------------------------------------------
+// RT_VIEW_RECORDS=0: never (tests run parity scenes both ways).  RT_VIEW_MIN_RAYS=k: a launch qualifies when a frame brings at
+// least k rays per view record it costs to write (default 8: a record is written once and read by tens of rays; below that --
+// a rank's thin stripes of a frame, a huge tree under a small frame -- the pre-pass would cost more than the subtractions).
+constexpr size_t kViewMaxBytes = (size_t)3 << 30;            // records + pool stay below 4 GiB: offsets are 32 bits
+
+int view_mode()
+{
+    static const int mode = [] { const char* e = getenv("RT_VIEW_RECORDS"); return e && e[0] == '1' ? 1 : 0; }();
+    return mode;
+}
+
+// Decides whether this launch renders through view records; if so: a slot of the pool (grown when needed), the launch's view
+// parameters in `p`, the pre-pass queued on `stream`.  Returns the slot (view_done records its event after the render kernel) or
+// -1: the launch then runs the kernels without views -- same pixels.
+int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream)
+{
+    if (!view_mode() || !s || p.num_instances < 1 || p.num_instances > kMaxViewInstances || p.num_ranks < 1) return -1;
+    RtScene::ViewPool& v = s->view;
+    std::lock_guard<std::mutex> lock(v.m);
+    if (!v.decided) {
+        v.decided = true;
+        int32_t cap = 0;
+        for (const auto& rf : s->mesh_refit) cap = std::max(cap, rf.int_cap);
+        // (an instance may be given another mesh later, rt_scene_update_instance: every instance gets room for the largest)
+        v.frame_records = cap * (int32_t)s->instances.size();
+        v.inst_first.resize(s->instances.size());
+        for (size_t i = 0; i < s->instances.size(); i++) v.inst_first[i] = (int32_t)i * cap;
+        v.usable = cap > 0 && s->records_bytes > 0 && s->records_bytes + (size_t)v.frame_records * 64 * 3 <= kViewMaxBytes;
+    }
+    if (!v.usable || (size_t)p.num_instances != s->instances.size()) return -1;
+    ViewJob job;
+    job.n = p.num_instances; job.total = 0;
+    for (int i = 0; i < job.n; i++) {
+        const RtScene::MeshRefit& rf = s->mesh_refit[(size_t)s->instances[(size_t)i].mesh_index];
+        job.first[i] = v.inst_first[(size_t)i]; job.node_base[i] = rf.node_base; job.count[i] = rf.int_cap;
+        job.total += rf.int_cap;
+    }
+    static const long min_rays = [] { const char* e = getenv("RT_VIEW_MIN_RAYS"); long k = e ? atol(e) : 8; return k < 0 ? 0 : k; }();
+    if (job.total <= 0 || (long long)job.total * min_rays > (long long)p.width * p.local_rows) return -1;
+    v.launches++;
+    const size_t frame_bytes = (size_t)v.frame_records * 64;
+    if (p.num_frames > v.slot_frames) {
+        // grow: 1, 4 or kMaxBatch frames per slot.  The records move into a new allocation with the pool as its tail: every
+        // launch in flight reads the old one, so the device is drained first (three times in a scene's life at most).
+        int want = p.num_frames <= 1 ? 1 : p.num_frames <= 4 ? 4 : kMaxBatch;
+        while (want > p.num_frames && s->records_bytes + frame_bytes * 3 * (size_t)want > kViewMaxBytes) want = p.num_frames;
+        if (s->records_bytes + frame_bytes * 3 * (size_t)want > kViewMaxBytes) { v.fallbacks++; return -1; }
+        const size_t base = (s->records_bytes + 255) & ~(size_t)255;
+        float4* block = nullptr;
+        if (hipDeviceSynchronize() != hipSuccess) { v.fallbacks++; return -1; }
+        if (hipMalloc((void**)&block, base + frame_bytes * 3 * (size_t)want) != hipSuccess) {
+            (void)hipGetLastError();
+            v.usable = false; v.fallbacks++;                    // (no memory for it: this scene renders without views from now on)
+            return -1;
+        }
+        if (hipMemcpy(block, s->d_records, s->records_bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(block); v.usable = false; v.fallbacks++; return -1; }
+        v.retired.push_back(s->d_records);
+        s->device_bytes += base + frame_bytes * 3 * (size_t)want;           // (the earlier block stays allocated until the scene goes)
+        s->d_records = block;
+        v.base_bytes = base; v.slot_frames = want; v.grows++;
+        for (auto& sl : v.slot) { sl.used = false; sl.stream = nullptr; }
+    }
+    int use = -1;
+    for (int k = 0; k < 3 && use < 0; k++) if (v.slot[k].used && v.slot[k].stream == stream) use = k;       // stream order protects it
+    for (int k = 0; k < 3 && use < 0; k++) if (!v.slot[k].used) use = k;
+    for (int k = 0; k < 3 && use < 0; k++) if (hipEventQuery(v.slot[k].done) == hipSuccess) use = k;        // its last launch has finished
+    if (use < 0) { (void)hipGetLastError(); v.fallbacks++; return -1; }                                      // (all busy on other streams)
+    if (!v.slot[use].done && hipEventCreateWithFlags(&v.slot[use].done, hipEventDisableTiming) != hipSuccess) { v.fallbacks++; return -1; }
+    v.slot[use].used = true; v.slot[use].stream = stream;
+    p.records = s->d_records;                                   // (fill_params read it before a possible move)
+    p.view_base = (uint32_t)(v.base_bytes + (size_t)use * v.slot_frames * frame_bytes);
+    p.view_frame_stride = (uint32_t)frame_bytes;
+    if (getenv("RT_VIEW_SHARED")) p.view_frame_stride = 0;      // EXPERIMENT ONLY (identical poses in every frame of the batch)
+    for (int i = 0; i < job.n; i++) p.view_inst_off[i] = (int32_t)(((int64_t)job.first[i] - job.node_base[i]) * 64);
+    hipLaunchKernelGGL(view_records_kernel, dim3((unsigned)(((size_t)job.total * 4 + 255) / 256), (unsigned)p.num_frames), dim3(256), 0, stream, p, job);
+    if (hipGetLastError() != hipSuccess) { v.fallbacks++; return -1; }
+    return use;
+}
+
+void view_done(RtScene* s, int slot, hipStream_t stream)
+{
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(s->view.m);
+    (void)hipEventRecord(s->view.slot[slot].done, stream);
+}
+
+int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchronize, bool view)
 {
     RtScene::TileOrderCache& cache = s->order;
     std::lock_guard<std::mutex> lock(cache.m);
@@ -1621,9 +2167,15 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     p.tile_order = (mine && o->cur >= 0) ? o->d_order[o->cur] : nullptr;
     p.tile_cost = mine ? o->d_cost : nullptr;
     const size_t lds = (size_t)(lds_stack_suffices(p) ? lds_block_rows<false, false, false>(p.stack_depth) : lds_block_rows<false, false, true>(p.stack_depth)) *
-                       kBlock * sizeof(int) + 2 * sizeof(int);
-    if (lds_stack_suffices(p)) hipLaunchKernelGGL((render_kernel<false, false, true, false>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
-    else hipLaunchKernelGGL((render_kernel<false, false, true>), dim3((unsigned)ntiles * (unsigned)p.num_frames), dim3(kBlock), lds, stream, p);
+                       kPrimBlock * sizeof(int) + 2 * sizeof(int);
+    const dim3 grid((unsigned)ntiles * (unsigned)p.num_frames);
+    if (lds_stack_suffices(p)) {
+        if (view) hipLaunchKernelGGL((render_kernel<false, false, true, false, true>), grid, dim3(kPrimBlock), lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, false, true, false>), grid, dim3(kPrimBlock), lds, stream, p);
+    } else {
+        if (view) hipLaunchKernelGGL((render_kernel<false, false, true, true, true>), grid, dim3(kPrimBlock), lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, false, true>), grid, dim3(kPrimBlock), lds, stream, p);
+    }
     RT_HIP(hipGetLastError());
     // The next order is sorted from the costs of EARLIER launches: the sort waits for the launches issued before this one (their
     // events; this launch's own is recorded below, after the sort has been queued), so it runs on the side stream WHILE this frame
@@ -1652,11 +2204,11 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
 {
     if (p.width <= 0 || p.local_rows < 0) return RT_E_INVALID;
     if (p.local_rows == 0) return RT_OK;
-    p.tiles_x = (p.width + kTile - 1) / kTile;
-    p.tiles_y = (p.local_rows + kTile - 1) / kTile;
+    p.tiles_x = (p.width + kPrimTile - 1) / kPrimTile;
+    p.tiles_y = (p.local_rows + kPrimTile - 1) / kPrimTile;
     // (one size for whichever kernel is launched below: the spare row of the optimistic stack costs the instrumented kernels nothing)
-    const size_t lds = (size_t)(lds_stack_suffices(p) ? lds_rows(p.stack_depth) : lds_block_rows<false, false, true>(p.stack_depth)) * kBlock * sizeof(int);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kBlock);
+    const size_t lds = (size_t)(lds_stack_suffices(p) ? lds_rows(p.stack_depth) : lds_block_rows<false, false, true>(p.stack_depth)) * kPrimBlock * sizeof(int);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.num_frames), block(kPrimBlock);
     const char* trace_file = getenv("RT_TRACE_FILE");                               // diagnostics only
     // Heavy-first dispatch (RT_TILE_ORDER=0 turns it off): for one frame per launch with enough tiles to have a tail worth
     // hiding.  Batches do not use it: the tail of one frame already overlaps the bulk of the next, and measured with the
@@ -1664,23 +2216,33 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     // (near), a rank's stripes of 32 frames -6 % on one stream but no better than the two alternating streams bench.py uses.
     // (RT_TRACE_ORDERED=1 with RT_TRACE_FILE: the stamps of the heavy-first launch itself, for tools/trace_one.py)
     const bool trace_ordered = trace_file && getenv("RT_TRACE_ORDERED");
-    if (scene && !debug && (!trace_file || trace_ordered) && !p.hit_instance && !p.hit_triangle && grid.x >= 256 && (size_t)grid.x * grid.y <= ((size_t)1 << 30)) {
+    const int view_slot = (scene && !debug && !trace_file) ? view_prepare(scene, p, stream) : -1;
+    struct ViewDone {                                           // (whichever way this function returns after the render kernel was queued)
+        RtScene* s; int slot; hipStream_t stream;
+        ~ViewDone() { view_done(s, slot, stream); }
+    } view_guard{scene, view_slot, stream};
+    if (scene && !debug && (!trace_file || trace_ordered) && !p.hit_instance && !p.hit_triangle && grid.x >= 1024 && (size_t)grid.x * grid.y <= ((size_t)1 << 30)) {
         static const bool enabled = [] { const char* e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
-        if (enabled && p.num_frames == 1 && grid.x >= 2048) {
-            if (!trace_ordered) return launch_ordered(scene, p, stream, synchronize);
-            const size_t n = (size_t)grid.x * (kBlock / 64) * 16;
+        if (enabled && p.num_frames == 1 && grid.x >= 8192) {   // (8x8-pixel tiles: half a million pixels)
+            if (!trace_ordered) return launch_ordered(scene, p, stream, synchronize, view_slot >= 0);
+            const size_t n = (size_t)grid.x * (kPrimBlock / 64) * 16;
             RT_HIP(trace_begin(p, n));
-            const int rc = launch_ordered(scene, p, stream, 1);
+            const int rc = launch_ordered(scene, p, stream, 1, false);
             const hipError_t e = trace_end(p, n, trace_file, stream);
             return rc ? rc : (int)e;
         }
     }
-    const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
+    const size_t trace_n = (size_t)grid.x * grid.y * (kPrimBlock / 64) * 16;
     if (trace_file) RT_HIP(trace_begin(p, trace_n));
     if (trace_file && getenv("RT_TRACE_PROF")) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, stream, p);
     else if (debug) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);
-    else if (lds_stack_suffices(p)) hipLaunchKernelGGL((render_kernel<false, false, false, false>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, stream, p);
+    else if (lds_stack_suffices(p)) {
+        if (view_slot >= 0) hipLaunchKernelGGL((render_kernel<false, false, false, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, false, false, false>), grid, block, lds, stream, p);
+    } else {
+        if (view_slot >= 0) hipLaunchKernelGGL((render_kernel<false, false, false, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, stream, p);
+    }
     RT_HIP(hipGetLastError());
     if (trace_file) RT_HIP(trace_end(p, trace_n, trace_file, stream));
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
@@ -1941,6 +2503,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             return e;
         };
         if ((he = make((void**)&s->d_records, (total + 1) * 4 * sizeof(float4), 0)) != hipSuccess) return fail((int)he);
+        s->records_bytes = (total + 1) * 4 * sizeof(float4);
         if ((he = make((void**)&s->d_tri_uv, total * 6 * sizeof(float), 0)) != hipSuccess) return fail((int)he);
         if ((he = make((void**)&s->d_tri_id, total * sizeof(int32_t), 0xff)) != hipSuccess) return fail((int)he);
         if ((he = make((void**)&s->d_leaf_count, total * sizeof(int32_t), 0)) != hipSuccess) return fail((int)he);
@@ -2129,6 +2692,8 @@ int rt_scene_destroy(RtScene* s)
     for (auto& rf : s->mesh_refit) (void)hipFree(rf.d_sched);
     (void)hipFree(s->d_refit_scratch);
     (void)hipFree(s->d_ex_scratch);
+    for (void* r : s->view.retired) (void)hipFree(r);
+    for (auto& sl : s->view.slot) if (sl.done) (void)hipEventDestroy(sl.done);
     (void)hipFree(s->d_records); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
     (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_mesh_flags); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
     for (uint8_t* t : s->d_textures) (void)hipFree(t);
@@ -2248,7 +2813,7 @@ int rt_render_ids(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t 
     int rc = fill_params(p, s, cam, &d_img, 1, pitch);
     if (rc) return rc;
     p.hit_instance = d_hit_instance; p.hit_triangle = d_hit_triangle;
-    return launch(p, false, (hipStream_t)stream, synchronize);
+    return launch(p, false, (hipStream_t)stream, synchronize, s);        // (with the scene: the kernel whose ids are checked is the one that is timed, views included)
 }
 
 int rt_render_debug(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch,

@@ -75,6 +75,26 @@ struct RtScene {
         int next = 0;
         uint64_t launches = 0, waits = 0;                    // (diagnostics: rt_render_overlapped_stats)
     } overlap;
+    // View records (render_kernel<.., VIEW>): primary rays of one frame share their origin, so `box - origin` of an interior
+    // record (twelve subtractions per node visit and lane) depends on the frame and the instance only.  A small kernel writes
+    // them once per frame -- the frame's "view" of the interior records -- and the traversal reads those instead.  The views
+    // live BEHIND the records in the same allocation (d_records is re-allocated with the pool as its tail the first time a
+    // launch qualifies, and when a launch brings more frames than a slot holds), so that a lane's fetch stays one 32-bit
+    // offset from one base whether it reads a triangle or a view record.  A slot = the views of the frames of one launch;
+    // a slot is reused by launches on the stream it was last used on (stream order) or once its event has completed.
+    struct ViewPool {
+        std::mutex m;
+        bool decided = false, usable = false;    // static eligibility of the scene (instances, sizes), decided at the first launch
+        int32_t frame_records = 0;               // interior-record capacity of all instances = records of one frame's view
+        std::vector<int32_t> inst_first;         // per instance: first view record within a frame's view
+        size_t base_bytes = 0;                   // byte offset of the pool from d_records
+        int32_t slot_frames = 0;                 // frames a slot holds (0 = no pool yet)
+        struct Slot { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; } slot[3];
+        std::vector<void*> retired;              // earlier d_records blocks: freed with the scene (a launch prepared on another
+                                                 // thread may still carry the pointer)
+        uint64_t launches = 0, fallbacks = 0, grows = 0;
+    } view;
+    size_t records_bytes = 0;                    // size of the record array proper (the head of the d_records allocation)
     struct TileOrderCache {
         std::mutex m;
         hipStream_t sort_stream = nullptr;
