@@ -1183,16 +1183,36 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
 // LOC: keep the accepted hit's world location (secondary rays start there).  ANYHIT: a shadow ray, cast_ray(..., true, FLT_MAX)
 // of raycast.cu:272 -- it returns at its first accepted hit (:129-133), i.e. a lane that has one (then, and only then, its
 // hit.min is below FLT_MAX) takes no part in the remaining instances.
-template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false>
-__device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, Stack& stack, int& pops)
+// OPTIMISTIC: only the samples-only kernel asks for it -- in the bounce kernel, which carries its path state across the casts in
+// registers it does not have, the second loop costs more in spills than the branches it saves: c3 +8 %
+// (profiles/r05_experiments/ex_one_wave_workgroups.log).
+template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false, class STK = Stack, bool OPTIMISTIC = false>
+__device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, STK& stack, int& pops)
 {
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
     hit.loc = v3(0.0f, 0.0f, 0.0f);
     Counters<false> none;
+    if constexpr (OPTIMISTIC && RT_OPTIMISTIC_STACK && RT_SENTINEL && STK::kSpill) {
+        // the optimistic stack (StackT, render_pixel): the cast on the LDS part alone, and again from its start on the general stack
+        // for the lanes whose stack outgrew it (their pop count starts again too)
+        StackT<STK::kStride, false, true> fast;
+        fast.lds = stack.lds; fast.spill = nullptr; fast.lds_depth = stack.lds_depth; fast.sp = 0;
+        const int pops_before = pops;
+        int outgrown = 0;
+        for (int i = 0; i < p.num_instances; i++) {
+            if constexpr (ANYHIT) { if (hit.min < FLT_MAX) continue; }
+            trace_instance<false, false, LOC, false, StackT<STK::kStride, false, true>, true, OCTANTS, ANYHIT>(p, p.instances[i], i, org, dir, fast, hit, none, nullptr, &pops);
+            outgrown |= fast.sp;
+        }
+        if (outgrown == 0) return hit;
+        pops = pops_before;
+        hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
+        hit.loc = v3(0.0f, 0.0f, 0.0f);
+    }
     for (int i = 0; i < p.num_instances; i++) {
         if constexpr (ANYHIT) { if (hit.min < FLT_MAX) continue; }
-        trace_instance<false, false, LOC, false, Stack, true, OCTANTS, ANYHIT>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
+        trace_instance<false, false, LOC, false, STK, true, OCTANTS, ANYHIT>(p, p.instances[i], i, org, dir, stack, hit, none, nullptr, &pops);
     }
     return hit;
 }
@@ -1260,26 +1280,31 @@ __device__ __forceinline__ Xorwow ex_stream(const RenderParams& p, int x, int y,
     return rng;
 }
 
+// One wave per workgroup (round 5, like the primary kernels: a wave's slot is refilled when the wave ends, not when the last of
+// four does): workgroups 4t .. 4t + 3 are the four waves of tile t, and `quarter` below is what the wave index within a 256-thread
+// workgroup used to be.
+constexpr int kExBlock = 64;
+typedef StackT<kExBlock> ExStack;
 template <bool SIMPLE, bool PX = false>
-__global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams p)
+__global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];
     const FrameParams& f = p.frames[0];
-    const int tile = blockIdx.x;
+    const int tile = (int)(blockIdx.x >> 2), quarter = (int)(blockIdx.x & 3);
     int x, ly, y, s;
     bool valid;
-    ex_work_item<PX>(p, tile, (int)blockIdx.y, (int)threadIdx.x, x, ly, y, s, valid);
+    ex_work_item<PX>(p, tile, (int)blockIdx.y, quarter * 64 + (int)threadIdx.x, x, ly, y, s, valid);
     if constexpr (!PX) { if (!valid) return; }
     unsigned long long t_start = 0;
     if (p.trace) t_start = wall_clock64();
 
     int spill[kMaxStack - kLdsStack];
-    Stack stack;
+    ExStack stack;
     // (the thread's index lives on as the address of its LDS stack column only)
     stack.lds = (lds_int*)lds_stack + threadIdx.x; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
     auto where = [&](int& x_, int& ly_, int& y_, int& s_, bool& valid_) {
         asm volatile("" : "+v"(stack.lds));                     // (hides the address's origin: the optimiser would keep the first results alive)
-        ex_work_item<PX>(p, tile, (int)blockIdx.y, (int)(stack.lds - (lds_int*)lds_stack), x_, ly_, y_, s_, valid_);
+        ex_work_item<PX>(p, tile, (int)blockIdx.y, quarter * 64 + (int)(stack.lds - (lds_int*)lds_stack), x_, ly_, y_, s_, valid_);
     };
     int pops = 0;
     V3 sample = v3(0.0f, 0.0f, 0.0f);
@@ -1297,7 +1322,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     V3 dir = camera_direction(f, px, py);
     V3 weight = v3(1.0f, 1.0f, 1.0f);
     if constexpr (SIMPLE) {                                     // the loop below for bounces = 0, lighting = 0, written out
-        const Hit hit = cast_ray_ex<false, true>(p, org, dir, stack, pops);
+        const Hit hit = cast_ray_ex<false, true, false, ExStack, true>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) sample = sample + weight * v3(1.0f, 0.8f, 0.6f);
         else {
             const V3 base = base_colour(p, hit);
@@ -1311,7 +1336,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     {
     // one depth of the path: cast, shade, reflect; false = the path has ended
     auto step = [&](const int depth) __attribute__((always_inline)) -> bool {
-        Hit hit = cast_ray_ex(p, org, dir, stack, pops);
+        Hit hit = cast_ray_ex<true, false, false, ExStack>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); return false; }
         float illum = 1.0f;
 #if RT_EX_RECOMPUTE
@@ -1325,7 +1350,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
             if (cos_illum > 0) {
                 // (only hit-or-miss survives a shadow cast: no hit location to keep.  Octant loops at either cast of this
                 // kernel: within +-0.6 %, profiles/r04_experiments/octants_in_extension_kernels.log)
-                const Hit sh = cast_ray_ex<false, false, true>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
+                const Hit sh = cast_ray_ex<false, false, true, ExStack>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
                 asm volatile("" : "+v"(hit.slot));
                 if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)dot(hit_normal(p, hit), sun));
             }
@@ -1339,7 +1364,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
             const float cos_illum = dot(n, sun);
             illum = (float)(0.4 * (double)cos_illum);
             if (dot(n, sun) > 0) {
-                const Hit sh = cast_ray_ex<false, false, true>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
+                const Hit sh = cast_ray_ex<false, false, true, ExStack>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
                 if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);
             }
         }
@@ -1377,21 +1402,21 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     }
     }
     where(x, ly, y, s, valid);
-    const int tid = (int)(stack.lds - (lds_int*)lds_stack), wave = tid >> 6, lane = tid & 63;
+    const int lane = (int)(stack.lds - (lds_int*)lds_stack);
     if constexpr (PX) {
-        // the wave's samples -> its own LDS columns (the traversal stacks are idle now), four rows of 64 words: r g b pops
-        lds_int* mine = (lds_int*)lds_stack + wave * 64;
-        mine[0 * kBlock + lane] = __float_as_int(sample.x);
-        mine[1 * kBlock + lane] = __float_as_int(sample.y);
-        mine[2 * kBlock + lane] = __float_as_int(sample.z);
-        mine[3 * kBlock + lane] = pops;
+        // the wave's samples -> its LDS columns (the traversal stacks are idle now), four rows of 64 words: r g b pops
+        lds_int* mine = (lds_int*)lds_stack;
+        mine[0 * kExBlock + lane] = __float_as_int(sample.x);
+        mine[1 * kExBlock + lane] = __float_as_int(sample.y);
+        mine[2 * kExBlock + lane] = __float_as_int(sample.z);
+        mine[3 * kExBlock + lane] = pops;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // the first four lanes of a pixel add up one channel each, in sample order (what resolve_ex_kernel does per pixel)
         const int c = lane % p.px_n;
         if (c < 4 && x < p.width && ly < p.local_rows) {
-            const lds_int* col = mine + c * kBlock + (lane - c);
+            const lds_int* col = mine + c * kExBlock + (lane - c);
             const size_t pixel = (size_t)ly * p.width + x;
             if (c < 3) {
                 float acc = 0.0f;
@@ -1413,7 +1438,7 @@ __global__ __launch_bounds__(kBlock, 8) void render_ex_kernel(const RenderParams
     if (p.trace) {                                              // diagnostic: per-wave lifetime (RT_TRACE_FILE)
         const unsigned long long active = __ballot(true);
         if (lane == __ffsll((long long)active) - 1) {
-            unsigned long long* t = p.trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlock / 64) + wave) * 16;
+            unsigned long long* t = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
             t[0] = t_start; t[1] = wall_clock64(); t[3] = (unsigned long long)tile;
         }
     }
@@ -2869,7 +2894,7 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
         }
         p.ex_acc = s->d_ex_scratch;
         // (four LDS rows per lane hold a wave's samples for the in-wave sum, whatever the depth of the stack)
-        const size_t lds = (size_t)std::max(lds_rows(p.stack_depth), 4) * kBlock * sizeof(int);
+        const size_t lds = (size_t)std::max(lds_rows(p.stack_depth) + 1, 4) * kExBlock * sizeof(int);       // (+ the optimistic stack's spare row)
         for (int base = 0; base < p.spp; base += 64) {
             const int n = std::min(64, p.spp - base);
             int slots = 4;
@@ -2882,9 +2907,9 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
             p.sample_base = base;
             p.tiles_x = (p.width + 2 * p.px_pw - 1) / (2 * p.px_pw);
             p.tiles_y = (p.local_rows + 2 * p.px_ph - 1) / (2 * p.px_ph);
-            const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y));
-            if (simple) hipLaunchKernelGGL((render_ex_kernel<true, true>), grid, dim3(kBlock), lds, stream, p);
-            else hipLaunchKernelGGL((render_ex_kernel<false, true>), grid, dim3(kBlock), lds, stream, p);
+            const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * 4));         // four one-wave workgroups per tile
+            if (simple) hipLaunchKernelGGL((render_ex_kernel<true, true>), grid, dim3(kExBlock), lds, stream, p);
+            else hipLaunchKernelGGL((render_ex_kernel<false, true>), grid, dim3(kExBlock), lds, stream, p);
             RT_HIP(hipGetLastError());
         }
         if (synchronize) RT_HIP(hipStreamSynchronize(stream));
@@ -2920,7 +2945,7 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
     }
     p.ex_acc = s->d_ex_scratch;
     p.ex_samples = s->d_ex_scratch + npix;
-    const size_t lds = (size_t)lds_rows(p.stack_depth) * kBlock * sizeof(int);
+    const size_t lds = (size_t)(lds_rows(p.stack_depth) + 1) * kBlock * sizeof(int);                // (+ the optimistic stack's spare row)
     for (int base = 0; base < p.spp; base += chunk) {
         const int n = std::min(chunk, p.spp - base);
         p.sample_base = base;
@@ -2965,12 +2990,13 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
             }
             RT_HIP(hipGetLastError());
         } else {
-            const dim3 grid((unsigned)ntiles, (unsigned)n);
-            const size_t trace_n = (size_t)grid.x * grid.y * (kBlock / 64) * 16;
+            const dim3 grid((unsigned)ntiles * 4, (unsigned)n);                    // four one-wave workgroups per tile
+            const size_t trace_n = (size_t)grid.x * grid.y * 16;
             const bool tracing = trace_file && base == 0;
             if (tracing) RT_HIP(trace_begin(p, trace_n));
-            if (simple) hipLaunchKernelGGL(render_ex_kernel<true>, grid, dim3(kBlock), lds, stream, p);
-            else hipLaunchKernelGGL(render_ex_kernel<false>, grid, dim3(kBlock), lds, stream, p);
+            const size_t lds_wave = (size_t)(lds_rows(p.stack_depth) + 1) * kExBlock * sizeof(int);
+            if (simple) hipLaunchKernelGGL(render_ex_kernel<true>, grid, dim3(kExBlock), lds_wave, stream, p);
+            else hipLaunchKernelGGL(render_ex_kernel<false>, grid, dim3(kExBlock), lds_wave, stream, p);
             RT_HIP(hipGetLastError());
             if (tracing) RT_HIP(trace_end(p, trace_n, trace_file, stream));
         }
