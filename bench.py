@@ -894,8 +894,13 @@ def run_stream(args, env):
     single = F == 1 and not dist_on
     # (fourth template argument: the kernel with the private overflow of the traversal stack, for trees deeper than its LDS part)
     spill = scene.info()["max_stack"] - 1 > 16 or os.environ.get("RT_STACK_SPILL", "")[:1] == "1"
-    roof = roofline("render_kernel<false,false,%s,%s>" % ("true" if single else "false", "true" if spill else "false"), g["key"] + ("_f1" if single else ""),
-                    kernel_ms, F, 1.0 / world, alg)
+    # (fifth: the launches of this run rendered through view records -- batches of four and more frames, rt_scene_view_stats; the
+    # pre-pass that writes them is part of kernel_ms)
+    views = scene.view_stats()
+    config["view_records"] = views
+    roof = roofline("render_kernel<false,false,%s,%s,%s>" % ("true" if single else "false", "true" if spill else "false",
+                                                               "true" if views["launches"] > views["fallbacks"] and F >= 4 else "false"),
+                    g["key"] + ("_f1" if single else ""), kernel_ms, F, 1.0 / world, alg)
     # ms_per_step is the throughput figure of a batch (F frames per launch); what one frame takes on its own is spelled out next to it
     extra = {"frames_per_launch": F,
              "ms_per_frame_single_launch": None if latency is None else latency["f1_kernel_ms"],

@@ -62,7 +62,7 @@ class RtSceneDesc(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_build_info", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_scene_mesh_flags", "rt_render", "rt_render_overlapped", "rt_render_overlapped_stats", "rt_render_batch",
+    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_scene_mesh_flags", "rt_render", "rt_render_overlapped", "rt_render_overlapped_stats", "rt_scene_view_stats", "rt_render_batch",
     "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_render_stripes_batch_rotating", "rt_unstripe", "rt_unstripe_batch", "rt_unstripe_batch_rotating",
     "rt_comm_available", "rt_comm_last_error", "rt_comm_last_error_any", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_info", "rt_comm_destroy",
     "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
@@ -163,6 +163,7 @@ def _declare(h, s):
     h.rt_render.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, C.c_int]
     h.rt_render_overlapped.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t]
     h.rt_render_overlapped_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    h.rt_scene_view_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
     h.rt_render_ids.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, _vp, _vp, C.c_int]
     h.rt_stripe_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i]
@@ -427,6 +428,12 @@ class Scene:
         a, b = C.c_uint64(0), C.c_uint64(0)
         check(libs()[0].rt_render_overlapped_stats(self.device_handle, C.byref(a), C.byref(b)), "rt_render_overlapped_stats")
         return a.value, b.value
+
+    def view_stats(self):
+        """rt_scene_view_stats: dict(launches=, fallbacks=, grows=, slot_frames=) of the scene's view records"""
+        a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        check(libs()[0].rt_scene_view_stats(self.device_handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "rt_scene_view_stats")
+        return dict(launches=a.value, fallbacks=b.value, grows=c.value, slot_frames=d.value)
 
     def info(self):
         b = C.c_size_t(0)

@@ -636,7 +636,40 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_or_b64 exec, exec, s[38:39]\n\t" \
     "v_cndmask_b32_e32 %[cur], -1, v18, vcc\n\t"        /* nothing passes: this lane pops */
 
-#define RT_ASM_LOOP_TEXT(COUNT_TEXT, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+// The pieces that differ between the plain loop and the VIEW loop (RtScene::ViewPool: interior records whose box words already are
+// box - origin, `vdelta` bytes behind the records themselves):
+//   UNI_OFFSET    s31 = byte offset of the wave's one entry            VEC_ADDR     v16 = byte offset of the lane's entry
+//   UNI_INTERIOR  the interior step of a whole wave at one node         VEC_SUBS     box - origin of the lanes at interior nodes
+#define RT_ASM_UNI_OFFSET_PLAIN \
+    "s_lshl_b32 s31, s30, 6\n\t"
+#define RT_ASM_UNI_OFFSET_VIEW \
+    "s_cmp_lt_i32 s30, 0\n\t" \
+    "s_cselect_b32 s38, 0, %[vdelta]\n\t"              /* (a triangle record is read where it always is) */ \
+    "s_lshl_b32 s31, s30, 6\n\t" \
+    "s_add_u32 s31, s31, s38\n\t"
+#define RT_ASM_UNI_SUBS \
+    "v_sub_f32_e32 v0, s48, %[rox]\n\t"  "v_sub_f32_e32 v1, s49, %[roy]\n\t"  "v_sub_f32_e32 v2, s50, %[roz]\n\t" \
+    "v_sub_f32_e32 v3, s51, %[rox]\n\t"  "v_sub_f32_e32 v4, s52, %[roy]\n\t"  "v_sub_f32_e32 v5, s53, %[roz]\n\t" \
+    "v_sub_f32_e32 v6, s54, %[rox]\n\t"  "v_sub_f32_e32 v7, s55, %[roy]\n\t"  "v_sub_f32_e32 v8, s56, %[roz]\n\t" \
+    "v_sub_f32_e32 v9, s57, %[rox]\n\t"  "v_sub_f32_e32 v10, s58, %[roy]\n\t" "v_sub_f32_e32 v11, s59, %[roz]\n\t"
+#define RT_ASM_VEC_ADDR_PLAIN \
+    "v_lshlrev_b32_e32 v16, 6, %[cur]\n\t"
+#define RT_ASM_VEC_ADDR_VIEW \
+    "v_mov_b32_e32 v17, %[vdelta]\n\t" \
+    "v_cndmask_b32_e64 v17, 0, v17, s[64:65]\n\t"      /* lanes at an interior node read the frame's view of it */ \
+    "v_lshl_add_u32 v16, %[cur], 6, v17\n\t"
+#define RT_ASM_VEC_SUBS \
+    "s_waitcnt vmcnt(3)\n\t" \
+    "v_sub_f32_e32 v0, v0, %[rox]\n\t"  "v_sub_f32_e32 v1, v1, %[roy]\n\t"  "v_sub_f32_e32 v2, v2, %[roz]\n\t" \
+    "v_sub_f32_e32 v3, v3, %[rox]\n\t" \
+    "s_waitcnt vmcnt(2)\n\t" \
+    "v_sub_f32_e32 v4, v4, %[roy]\n\t"  "v_sub_f32_e32 v5, v5, %[roz]\n\t" \
+    "v_sub_f32_e32 v6, v6, %[rox]\n\t"  "v_sub_f32_e32 v7, v7, %[roy]\n\t" \
+    "s_waitcnt vmcnt(1)\n\t" \
+    "v_sub_f32_e32 v8, v8, %[roz]\n\t" \
+    "v_sub_f32_e32 v9, v9, %[rox]\n\t"  "v_sub_f32_e32 v10, v10, %[roy]\n\t" "v_sub_f32_e32 v11, v11, %[roz]\n\t"
+
+#define RT_ASM_LOOP_TEXT(COUNT_TEXT, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
     "s_mov_b64 s[46:47], exec\n\t" \
     ".Lrt_top%=:\n\t" \
     COUNT_TEXT \
@@ -646,18 +679,14 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_cmp_ne_u32_e32 vcc, s30, %[cur]\n\t" \
     "s_cbranch_vccnz .Lrt_vector%=\n\t" \
     /* ---- every lane holds the same entry: the record comes through the scalar cache */ \
-    "s_lshl_b32 s31, s30, 6\n\t" \
+    UNI_OFFSET \
     "s_load_dwordx16 s[48:63], %[rec], s31\n\t" \
     "s_cmp_lt_i32 s30, 0\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
     "s_cbranch_scc1 .Lrt_one_leaf%=\n\t" \
-    "v_sub_f32_e32 v0, s48, %[rox]\n\t"  "v_sub_f32_e32 v1, s49, %[roy]\n\t"  "v_sub_f32_e32 v2, s50, %[roz]\n\t" \
-    "v_sub_f32_e32 v3, s51, %[rox]\n\t"  "v_sub_f32_e32 v4, s52, %[roy]\n\t"  "v_sub_f32_e32 v5, s53, %[roz]\n\t" \
-    "v_sub_f32_e32 v6, s54, %[rox]\n\t"  "v_sub_f32_e32 v7, s55, %[roy]\n\t"  "v_sub_f32_e32 v8, s56, %[roz]\n\t" \
-    "v_sub_f32_e32 v9, s57, %[rox]\n\t"  "v_sub_f32_e32 v10, s58, %[roy]\n\t" "v_sub_f32_e32 v11, s59, %[roz]\n\t" \
     "v_mov_b32_e32 v12, s60\n\t" \
     "v_mov_b32_e32 v13, s61\n\t" \
-    RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+    UNI_INTERIOR \
     "s_branch .Lrt_pop%=\n\t" \
     ".Lrt_one_leaf%=:\n\t" \
     "v_mov_b32_e32 v0, s48\n\t"  "v_mov_b32_e32 v1, s49\n\t"  "v_mov_b32_e32 v2, s50\n\t"  "v_mov_b32_e32 v3, s51\n\t" \
@@ -668,22 +697,14 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_branch .Lrt_leaf%=\n\t" \
     /* ---- lanes hold different entries: one 64-byte record per lane, node or triangle, from one array */ \
     ".Lrt_vector%=:\n\t" \
-    "v_lshlrev_b32_e32 v16, 6, %[cur]\n\t" \
+    VEC_ADDR \
     "global_load_dwordx4 v[0:3], v16, %[rec]\n\t" \
     "global_load_dwordx4 v[4:7], v16, %[rec] offset:16\n\t" \
     "global_load_dwordx4 v[8:11], v16, %[rec] offset:32\n\t" \
     "global_load_dwordx4 v[12:15], v16, %[rec] offset:48\n\t" \
     "s_and_saveexec_b64 s[36:37], s[64:65]\n\t" \
     "s_cbranch_execz .Lrt_leaf_lanes%=\n\t" \
-    "s_waitcnt vmcnt(3)\n\t" \
-    "v_sub_f32_e32 v0, v0, %[rox]\n\t"  "v_sub_f32_e32 v1, v1, %[roy]\n\t"  "v_sub_f32_e32 v2, v2, %[roz]\n\t" \
-    "v_sub_f32_e32 v3, v3, %[rox]\n\t" \
-    "s_waitcnt vmcnt(2)\n\t" \
-    "v_sub_f32_e32 v4, v4, %[roy]\n\t"  "v_sub_f32_e32 v5, v5, %[roz]\n\t" \
-    "v_sub_f32_e32 v6, v6, %[rox]\n\t"  "v_sub_f32_e32 v7, v7, %[roy]\n\t" \
-    "s_waitcnt vmcnt(1)\n\t" \
-    "v_sub_f32_e32 v8, v8, %[roz]\n\t" \
-    "v_sub_f32_e32 v9, v9, %[rox]\n\t"  "v_sub_f32_e32 v10, v10, %[roy]\n\t" "v_sub_f32_e32 v11, v11, %[roz]\n\t" \
+    VEC_SUBS \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
     RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
     ".Lrt_leaf_lanes%=:\n\t" \
@@ -851,30 +872,6 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 
 struct AsmLoopState { int32_t cur, sp, rem; };
 
-template <int OCT, bool COUNT, int ROW_SHIFT>        // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
-__device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_index, const MeshRay& r, V3 org, lds_int* column, int lds_depth,
-                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters)
-{
-    int32_t rem = -1;
-    int32_t tos = kSentinel;                                    // the stack's top entry (row 0 of the LDS column holds a second sentinel, so
-                                                                // that the last pop's reload reads a row that exists and leaves sp == 0)
-    const float eps = __int_as_float(0x358637be);
-    // near / far plane registers per axis: bit k of OCT set = direction component k negative = the box's max plane is the near one
-#define RT_ASM_PICK(bit, lo, hi) ((OCT & bit) ? hi : lo)
-#define RT_ASM_GO(COUNT_TEXT, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
-    asm volatile(RT_ASM_LOOP_TEXT(COUNT_TEXT, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
-                 : [cur] "+v"(cur), [sp] "+v"(sp), [rem] "+v"(rem), [tos] "+v"(tos), [hmin] "+v"(hit.min), [hslot] "+v"(hit.slot), [hinst] "+v"(hit.instance), \
-                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters) \
-                 : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
-                   [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), [col] "v"(column), \
-                   [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
-                   [depth] "s"(lds_depth), [inst] "s"(inst_index), [eps] "s"(eps), [shift] "n"(ROW_SHIFT) \
-                 : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
-                   "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
-                   "s30", "s31", "s64", "s65", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", \
-                   "vcc", "scc", "memory")
-#define RT_ASM_OCT(COUNT_TEXT, X0, X1, Y0, Y1, Z0, Z1, BX0, BX1, BY0, BY1, BZ0, BZ1) \
-    RT_ASM_GO(COUNT_TEXT, X0, X1, Y0, Y1, Z0, Z1, BX0, BX1, BY0, BY1, BZ0, BZ1)
 // (experiments: -DRT_ASM_PAD_KIND=1|2|3 adds eight scalar / vector / no-op instructions to every iteration, to price an instruction of each kind)
 #define RT_ASM_X8(t) t t t t t t t t
 #if RT_ASM_PAD_KIND == 1
@@ -886,6 +883,27 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
 #else
 #define RT_ASM_PAD ""
 #endif
+
+template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW>        // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
+__device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_index, const MeshRay& r, V3 org, lds_int* column, int lds_depth,
+                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta)
+{
+    int32_t rem = -1;
+    int32_t tos = kSentinel;                                    // the stack's top entry (row 0 of the LDS column holds a second sentinel, so
+                                                                // that the last pop's reload reads a row that exists and leaves sp == 0)
+    const float eps = __int_as_float(0x358637be);
+#define RT_ASM_GO(TEXT) \
+    asm volatile(TEXT \
+                 : [cur] "+v"(cur), [sp] "+v"(sp), [rem] "+v"(rem), [tos] "+v"(tos), [hmin] "+v"(hit.min), [hslot] "+v"(hit.slot), [hinst] "+v"(hit.instance), \
+                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters) \
+                 : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
+                   [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), [col] "v"(column), \
+                   [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
+                   [depth] "s"(lds_depth), [inst] "s"(inst_index), [eps] "s"(eps), [shift] "n"(ROW_SHIFT), [vdelta] "s"(vdelta) \
+                 : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
+                   "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+                   "s30", "s31", "s64", "s65", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", \
+                   "vcc", "scc", "memory")
 #if RT_ASM_GUARD    // (bring-up only: a loop that does not end leaves after a million iterations instead of hanging the GPU)
 #define RT_ASM_COUNT "s_add_u32 %[iters], %[iters], 1\n\ts_cmp_gt_u32 %[iters], 0x100000\n\ts_cbranch_scc1 .Lrt_exit%=\n\t"
 #define RT_ASM_NOCOUNT RT_ASM_COUNT
@@ -893,24 +911,30 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
 #define RT_ASM_COUNT "s_add_u32 %[iters], %[iters], 1\n\t" RT_ASM_PAD
 #define RT_ASM_NOCOUNT RT_ASM_PAD
 #endif
-    // x: v0 / v3 (box a), v6 / v9 (box b); y: v1 / v4, v7 / v10; z: v2 / v5, v8 / v11 -- (min, max) planes
-#define RT_ASM_CASE(N, XA, XB, YA, YB, ZA, ZB, XC, XD, YC, YD, ZC, ZD) \
-    if constexpr (OCT == N) { if constexpr (COUNT) RT_ASM_OCT(RT_ASM_COUNT, XA, XB, YA, YB, ZA, ZB, XC, XD, YC, YD, ZC, ZD); \
-                              else RT_ASM_OCT(RT_ASM_NOCOUNT, XA, XB, YA, YB, ZA, ZB, XC, XD, YC, YD, ZC, ZD); }
-    RT_ASM_CASE(0, "v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11")
-    RT_ASM_CASE(1, "v3", "v0", "v1", "v4", "v2", "v5", "v9", "v6", "v7", "v10", "v8", "v11")
-    RT_ASM_CASE(2, "v0", "v3", "v4", "v1", "v2", "v5", "v6", "v9", "v10", "v7", "v8", "v11")
-    RT_ASM_CASE(3, "v3", "v0", "v4", "v1", "v2", "v5", "v9", "v6", "v10", "v7", "v8", "v11")
-    RT_ASM_CASE(4, "v0", "v3", "v1", "v4", "v5", "v2", "v6", "v9", "v7", "v10", "v11", "v8")
-    RT_ASM_CASE(5, "v3", "v0", "v1", "v4", "v5", "v2", "v9", "v6", "v7", "v10", "v11", "v8")
-    RT_ASM_CASE(6, "v0", "v3", "v4", "v1", "v5", "v2", "v6", "v9", "v10", "v7", "v11", "v8")
-    RT_ASM_CASE(7, "v3", "v0", "v4", "v1", "v5", "v2", "v9", "v6", "v10", "v7", "v11", "v8")
+#define RT_ASM_ARGS(...) __VA_ARGS__
+    // VN = the registers of the record's planes as the per-lane fetch leaves them (x: v0 / v3 for box a, v6 / v9 for box b; y: v1 / v4,
+    // v7 / v10; z: v2 / v5, v8 / v11 -- min, max), SN = the scalar registers a wave-uniform fetch leaves them in (s48 ..): per axis
+    // (near, far) for this octant -- bit k of OCT set = direction component k negative = the max plane is the near one (slab_oct).
+#define RT_ASM_VARIANT(CT, VN, SN) \
+    if constexpr (VIEW) RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, RT_ASM_UNI_OFFSET_VIEW, RT_ASM_INTERIOR(SN), RT_ASM_VEC_ADDR_VIEW, "", VN)); \
+    else RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, RT_ASM_UNI_OFFSET_PLAIN, RT_ASM_UNI_SUBS RT_ASM_INTERIOR(VN), RT_ASM_VEC_ADDR_PLAIN, RT_ASM_VEC_SUBS, VN))
+#define RT_ASM_CASE(N, VN, SN) \
+    if constexpr (OCT == N) { if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
+    RT_ASM_CASE(0, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s50", "s53", "s54", "s57", "s55", "s58", "s56", "s59"))
+    RT_ASM_CASE(1, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v2", "v5", "v9", "v6", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s50", "s53", "s57", "s54", "s55", "s58", "s56", "s59"))
+    RT_ASM_CASE(2, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v2", "v5", "v6", "v9", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s50", "s53", "s54", "s57", "s58", "s55", "s56", "s59"))
+    RT_ASM_CASE(3, RT_ASM_ARGS("v3", "v0", "v4", "v1", "v2", "v5", "v9", "v6", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s52", "s49", "s50", "s53", "s57", "s54", "s58", "s55", "s56", "s59"))
+    RT_ASM_CASE(4, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v5", "v2", "v6", "v9", "v7", "v10", "v11", "v8"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s53", "s50", "s54", "s57", "s55", "s58", "s59", "s56"))
+    RT_ASM_CASE(5, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v5", "v2", "v9", "v6", "v7", "v10", "v11", "v8"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s53", "s50", "s57", "s54", "s55", "s58", "s59", "s56"))
+    RT_ASM_CASE(6, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v5", "v2", "v6", "v9", "v10", "v7", "v11", "v8"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s53", "s50", "s54", "s57", "s58", "s55", "s59", "s56"))
+    RT_ASM_CASE(7, RT_ASM_ARGS("v3", "v0", "v4", "v1", "v5", "v2", "v9", "v6", "v10", "v7", "v11", "v8"), RT_ASM_ARGS("s51", "s48", "s52", "s49", "s53", "s50", "s57", "s54", "s58", "s55", "s59", "s56"))
 #undef RT_ASM_CASE
+#undef RT_ASM_VARIANT
+#undef RT_ASM_ARGS
 #undef RT_ASM_COUNT
 #undef RT_ASM_NOCOUNT
-#undef RT_ASM_OCT
 #undef RT_ASM_GO
-#undef RT_ASM_PICK
 }
 
 // Octant-specialised loops (RT_OCTANTS=0 at compile time keeps only the generic one).  The rays of a wave -- an 8x8-pixel
@@ -942,7 +966,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         const int first = __builtin_amdgcn_readfirstlane(mine);
         if ((p.mesh_flags[in.mesh_index] & 1) == 0 && __ballot(!usable || mine != first) == 0ull) oct = first;
     }
-    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && !EX && !POPS && !ANYHIT && !VIEW && !STK::kSpill) {
+    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && !EX && !POPS && !ANYHIT && !STK::kSpill) {
         // the hand-written loop (trace_loop_asm) for what it covers; everything else takes the C++ loops below
         if (oct >= 0 && in.exact_uv == 0 && in.identity_inv != 0) {
             stack.sp = 0;
@@ -950,7 +974,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             int32_t cur = in.root_ref, sp = stack.sp;
             int wave_iters = 0;
             static_assert(STK::kStride == 64 || STK::kStride == 256, "the stack column's row pitch as a shift");
-#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10)>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters)
+#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta)
             switch (oct) {
             case 0: RT_TRACE_ASM(0); break;
             case 1: RT_TRACE_ASM(1); break;
@@ -2062,11 +2086,14 @@ bool lds_stack_suffices(const RenderParams& p)
 // RT_VIEW_RECORDS=0: never (tests run parity scenes both ways).  RT_VIEW_MIN_RAYS=k: a launch qualifies when a frame brings at
 // least k rays per view record it costs to write (default 8: a record is written once and read by tens of rays; below that --
 // a rank's thin stripes of a frame, a huge tree under a small frame -- the pre-pass would cost more than the subtractions).
+// RT_VIEW_MIN_FRAMES=f: ... and when it carries at least f frames (default 4): the pre-pass is a launch of its own in front of
+// the render kernel, a few microseconds that a batch shares and a single frame pays alone (measured on c2: 32 frames per
+// launch -3 % / -6 % for the mid / near camera, one frame per launch +4 % / +7 %; profiles/r05_experiments/view_records_asm_ab.log).
 constexpr size_t kViewMaxBytes = (size_t)3 << 30;            // records + pool stay below 4 GiB: offsets are 32 bits
 
 int view_mode()
 {
-    static const int mode = [] { const char* e = getenv("RT_VIEW_RECORDS"); return e && e[0] == '1' ? 1 : 0; }();
+    static const int mode = [] { const char* e = getenv("RT_VIEW_RECORDS"); return e && e[0] == '0' ? 0 : 1; }();
     return mode;
 }
 
@@ -2097,7 +2124,12 @@ int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream)
         job.total += rf.int_cap;
     }
     static const long min_rays = [] { const char* e = getenv("RT_VIEW_MIN_RAYS"); long k = e ? atol(e) : 8; return k < 0 ? 0 : k; }();
-    if (job.total <= 0 || (long long)job.total * min_rays > (long long)p.width * p.local_rows) return -1;
+    static const int min_frames = [] { const char* e = getenv("RT_VIEW_MIN_FRAMES"); int k = e ? atoi(e) : 4; return k < 1 ? 1 : k; }();
+    if (job.total <= 0 || p.num_frames < min_frames || (long long)job.total * min_rays > (long long)p.width * p.local_rows) {
+        if (getenv("RT_VIEW_DEBUG")) fprintf(stderr, "rt view: not for this launch (records %d, frames %d of %d, rays per frame %lld, rays per record wanted %ld)\n",
+                                             job.total, p.num_frames, min_frames, (long long)p.width * p.local_rows, min_rays);
+        return -1;
+    }
     v.launches++;
     const size_t frame_bytes = (size_t)v.frame_records * 64;
     if (p.num_frames > v.slot_frames) {
@@ -2131,7 +2163,6 @@ int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream)
     p.records = s->d_records;                                   // (fill_params read it before a possible move)
     p.view_base = (uint32_t)(v.base_bytes + (size_t)use * v.slot_frames * frame_bytes);
     p.view_frame_stride = (uint32_t)frame_bytes;
-    if (getenv("RT_VIEW_SHARED")) p.view_frame_stride = 0;      // EXPERIMENT ONLY (identical poses in every frame of the batch)
     for (int i = 0; i < job.n; i++) p.view_inst_off[i] = (int32_t)(((int64_t)job.first[i] - job.node_base[i]) * 64);
     hipLaunchKernelGGL(view_records_kernel, dim3((unsigned)(((size_t)job.total * 4 + 255) / 256), (unsigned)p.num_frames), dim3(256), 0, stream, p, job);
     if (hipGetLastError() != hipSuccess) { v.fallbacks++; return -1; }
@@ -2731,6 +2762,17 @@ int rt_scene_info(const RtScene* s, size_t* device_bytes, int32_t* max_stack)
     if (!s) return RT_E_INVALID;
     if (device_bytes) *device_bytes = s->device_bytes;
     if (max_stack) *max_stack = s->max_stack;
+    return RT_OK;
+}
+
+int rt_scene_view_stats(RtScene* s, uint64_t* launches, uint64_t* fallbacks, uint64_t* grows, int32_t* slot_frames)
+{
+    if (!s) return RT_E_INVALID;
+    std::lock_guard<std::mutex> lock(s->view.m);
+    if (launches) *launches = s->view.launches;
+    if (fallbacks) *fallbacks = s->view.fallbacks;
+    if (grows) *grows = s->view.grows;
+    if (slot_frames) *slot_frames = s->view.slot_frames;
     return RT_OK;
 }
 

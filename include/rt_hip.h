@@ -209,6 +209,16 @@ int rt_render_overlapped(RtScene *scene, const RtCameraParams *cam, uint8_t *d_i
 /* how many frames went through rt_render_overlapped on this scene and how many of them had to wait for the other stream
  * (an image overlapping one written there and one written here); either pointer may be NULL */
 int rt_render_overlapped_stats(const RtScene *scene, uint64_t *launches, uint64_t *cross_stream_waits);
+/* View records (round 5; no counterpart in the reference, whose kernel subtracts the ray origin from every box at every visit,
+ * BVHTree.hpp:40-54 through raycast.cu:69-70): launches of at least four frames whose frames bring enough rays first write, per
+ * frame and instance, the interior records with `box - origin` in place of the boxes (the same fp32 subtraction, done once), and
+ * the traversal reads those.  The library keeps them behind the scene's records (the record array is re-allocated with a pool
+ * of three launches' views the first time a launch qualifies, and when a launch brings more frames than the pool was sized for:
+ * a device-wide synchronise, at most three times in a scene's life).  Nothing in a frame depends on it; RT_VIEW_RECORDS=0 turns
+ * it off.  This reports how many launches qualified, how many of those rendered without views after all (no free slot: more than
+ * three launches in flight on different streams; no memory), how often the pool grew, and the frames a slot holds now; any
+ * pointer may be NULL. */
+int rt_scene_view_stats(RtScene *scene, uint64_t *launches, uint64_t *fallbacks, uint64_t *grows, int32_t *slot_frames);
 /* `count` (1..RT_MAX_BATCH) frames of the same size in ONE launch: cams[i] is rendered into d_imgs[i].  A frame
  * stream rendered this way keeps the GPU full while the last long rays of one frame finish (the reference's own
  * loop issues two renders before it synchronises, kernel.cu:277-279). */

@@ -455,6 +455,109 @@ def test_batched_frames_equal_single_frames(rt, orc, scenes, blob5k):
         b.free()
 
 
+def test_view_records(rt, orc, scenes, blob5k):
+    """Round 5: launches of four and more frames render through VIEW records -- per frame and instance the interior records with
+    `box - origin` in place of the boxes, written once by a pre-pass into a pool behind the scene's records (rt_scene_view_stats).
+    Frames must not change: batches against single-frame launches (which take no views) and the oracle; the pool grows from 4 to
+    32 frames per slot (the record array moves); an instance moved between two batches; a mesh refitted after the array has moved;
+    more launches in flight on different streams than the pool has slots (the extra ones render without views)."""
+    import torch
+    W, H = 400, 240                             # (a frame must bring eight rays per view record: 10 297 records in the second scene)
+    K = scenes.scaled_K(W)
+    poses = [(0.05 * i, -1.5 - 0.1 * i, 0.2 + 0.02 * i, 0.02 * i, -0.01 * i, 0.0) for i in range(32)]
+    for desc in (sd.blob_scene(scenes, blob5k), sd.multi_instance_scene(scenes, blob5k)):
+        sp = desc.build_product(rt)
+        sp.upload_to_device()
+        cam = rt.Camera(W, H, K, scenes.D_REF)
+        singles = []
+        for ps in poses[:9]:
+            cam.set_pose(ps)
+            singles.append(rt.render_ids(sp, cam)["img"])                # one frame per launch: no views
+        assert sp.view_stats()["launches"] == 0
+        so = desc.build_oracle(orc)
+        for k in (0, 5):
+            assert np.array_equal(singles[k], so.render(W, H, K, scenes.D_REF, poses[k], planes=False)["img"])
+        so.close()
+        bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(32)]
+        for n, slot_frames, grows in ((4, 4, 1), (3, 4, 1), (9, 32, 2), (4, 32, 2)):
+            cam.render_scene_batch(sp, poses[:n], [b.ptr for b in bufs[:n]], bufs[0].pitch, synchronize=True)
+            st = sp.view_stats()
+            if n >= 4:
+                assert (st["slot_frames"], st["grows"], st["fallbacks"]) == (slot_frames, grows, 0), (n, st)
+            for i in range(n):
+                assert np.array_equal(bufs[i].to_host().reshape(H, W, 3), singles[i]), "batch of %d, frame %d" % (n, i)
+        assert sp.view_stats()["launches"] == 3
+        # an instance moved between two batches: the views are of the pose at launch time
+        mesh0, mat0, pose0, scale0 = desc.instances[0]
+        sp.update_mesh_instance(0, mesh0, mat0, (0.3, 0.2, -0.1, 0.2, 0.0, 0.1), scale0)
+        cam.set_pose(poses[2])
+        moved = rt.render_debug(sp, cam)["img"]
+        cam.render_scene_batch(sp, [poses[2]] * 4, [b.ptr for b in bufs[:4]], bufs[0].pitch, synchronize=True)
+        assert np.array_equal(bufs[3].to_host().reshape(H, W, 3), moved) and not np.array_equal(moved, singles[2])
+        sp.update_mesh_instance(0, mesh0, mat0, pose0, scale0)
+        # six streams, three slots: some launches find no slot and render without views -- every frame is still right
+        streams = [torch.cuda.Stream() for _ in range(6)]
+        cams = [rt.Camera(W, H, K, scenes.D_REF) for _ in streams]
+        sets = [[rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(4)] for _ in streams]
+        for rep in range(3):
+            for c, st_, bs in zip(cams, streams, sets):
+                c.set_stream(st_.cuda_stream)
+                c.render_scene_batch(sp, poses[rep:rep + 4], [b.ptr for b in bs], bs[0].pitch)
+            torch.cuda.synchronize()
+            for bs in sets:
+                for i, b in enumerate(bs):
+                    assert np.array_equal(b.to_host().reshape(H, W, 3), singles[rep + i]), (rep, i)
+        assert sp.view_stats()["launches"] == 4 + 18
+        for bs in sets:
+            for b in bs:
+                b.free()
+        for b in bufs:
+            b.free()
+    # a refit after the record array has moved behind the pool (single mesh: the blob, squeezed and back)
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    mesh = rt.Mesh.load_obj(blob5k)
+    tris = mesh.dump()["tris"].copy()
+    sp = rt.Scene()
+    sp.add_material((0.9, 0.5, 0.2))
+    sp.add_mesh(mesh)
+    sp.add_mesh_instance(0, 0)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(4)]
+    cam.render_scene_batch(sp, poses[:4], [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)
+    tris[:, :9].reshape(-1, 3, 3)[..., 0] *= np.float32(0.7)
+    for i in range(len(tris)):
+        tris[i, :12] = o.tri_from_vertices(tris[i, :9])[:12]
+    sp.refit_mesh(0, tris)
+    cam.set_pose(poses[1])
+    want = rt.render_debug(sp, cam)["img"]
+    cam.render_scene_batch(sp, poses[:4], [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)
+    assert np.array_equal(bufs[1].to_host().reshape(H, W, 3), want)
+    assert sp.view_stats()["launches"] == 2 and sp.view_stats()["fallbacks"] == 0
+
+
+def test_view_records_switched_off_in_a_child_process():
+    """RT_VIEW_RECORDS=0 (read once per process): the batch launches of the smoke scenes without view records, against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, importlib, numpy as np; sys.path.insert(0, 'tests'); import orc, scene_defs as sd\n"
+            "rt = importlib.import_module('cuda-raytracing_amd'); scenes = importlib.import_module('cuda-raytracing_amd.scenes'); rt.build(); orc.build_oracle()\n"
+            "blob = os.path.join('.scene_cache', 'blob5k.obj')\n"
+            "os.makedirs('.scene_cache', exist_ok=True)\n"
+            "if not os.path.exists(blob): scenes.write_blob_obj(blob, 50, 51)\n"
+            "W, H = 320, 200; K = scenes.scaled_K(W); desc = sd.blob_scene(scenes, blob); sp = desc.build_product(rt); sp.upload_to_device()\n"
+            "poses = [(0.05 * i, -1.5 - 0.1 * i, 0.2, 0.02 * i, 0.0, 0.0) for i in range(4)]\n"
+            "cam = rt.Camera(W, H, K, scenes.D_REF); bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(4)]\n"
+            "cam.render_scene_batch(sp, poses, [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)\n"
+            "so = desc.build_oracle(orc)\n"
+            "assert np.array_equal(bufs[3].to_host().reshape(H, W, 3), so.render(W, H, K, scenes.D_REF, poses[3], planes=False)['img'])\n"
+            "assert sp.view_stats()['launches'] == 0; print('no views ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RT_VIEW_RECORDS="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no views ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_scene_upload_builds_the_tree_on_the_device(rt, orc, scenes, blob5k, tmp_path):
     """A mesh that arrives without a tree (MeshPrimitive::for_device_build / OBJLoader::load_for_device; RtMeshDesc.num_nodes = 0):
     rt_scene_upload reserves its part of the arrays and the GPU builds the reference's tree in place.  The device arrays are byte
@@ -970,6 +1073,23 @@ def test_deep_traversal_stack_spills(rt, orc, scenes):
     img, ref = _compare(rt, orc, desc, W, H, scenes.scaled_K(W), scenes.D_REF, (0.0, -1.0, 0.0, 0, 0, 0))
     assert ref["stats"]["max_stack"] >= 24, ref["stats"]           # the scene really is deep (the reference stack holds 32)
     assert ref["stats"]["hits"] > 0
+
+
+def test_outgrown_stack_with_several_instances(rt, orc, scenes, blob5k):
+    """The timed kernels run the LDS-only stack and trace a ray whose stack outgrows it AGAIN on the general stack, from the first
+    instance on (round 5).  A deep chain between two ordinary meshes, in all three orders, one of them scaled and rotated (its loop is
+    the C++ one, the others' the hand-written one): the hit of an outgrown ray may come from an instance traced before or after the
+    chain, and every plane must equal the oracle's -- the production kernel's image and hit ids included."""
+    W, H = 96, 64
+    K, pose = scenes.scaled_K(W), (0.0, -1.0, 0.0, 0, 0, 0)
+    chain = sd.deep_stack_scene(26)
+    chain_tris = chain.meshes[0]
+    for order in ((0, 1, 2), (1, 0, 2), (1, 2, 0)):
+        meshes = [chain_tris, ("obj", blob5k), ("obj", blob5k)]
+        inst = [(0, 0, (0,) * 6, (1, 1, 1)), (1, 0, (0.4, 30.0, 0.2, 0, 0, 0), (1, 1, 1)), (2, 0, (-0.5, 3.0, -0.3, 0.3, 0.1, 0.2), (1.3, 0.8, 1.1))]
+        desc = sd.SceneDesc([((0.2, 0.9, 0.4), None)], meshes, [inst[k] for k in order])
+        img, ref = _compare(rt, orc, desc, W, H, K, scenes.D_REF, pose)
+        assert ref["stats"]["max_stack"] >= 20 and ref["stats"]["hits"] > 0, ref["stats"]
 
 
 def test_stack_depth_at_the_lds_boundary(rt, orc, scenes):

@@ -4,8 +4,8 @@
   profiles/<tag>_bench_line.json    the line bench.py printed under the profiler
   profiles/r05_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
                                     hash of the kernel source + build flags they were taken from (bench.py checks it)
-A frame = width x height x spp primary rays.  A dispatch of G work-items renders G / (tiles * 256 * spp) frames (one 256-thread
-workgroup per 16x16 tile per frame of the batch, or per sample of the frame), so counters are summed over every dispatch of
+A frame = width x height x spp primary rays.  A dispatch of G work-items renders G / (work-items per frame) frames (one 64-thread
+workgroup per 8x8 tile per frame of the batch; the extension kernel: 256 threads per 16x16 tile per sample), so counters are summed over every dispatch of
 the kernel and divided by the frames those dispatches rendered: the result does not depend on --steps or frames per launch.
    python tools/summarize_profile.py <profdir> <tag>"""
 import collections, csv, glob, json, os, shutil, sys
@@ -31,8 +31,10 @@ if kernel == "render_kernel<false, false>":                 # (lines printed bef
     kernel = "render_kernel<false, false, false>"
 if kernel.startswith("render_kernel<") and kernel.count(",") == 2:      # (lines printed before the SPILL parameter existed: either form)
     kernel = kernel[:-1] + ", "
+# (round 5: the primary kernels' workgroup is one wave = one 8x8-pixel tile; the extension kernel's tile is still 16x16 pixels,
+# rendered by four one-wave workgroups)
 tiles = ((W + 15) // 16) * ((H + 15) // 16)
-per_frame_items = tiles * 256 * (cfg["spp"] if "render_ex" in kernel else 1)
+per_frame_items = tiles * 256 * cfg["spp"] if "render_ex" in kernel else ((W + 7) // 8) * ((H + 7) // 8) * 64
 # render_ex_kernel<.., PX> (4 and more samples per pixel): a launch covers up to 64 samples of every pixel, a frame is
 # ceil(spp / 64) launches of ceil(W / 2pw) x ceil(H / 2ph) workgroups -- count frames by dispatches, not by work-items
 ex_launches_per_frame = (cfg["spp"] + 63) // 64 if ("render_ex" in kernel and cfg["spp"] >= 4) else 0
