@@ -599,6 +599,21 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 #define RT_ASM_GUARD 0
 #endif
 
+// RT_ASM_BACKFACE: when no lane of the wave holds a triangle that faces its ray (denom < 0, raycast.cu:107-109) the rest of
+// the triangle test -- the division, the point on the plane, the barycentrics -- is skipped for the whole wave.
+#ifndef RT_ASM_BACKFACE
+#define RT_ASM_BACKFACE 1
+#endif
+#if RT_ASM_BACKFACE
+#define RT_ASM_BACKFACE_EXIT \
+    "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t" \
+    "s_cbranch_scc0 .Lrt_next_triangle%=\n\t"
+#define RT_ASM_BACKFACE_AND ""
+#else
+#define RT_ASM_BACKFACE_EXIT ""
+#define RT_ASM_BACKFACE_AND "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t"
+#endif
+
 // one interior node: v0..v11 hold box - origin, v12 / v13 the two child entries; exec = the lanes at this node.
 // N* / F* = the registers holding the near / far plane of the axis for this octant (slab_oct's operand choice).
 #define RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
@@ -745,6 +760,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_rcp_f32_e32 v19, v18\n\t" \
     "v_cmp_nlt_f32_e64 s[40:41], |v16|, %[eps]\n\t"     /* !(|denom| < 1e-6) */ \
     "v_cmp_gt_f32_e64 s[42:43], 0, v16\n\t"             /* denom < 0: the only candidates that can be accepted */ \
+    RT_ASM_BACKFACE_EXIT \
     "v_fma_f32 v20, -v18, v19, 1.0\n\t" \
     "v_fmac_f32_e32 v19, v20, v19\n\t" \
     "v_div_scale_f32 v20, vcc, v17, v16, v17\n\t" \
@@ -754,7 +770,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_fma_f32 v18, -v18, v21, v20\n\t" \
     "v_div_fmas_f32 v18, v18, v19, v21\n\t" \
     "v_div_fixup_f32 v17, v18, v16, v17\n\t"            /* tt */ \
-    "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t" \
+    RT_ASM_BACKFACE_AND \
     "v_mul_f32_e32 v18, %[rdx], v17\n\t" \
     "v_mul_f32_e32 v19, %[rdy], v17\n\t" \
     "v_mul_f32_e32 v20, %[rdz], v17\n\t" \
@@ -842,6 +858,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_mov_b32_e32 %[hv], v27\n\t" \
     ".Lrt_no_candidate%=:\n\t" \
     "s_or_b64 exec, exec, s[44:45]\n\t" \
+    ".Lrt_next_triangle%=:\n\t" \
     /* next triangle of the leaf, or a pop */ \
     "v_add_u32_e32 %[rem], -1, %[rem]\n\t" \
     "v_add_u32_e32 v16, 1, %[cur]\n\t" \

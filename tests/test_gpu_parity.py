@@ -42,6 +42,13 @@ def _compare(rt, orc, desc, width, height, K, D, pose, threads=8, gpu_build=Fals
         bad = int((dbg[n] != ref[n]).sum())
         assert bad == 0, "%s: %d pixels differ from the oracle" % (n, bad)
     so.close()
+    # a launch of four frames renders through VIEW records where the scene allows them (at most eight instances; tests/conftest.py
+    # lifts the rays-per-record threshold, so that frames of any size do): all four must be the frame above
+    bufs = [rt.DeviceBuffer(width_bytes=width * 3, height=height) for _ in range(4)]
+    cam.render_scene_batch(sp, [pose] * 4, [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)
+    for k, b in enumerate(bufs):
+        assert np.array_equal(b.to_host().reshape(height, width, 3), img), "frame %d of a batch of four differs (view records %s)" % (k, sp.view_stats())
+        b.free()
     return img, ref
 
 
@@ -1446,6 +1453,13 @@ def test_fuzz_random_scenes(rt, orc, scenes, blob5k, seed):
         pose = tuple(np.concatenate([rng.uniform(-1.5, 1.5, 3), rng.uniform(-3.1, 3.1, 3)]))
         scale = tuple(rng.uniform(0.3, 1.8, 3)) if rng.random() < 0.7 else (1.0, 1.0, 1.0)
         instances.append((int(rng.integers(n_mesh)), int(rng.integers(len(materials))), pose, scale))
+    # (from seed 34000 on: a fresh generator, so that the scenes of the earlier campaigns stay what they were.  A third of the scenes
+    # get one instance whose transform is the identity -- the case the hand-written traversal loop takes)
+    if seed >= 34000 or seed < 12:
+        extra = np.random.default_rng(5000 + seed)
+        if extra.random() < (0.34 if seed >= 34000 else 0.5):
+            k = int(extra.integers(len(instances)))
+            instances[k] = (instances[k][0], instances[k][1], (0.0,) * 6, (1.0, 1.0, 1.0))
     W, H = int(rng.integers(20, 200)), int(rng.integers(20, 140))
     cam_pose = tuple(np.concatenate([rng.uniform(-1, 1, 1), rng.uniform(-5, -2, 1), rng.uniform(-1, 1, 1), rng.uniform(-0.4, 0.4, 3)]))
     # (every third scene takes its trees from the GPU builder)

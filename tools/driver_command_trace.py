@@ -13,7 +13,7 @@ for r in csv.DictReader(open(kt)):
     if "render_kernel<false, false, false" in r["Kernel_Name"]:
         grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
         groups[grid].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-per_frame = ((line["config"]["width"] + 15) // 16) * ((line["config"]["height"] + 15) // 16) * 256
+per_frame = ((line["config"]["width"] + 7) // 8) * ((line["config"]["height"] + 7) // 8) * 64          # (round 5: one 64-thread workgroup per 8x8-pixel tile)
 out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5",
        "line": {k: line.get(k) for k in ("value", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repeats")},
        "line_kernel_ms_per_launch": line["roofline"]["kernel_ms"], "line_frames_per_launch": line["roofline"]["frames_per_launch"],
