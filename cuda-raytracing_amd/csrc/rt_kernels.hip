@@ -684,7 +684,13 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_sub_f32_e32 v8, v8, %[roz]\n\t" \
     "v_sub_f32_e32 v9, v9, %[rox]\n\t"  "v_sub_f32_e32 v10, v10, %[roy]\n\t" "v_sub_f32_e32 v11, v11, %[roz]\n\t"
 
-#define RT_ASM_LOOP_TEXT(COUNT_TEXT, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+// POPS (the samples-only extension kernel counts node pops per lane): one more per interior node, one per leaf arrived at
+#define RT_ASM_POPS_INTERIOR "v_add_u32_e32 %[pops], 1, %[pops]\n\t"
+#define RT_ASM_POPS_LEAF \
+    "v_cndmask_b32_e64 v17, 0, 1, vcc\n\t"             /* (vcc = first triangle of this leaf, two instructions old) */ \
+    "v_add_u32_e32 %[pops], %[pops], v17\n\t"
+
+#define RT_ASM_LOOP_TEXT(COUNT_TEXT, POPS_INT, POPS_LEAF, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
     "s_mov_b64 s[46:47], exec\n\t" \
     ".Lrt_top%=:\n\t" \
     COUNT_TEXT \
@@ -701,6 +707,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_cbranch_scc1 .Lrt_one_leaf%=\n\t" \
     "v_mov_b32_e32 v12, s60\n\t" \
     "v_mov_b32_e32 v13, s61\n\t" \
+    POPS_INT \
     UNI_INTERIOR \
     "s_branch .Lrt_pop%=\n\t" \
     ".Lrt_one_leaf%=:\n\t" \
@@ -719,6 +726,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "global_load_dwordx4 v[12:15], v16, %[rec] offset:48\n\t" \
     "s_and_saveexec_b64 s[36:37], s[64:65]\n\t" \
     "s_cbranch_execz .Lrt_leaf_lanes%=\n\t" \
+    POPS_INT \
     VEC_SUBS \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
     RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
@@ -733,6 +741,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_cmp_eq_u32_e64 s[38:39], 31, v16\n\t" \
     "s_waitcnt vmcnt(0)\n\t" \
     "v_cndmask_b32_e32 %[rem], %[rem], v16, vcc\n\t" \
+    POPS_LEAF \
     "s_and_b64 s[38:39], s[38:39], vcc\n\t"             /* a leaf of more than 30 triangles: its count is in leaf_count */ \
     "s_cbranch_scc0 .Lrt_short%=\n\t" \
     "s_and_saveexec_b64 s[40:41], s[38:39]\n\t" \
@@ -901,9 +910,9 @@ struct AsmLoopState { int32_t cur, sp, rem; };
 #define RT_ASM_PAD ""
 #endif
 
-template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW>        // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
+template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW, bool POPS>  // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
 __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_index, const MeshRay& r, V3 org, lds_int* column, int lds_depth,
-                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta)
+                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta, int& pops)
 {
     int32_t rem = -1;
     int32_t tos = kSentinel;                                    // the stack's top entry (row 0 of the LDS column holds a second sentinel, so
@@ -912,7 +921,7 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
 #define RT_ASM_GO(TEXT) \
     asm volatile(TEXT \
                  : [cur] "+v"(cur), [sp] "+v"(sp), [rem] "+v"(rem), [tos] "+v"(tos), [hmin] "+v"(hit.min), [hslot] "+v"(hit.slot), [hinst] "+v"(hit.instance), \
-                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters) \
+                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters), [pops] "+v"(pops) \
                  : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
                    [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), [col] "v"(column), \
                    [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
@@ -932,12 +941,14 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
     // VN = the registers of the record's planes as the per-lane fetch leaves them (x: v0 / v3 for box a, v6 / v9 for box b; y: v1 / v4,
     // v7 / v10; z: v2 / v5, v8 / v11 -- min, max), SN = the scalar registers a wave-uniform fetch leaves them in (s48 ..): per axis
     // (near, far) for this octant -- bit k of OCT set = direction component k negative = the max plane is the near one (slab_oct).
-#define RT_ASM_VARIANT(CT, VN, SN) \
-    if constexpr (VIEW) RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, RT_ASM_UNI_OFFSET_VIEW, RT_ASM_INTERIOR(SN), RT_ASM_VEC_ADDR_VIEW, "", VN)); \
-    else RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, RT_ASM_UNI_OFFSET_PLAIN, RT_ASM_UNI_SUBS RT_ASM_INTERIOR(VN), RT_ASM_VEC_ADDR_PLAIN, RT_ASM_VEC_SUBS, VN))
+#define RT_ASM_VARIANT(CT, PI, PL, VN, SN) \
+    if constexpr (VIEW) RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, PI, PL, RT_ASM_UNI_OFFSET_VIEW, RT_ASM_INTERIOR(SN), RT_ASM_VEC_ADDR_VIEW, "", VN)); \
+    else RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, PI, PL, RT_ASM_UNI_OFFSET_PLAIN, RT_ASM_UNI_SUBS RT_ASM_INTERIOR(VN), RT_ASM_VEC_ADDR_PLAIN, RT_ASM_VEC_SUBS, VN))
+    // (COUNT -- the tile cost of single-frame primary launches -- and POPS -- the extension kernel's pop plane -- never meet)
 #define RT_ASM_CASE(N, VN, SN) \
-    if constexpr (OCT == N) { if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
-                              else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
+    if constexpr (OCT == N) { if constexpr (POPS) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, "", "", RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, "", "", RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
     RT_ASM_CASE(0, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s50", "s53", "s54", "s57", "s55", "s58", "s56", "s59"))
     RT_ASM_CASE(1, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v2", "v5", "v9", "v6", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s50", "s53", "s57", "s54", "s55", "s58", "s56", "s59"))
     RT_ASM_CASE(2, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v2", "v5", "v6", "v9", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s50", "s53", "s54", "s57", "s58", "s55", "s56", "s59"))
@@ -983,7 +994,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         const int first = __builtin_amdgcn_readfirstlane(mine);
         if ((p.mesh_flags[in.mesh_index] & 1) == 0 && __ballot(!usable || mine != first) == 0ull) oct = first;
     }
-    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && !EX && !POPS && !ANYHIT && !STK::kSpill) {
+    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && !EX && !(POPS && COUNT) && !ANYHIT && !STK::kSpill) {
         // the hand-written loop (trace_loop_asm) for what it covers; everything else takes the C++ loops below
         if (oct >= 0 && in.exact_uv == 0 && in.identity_inv != 0) {
             stack.sp = 0;
@@ -991,7 +1002,9 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             int32_t cur = in.root_ref, sp = stack.sp;
             int wave_iters = 0;
             static_assert(STK::kStride == 64 || STK::kStride == 256, "the stack column's row pitch as a shift");
-#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta)
+            int no_pops = 0;
+#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW, POPS>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta, \
+                                                                                          POPS ? *pops : no_pops)
             switch (oct) {
             case 0: RT_TRACE_ASM(0); break;
             case 1: RT_TRACE_ASM(1); break;
@@ -1227,9 +1240,11 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
 // OPTIMISTIC: only the samples-only kernel asks for it -- in the bounce kernel, which carries its path state across the casts in
 // registers it does not have, the second loop costs more in spills than the branches it saves: c3 +8 %
 // (profiles/r05_experiments/ex_one_wave_workgroups.log).
-template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false, class STK = Stack, bool OPTIMISTIC = false>
+// VIEW (the samples-only kernel's primary rays: they share the frame's origin): the cast reads view records, see trace_loop.
+template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false, class STK = Stack, bool OPTIMISTIC = false, bool VIEW = false>
 __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, STK& stack, int& pops)
 {
+    static_assert(!VIEW || OPTIMISTIC, "view records are read by the LDS-only loops");
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
     hit.loc = v3(0.0f, 0.0f, 0.0f);
@@ -1243,7 +1258,8 @@ __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir
         int outgrown = 0;
         for (int i = 0; i < p.num_instances; i++) {
             if constexpr (ANYHIT) { if (hit.min < FLT_MAX) continue; }
-            trace_instance<false, false, LOC, false, StackT<STK::kStride, false, true>, true, OCTANTS, ANYHIT>(p, p.instances[i], i, org, dir, fast, hit, none, nullptr, &pops);
+            trace_instance<false, false, LOC, false, StackT<STK::kStride, false, true>, true, OCTANTS, ANYHIT, VIEW>(p, p.instances[i], i, org, dir, fast, hit, none, nullptr, &pops,
+                                                                                                                  p.view_base);
             outgrown |= fast.sp;
         }
         if (outgrown == 0) return hit;
@@ -1326,7 +1342,7 @@ __device__ __forceinline__ Xorwow ex_stream(const RenderParams& p, int x, int y,
 // workgroup used to be.
 constexpr int kExBlock = 64;
 typedef StackT<kExBlock> ExStack;
-template <bool SIMPLE, bool PX = false>
+template <bool SIMPLE, bool PX = false, bool VIEW = false>
 __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];
@@ -1363,7 +1379,7 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     V3 dir = camera_direction(f, px, py);
     V3 weight = v3(1.0f, 1.0f, 1.0f);
     if constexpr (SIMPLE) {                                     // the loop below for bounces = 0, lighting = 0, written out
-        const Hit hit = cast_ray_ex<false, true, false, ExStack, true>(p, org, dir, stack, pops);
+        const Hit hit = cast_ray_ex<false, true, false, ExStack, true, VIEW>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) sample = sample + weight * v3(1.0f, 0.8f, 0.6f);
         else {
             const V3 base = base_colour(p, hit);
@@ -2117,7 +2133,8 @@ int view_mode()
 // Decides whether this launch renders through view records; if so: a slot of the pool (grown when needed), the launch's view
 // parameters in `p`, the pre-pass queued on `stream`.  Returns the slot (view_done records its event after the render kernel) or
 // -1: the launch then runs the kernels without views -- same pixels.
-int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream)
+// `samples`: primary rays per pixel (the samples-only extension kernel: its jittered rays share the frame's origin too).
+int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream, int samples = 1)
 {
     if (!view_mode() || !s || p.num_instances < 1 || p.num_instances > kMaxViewInstances || p.num_ranks < 1) return -1;
     RtScene::ViewPool& v = s->view;
@@ -2142,7 +2159,7 @@ int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream)
     }
     static const long min_rays = [] { const char* e = getenv("RT_VIEW_MIN_RAYS"); long k = e ? atol(e) : 8; return k < 0 ? 0 : k; }();
     static const int min_frames = [] { const char* e = getenv("RT_VIEW_MIN_FRAMES"); int k = e ? atoi(e) : 4; return k < 1 ? 1 : k; }();
-    if (job.total <= 0 || p.num_frames < min_frames || (long long)job.total * min_rays > (long long)p.width * p.local_rows) {
+    if (job.total <= 0 || (long long)p.num_frames * samples < min_frames || (long long)job.total * min_rays > (long long)p.width * p.local_rows * samples) {
         if (getenv("RT_VIEW_DEBUG")) fprintf(stderr, "rt view: not for this launch (records %d, frames %d of %d, rays per frame %lld, rays per record wanted %ld)\n",
                                              job.total, p.num_frames, min_frames, (long long)p.width * p.local_rows, min_rays);
         return -1;
@@ -2954,6 +2971,12 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
         p.ex_acc = s->d_ex_scratch;
         // (four LDS rows per lane hold a wave's samples for the in-wave sum, whatever the depth of the stack)
         const size_t lds = (size_t)std::max(lds_rows(p.stack_depth) + 1, 4) * kExBlock * sizeof(int);       // (+ the optimistic stack's spare row)
+        // the samples-only kernel's rays all start at the camera: one view of the tree serves every sample of the frame
+        const int view_slot = simple ? view_prepare(s, p, stream, p.spp) : -1;
+        struct ViewDone {
+            RtScene* s; int slot; hipStream_t stream;
+            ~ViewDone() { view_done(s, slot, stream); }
+        } view_guard{s, view_slot, stream};
         for (int base = 0; base < p.spp; base += 64) {
             const int n = std::min(64, p.spp - base);
             int slots = 4;
@@ -2967,7 +2990,8 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
             p.tiles_x = (p.width + 2 * p.px_pw - 1) / (2 * p.px_pw);
             p.tiles_y = (p.local_rows + 2 * p.px_ph - 1) / (2 * p.px_ph);
             const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * 4));         // four one-wave workgroups per tile
-            if (simple) hipLaunchKernelGGL((render_ex_kernel<true, true>), grid, dim3(kExBlock), lds, stream, p);
+            if (simple && view_slot >= 0) hipLaunchKernelGGL((render_ex_kernel<true, true, true>), grid, dim3(kExBlock), lds, stream, p);
+            else if (simple) hipLaunchKernelGGL((render_ex_kernel<true, true>), grid, dim3(kExBlock), lds, stream, p);
             else hipLaunchKernelGGL((render_ex_kernel<false, true>), grid, dim3(kExBlock), lds, stream, p);
             RT_HIP(hipGetLastError());
         }
