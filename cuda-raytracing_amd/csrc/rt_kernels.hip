@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -52,6 +53,9 @@ using namespace rt;
 #ifndef RT_OPTIMISTIC_STACK
 #define RT_OPTIMISTIC_STACK 1   // deep trees: the timed kernels run the LDS-only stack and a lane whose stack would outgrow it starts again on the
                                 // general stack afterwards (render_pixel), instead of every push and pop asking "which memory"
+#endif
+#ifndef RT_EX_PRIMARY_ASM
+#define RT_EX_PRIMARY_ASM 1     // the bounce kernel's camera ray through the hand-written loop and the view records
 #endif
 #ifndef RT_NEED_POP_VALUE
 #define RT_NEED_POP_VALUE 1     // "this lane must pop" is a value of `cur` (kNeedPop), not a flag merged across the loop's branches
@@ -690,7 +694,11 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_cndmask_b32_e64 v17, 0, 1, vcc\n\t"             /* (vcc = first triangle of this leaf, two instructions old) */ \
     "v_add_u32_e32 %[pops], %[pops], v17\n\t"
 
-#define RT_ASM_LOOP_TEXT(COUNT_TEXT, POPS_INT, POPS_LEAF, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+// LOC (the bounce kernel's primary ray): the accepted candidate's point on its plane, in mesh space -- the caller turns it into the
+// world-space hit location with the reference's own sequence (raycast.cu:98-104), once, for the hit that was kept
+#define RT_ASM_LOC "v_mov_b32_e32 %[px], v18\n\tv_mov_b32_e32 %[py], v19\n\tv_mov_b32_e32 %[pz], v20\n\t"
+
+#define RT_ASM_LOOP_TEXT(COUNT_TEXT, POPS_INT, POPS_LEAF, LOC_TEXT, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
     "s_mov_b64 s[46:47], exec\n\t" \
     ".Lrt_top%=:\n\t" \
     COUNT_TEXT \
@@ -865,6 +873,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_mov_b32_e32 %[hinst], %[inst]\n\t" \
     "v_mov_b32_e32 %[hu], v26\n\t" \
     "v_mov_b32_e32 %[hv], v27\n\t" \
+    LOC_TEXT \
     ".Lrt_no_candidate%=:\n\t" \
     "s_or_b64 exec, exec, s[44:45]\n\t" \
     ".Lrt_next_triangle%=:\n\t" \
@@ -896,8 +905,6 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_waitcnt lgkmcnt(0)\n\t"                         /* (the last pop's reload of the top) */ \
     "s_mov_b64 exec, s[46:47]\n\t"
 
-struct AsmLoopState { int32_t cur, sp, rem; };
-
 // (experiments: -DRT_ASM_PAD_KIND=1|2|3 adds eight scalar / vector / no-op instructions to every iteration, to price an instruction of each kind)
 #define RT_ASM_X8(t) t t t t t t t t
 #if RT_ASM_PAD_KIND == 1
@@ -910,18 +917,22 @@ struct AsmLoopState { int32_t cur, sp, rem; };
 #define RT_ASM_PAD ""
 #endif
 
-template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW, bool POPS>  // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
+template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW, bool POPS, bool LOC>  // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
 __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_index, const MeshRay& r, V3 org, lds_int* column, int lds_depth,
-                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta, int& pops)
+                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta, int& pops, V3& point)
 {
+    static_assert(!LOC || POPS, "the hit point is kept for the extension kernel, which counts pops");
     int32_t rem = -1;
     int32_t tos = kSentinel;                                    // the stack's top entry (row 0 of the LDS column holds a second sentinel, so
                                                                 // that the last pop's reload reads a row that exists and leaves sp == 0)
     const float eps = __int_as_float(0x358637be);
-#define RT_ASM_GO(TEXT) \
+#define RT_ASM_OUT_PLAIN
+#define RT_ASM_OUT_LOC , [px] "+v"(point.x), [py] "+v"(point.y), [pz] "+v"(point.z)
+#define RT_ASM_GO(TEXT) RT_ASM_GO2(TEXT, RT_ASM_OUT_PLAIN)
+#define RT_ASM_GO2(TEXT, ...)        /* (... = more output operands, with their leading comma, or nothing) */ \
     asm volatile(TEXT \
                  : [cur] "+v"(cur), [sp] "+v"(sp), [rem] "+v"(rem), [tos] "+v"(tos), [hmin] "+v"(hit.min), [hslot] "+v"(hit.slot), [hinst] "+v"(hit.instance), \
-                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters), [pops] "+v"(pops) \
+                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters), [pops] "+v"(pops) __VA_ARGS__ \
                  : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
                    [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), [col] "v"(column), \
                    [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
@@ -941,14 +952,15 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
     // VN = the registers of the record's planes as the per-lane fetch leaves them (x: v0 / v3 for box a, v6 / v9 for box b; y: v1 / v4,
     // v7 / v10; z: v2 / v5, v8 / v11 -- min, max), SN = the scalar registers a wave-uniform fetch leaves them in (s48 ..): per axis
     // (near, far) for this octant -- bit k of OCT set = direction component k negative = the max plane is the near one (slab_oct).
-#define RT_ASM_VARIANT(CT, PI, PL, VN, SN) \
-    if constexpr (VIEW) RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, PI, PL, RT_ASM_UNI_OFFSET_VIEW, RT_ASM_INTERIOR(SN), RT_ASM_VEC_ADDR_VIEW, "", VN)); \
-    else RT_ASM_GO(RT_ASM_LOOP_TEXT(CT, PI, PL, RT_ASM_UNI_OFFSET_PLAIN, RT_ASM_UNI_SUBS RT_ASM_INTERIOR(VN), RT_ASM_VEC_ADDR_PLAIN, RT_ASM_VEC_SUBS, VN))
+#define RT_ASM_VARIANT(CT, PI, PL, LT, OUT, VN, SN) \
+    if constexpr (VIEW) RT_ASM_GO2(RT_ASM_LOOP_TEXT(CT, PI, PL, LT, RT_ASM_UNI_OFFSET_VIEW, RT_ASM_INTERIOR(SN), RT_ASM_VEC_ADDR_VIEW, "", VN), OUT); \
+    else RT_ASM_GO2(RT_ASM_LOOP_TEXT(CT, PI, PL, LT, RT_ASM_UNI_OFFSET_PLAIN, RT_ASM_UNI_SUBS RT_ASM_INTERIOR(VN), RT_ASM_VEC_ADDR_PLAIN, RT_ASM_VEC_SUBS, VN), OUT)
     // (COUNT -- the tile cost of single-frame primary launches -- and POPS -- the extension kernel's pop plane -- never meet)
 #define RT_ASM_CASE(N, VN, SN) \
-    if constexpr (OCT == N) { if constexpr (POPS) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
-                              else if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, "", "", RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
-                              else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, "", "", RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
+    if constexpr (OCT == N) { if constexpr (LOC) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, RT_ASM_LOC, RT_ASM_OUT_LOC, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else if constexpr (POPS) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
     RT_ASM_CASE(0, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s50", "s53", "s54", "s57", "s55", "s58", "s56", "s59"))
     RT_ASM_CASE(1, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v2", "v5", "v9", "v6", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s50", "s53", "s57", "s54", "s55", "s58", "s56", "s59"))
     RT_ASM_CASE(2, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v2", "v5", "v6", "v9", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s50", "s53", "s54", "s57", "s58", "s55", "s56", "s59"))
@@ -963,6 +975,9 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
 #undef RT_ASM_COUNT
 #undef RT_ASM_NOCOUNT
 #undef RT_ASM_GO
+#undef RT_ASM_GO2
+#undef RT_ASM_OUT_PLAIN
+#undef RT_ASM_OUT_LOC
 }
 
 // Octant-specialised loops (RT_OCTANTS=0 at compile time keeps only the generic one).  The rays of a wave -- an 8x8-pixel
@@ -976,8 +991,9 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
 // 23.7 ms with the generic loop alone, profiles/r04_experiments/octants_in_extension_kernels.log), while the samples-only
 // kernel, which carries nothing, gains like the primary kernel (c4 at 16 spp: 8.27 against 8.50 ms).
 // VIEW: `view_off` = byte offset of the frame's view records from p.records (see trace_loop).
+// UNIFORM_ORG: every lane's ray starts at the same point (primary rays; the hand-written loop takes the origin as scalars).
 template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true, bool ANYHIT = false,
-          bool VIEW = false>
+          bool VIEW = false, bool UNIFORM_ORG = !EX>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
                                                int* pops = nullptr, uint32_t view_off = 0)
@@ -994,7 +1010,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         const int first = __builtin_amdgcn_readfirstlane(mine);
         if ((p.mesh_flags[in.mesh_index] & 1) == 0 && __ballot(!usable || mine != first) == 0ull) oct = first;
     }
-    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && !EX && !(POPS && COUNT) && !ANYHIT && !STK::kSpill) {
+    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && UNIFORM_ORG && (!EX || POPS) && !(POPS && COUNT) && !ANYHIT && !STK::kSpill) {
         // the hand-written loop (trace_loop_asm) for what it covers; everything else takes the C++ loops below
         if (oct >= 0 && in.exact_uv == 0 && in.identity_inv != 0) {
             stack.sp = 0;
@@ -1003,8 +1019,13 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             int wave_iters = 0;
             static_assert(STK::kStride == 64 || STK::kStride == 256, "the stack column's row pitch as a shift");
             int no_pops = 0;
-#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW, POPS>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta, \
-                                                                                          POPS ? *pops : no_pops)
+            // EX (the bounce kernel's primary ray keeps the hit's world location): the loop hands back the accepted candidate's point in
+            // mesh space; whether it accepted anything shows in the instance field, which it overwrites
+            V3 point = v3(0.0f, 0.0f, 0.0f);
+            const int32_t instance_before = hit.instance;
+            if constexpr (EX) hit.instance = -7;
+#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW, POPS, EX>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta, \
+                                                                                              POPS ? *pops : no_pops, point)
             switch (oct) {
             case 0: RT_TRACE_ASM(0); break;
             case 1: RT_TRACE_ASM(1); break;
@@ -1018,10 +1039,19 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
 #undef RT_TRACE_ASM
             stack.sp = sp;
             if constexpr (COUNT) *iters += wave_iters;          // (the wave's iterations = those of its longest lane, which is what the tile cost is)
+            if constexpr (EX) {
+                if (hit.instance == -7) hit.instance = instance_before;
+                else {                                          // raycast.cu:98-104, as triangle_test<.., EX> does it for every candidate
+                    V3 loc = v3(point.x * in.scale[0], point.y * in.scale[1], point.z * in.scale[2]);
+                    hit.loc = apply_quat(in.q_inv_pose, v3(loc.x - in.inv_pose_xyz[0], loc.y - in.inv_pose_xyz[1], loc.z - in.inv_pose_xyz[2]));
+                }
+            }
             return;
         }
     }
-#define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O, ANYHIT, VIEW>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops, vdelta)
+    // (the C++ loop reads view records for the primary kernels' rays only; an extension ray that does not qualify for the hand-written
+    // loop reads the records themselves)
+#define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O, ANYHIT, (VIEW && !EX)>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops, vdelta)
     switch (oct) {                                              // (wave-uniform: a scalar branch)
     case 0: RT_TRACE_LOOP(0); break;
     case 1: RT_TRACE_LOOP(1); break;
@@ -1241,7 +1271,8 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
 // registers it does not have, the second loop costs more in spills than the branches it saves: c3 +8 %
 // (profiles/r05_experiments/ex_one_wave_workgroups.log).
 // VIEW (the samples-only kernel's primary rays: they share the frame's origin): the cast reads view records, see trace_loop.
-template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false, class STK = Stack, bool OPTIMISTIC = false, bool VIEW = false>
+// PRIMARY: the ray starts at the camera in every lane (trace_instance's UNIFORM_ORG).
+template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false, class STK = Stack, bool OPTIMISTIC = false, bool VIEW = false, bool PRIMARY = false>
 __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, STK& stack, int& pops)
 {
     static_assert(!VIEW || OPTIMISTIC, "view records are read by the LDS-only loops");
@@ -1258,8 +1289,8 @@ __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir
         int outgrown = 0;
         for (int i = 0; i < p.num_instances; i++) {
             if constexpr (ANYHIT) { if (hit.min < FLT_MAX) continue; }
-            trace_instance<false, false, LOC, false, StackT<STK::kStride, false, true>, true, OCTANTS, ANYHIT, VIEW>(p, p.instances[i], i, org, dir, fast, hit, none, nullptr, &pops,
-                                                                                                                  p.view_base);
+            trace_instance<false, false, LOC, false, StackT<STK::kStride, false, true>, true, OCTANTS, ANYHIT, VIEW, PRIMARY>(p, p.instances[i], i, org, dir, fast, hit, none, nullptr,
+                                                                                                                           &pops, p.view_base);
             outgrown |= fast.sp;
         }
         if (outgrown == 0) return hit;
@@ -1379,7 +1410,7 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     V3 dir = camera_direction(f, px, py);
     V3 weight = v3(1.0f, 1.0f, 1.0f);
     if constexpr (SIMPLE) {                                     // the loop below for bounces = 0, lighting = 0, written out
-        const Hit hit = cast_ray_ex<false, true, false, ExStack, true, VIEW>(p, org, dir, stack, pops);
+        const Hit hit = cast_ray_ex<false, true, false, ExStack, true, VIEW, true>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) sample = sample + weight * v3(1.0f, 0.8f, 0.6f);
         else {
             const V3 base = base_colour(p, hit);
@@ -1392,8 +1423,10 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     } else
     {
     // one depth of the path: cast, shade, reflect; false = the path has ended
-    auto step = [&](const int depth) __attribute__((always_inline)) -> bool {
-        Hit hit = cast_ray_ex<true, false, false, ExStack>(p, org, dir, stack, pops);
+    // (`primary` = std::true_type for the camera ray, which takes the hand-written loop and the frame's view records: RT_EX_PRIMARY_ASM)
+    auto step = [&](auto primary, const int depth) __attribute__((always_inline)) -> bool {
+        constexpr bool kPrimary = RT_EX_PRIMARY_ASM && decltype(primary)::value;
+        Hit hit = cast_ray_ex<true, kPrimary, false, ExStack, kPrimary, kPrimary && VIEW, kPrimary>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); return false; }
         float illum = 1.0f;
 #if RT_EX_RECOMPUTE
@@ -1451,10 +1484,10 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     };
 #if RT_EX_PEEL
     // the primary ray's depth written out: weight = 1 and sample = 0 are constants across its cast, not registers to keep
-    if (step(0))
-        for (int depth = 1; depth <= p.bounces; depth++) if (!step(depth)) break;
+    if (step(std::true_type{}, 0))
+        for (int depth = 1; depth <= p.bounces; depth++) if (!step(std::false_type{}, depth)) break;
 #else
-    for (int depth = 0; depth <= p.bounces; depth++) if (!step(depth)) break;
+    for (int depth = 0; depth <= p.bounces; depth++) if (!step(std::false_type{}, depth)) break;
 #endif
     }
     }
@@ -2972,7 +3005,7 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
         // (four LDS rows per lane hold a wave's samples for the in-wave sum, whatever the depth of the stack)
         const size_t lds = (size_t)std::max(lds_rows(p.stack_depth) + 1, 4) * kExBlock * sizeof(int);       // (+ the optimistic stack's spare row)
         // the samples-only kernel's rays all start at the camera: one view of the tree serves every sample of the frame
-        const int view_slot = simple ? view_prepare(s, p, stream, p.spp) : -1;
+        const int view_slot = (simple || RT_EX_PRIMARY_ASM) ? view_prepare(s, p, stream, p.spp) : -1;
         struct ViewDone {
             RtScene* s; int slot; hipStream_t stream;
             ~ViewDone() { view_done(s, slot, stream); }
@@ -2992,6 +3025,7 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
             const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * 4));         // four one-wave workgroups per tile
             if (simple && view_slot >= 0) hipLaunchKernelGGL((render_ex_kernel<true, true, true>), grid, dim3(kExBlock), lds, stream, p);
             else if (simple) hipLaunchKernelGGL((render_ex_kernel<true, true>), grid, dim3(kExBlock), lds, stream, p);
+            else if (view_slot >= 0) hipLaunchKernelGGL((render_ex_kernel<false, true, true>), grid, dim3(kExBlock), lds, stream, p);
             else hipLaunchKernelGGL((render_ex_kernel<false, true>), grid, dim3(kExBlock), lds, stream, p);
             RT_HIP(hipGetLastError());
         }
