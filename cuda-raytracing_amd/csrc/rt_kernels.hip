@@ -1423,10 +1423,13 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     } else
     {
     // one depth of the path: cast, shade, reflect; false = the path has ended
-    // (`primary` = std::true_type for the camera ray, which takes the hand-written loop and the frame's view records: RT_EX_PRIMARY_ASM)
+    // (`primary` = std::true_type for the camera ray.  In the VIEW form of this kernel -- launched when the frame qualifies for view
+    // records, i.e. when the tree is small beside the frame -- it takes the hand-written loop and the frame's view: c3 / c5 -4.5 %.
+    // The other form keeps the compiler's loop for it: without a view the camera ray's gain is smaller than what 18 more spilled
+    // registers cost the bounce casts -- c6 with mirror walls, whose 4 M-node tree gets no view, lost 9 % with it.)
     auto step = [&](auto primary, const int depth) __attribute__((always_inline)) -> bool {
-        constexpr bool kPrimary = RT_EX_PRIMARY_ASM && decltype(primary)::value;
-        Hit hit = cast_ray_ex<true, kPrimary, false, ExStack, kPrimary, kPrimary && VIEW, kPrimary>(p, org, dir, stack, pops);
+        constexpr bool kPrimary = RT_EX_PRIMARY_ASM && VIEW && decltype(primary)::value;
+        Hit hit = cast_ray_ex<true, kPrimary, false, ExStack, kPrimary, kPrimary, kPrimary>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); return false; }
         float illum = 1.0f;
 #if RT_EX_RECOMPUTE
