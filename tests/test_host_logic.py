@@ -58,6 +58,7 @@ def test_argument_validation_without_gpu(rt):
     cap = C.c_int32(7)
     assert h.rt_scene_mesh_capacity(None, 0, C.byref(cap)) == -1 and cap.value == 7    # (no scene: refused, the output untouched)
     assert h.rt_scene_rebuild_mesh_device(None, 0, None, None, None, 0, None) == -1
+    assert h.rt_scene_view_stats(None, None, None, None, None) == -1
 
 
 def test_comm_argument_validation_without_gpu(rt):
