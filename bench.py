@@ -265,28 +265,50 @@ def scene_path(workload):
             log("bench.py: writing the c6 scene (%d triangles) to %s" % (scenes.C6["n_tris"], p))
             scenes.write_atrium_obj(p, **scenes.C6["atrium"])
         return p
+    if workload == "demo":                                              # (area, board as the demo places it, board with the translation baked in)
+        ps = tuple(os.path.join(d, n) for n in ("demo_area.obj", "demo_board.obj", "demo_board_baked.obj"))
+        if not all(os.path.exists(q) for q in ps):
+            scenes.write_demo_objs(ps[0], ps[1])
+            scenes.write_demo_objs(ps[0], ps[2], offset=scenes.DEMO["board_pose"][:3])
+        return ps
     p = os.path.join(d, "blob70k.obj")
     if not os.path.exists(p):
         scenes.write_blob_obj(p, *scenes.blob_dims_for(scenes.C2["n_tris"]))
     return p
 
 
-def oracle_scene(obj, wl):
+def scene_parts(workload, wl, obj, baked=False):
+    """The scene of a workload as lists both sides build from: materials [(albedo, texture or None, dict)], mesh OBJ paths,
+    instances [(mesh, material, pose, scale)].  demo = the reference's own scene shape (kernel.cu:166-240): two OBJ meshes, two
+    textured materials, the second instance translated; baked = its twin with the translation folded into the vertices."""
+    ident = (0.0,) * 6
+    if workload == "demo":
+        area_tex, board_tex = scenes.demo_textures()
+        return ([(wl["albedo"], area_tex, {}), (wl["albedo"], board_tex, {})], [obj[0], obj[2] if baked else obj[1]],
+                [(0, 0, ident, (1, 1, 1)), (1, 1, ident if baked else wl["board_pose"], (1, 1, 1))])
+    return ([(wl["albedo"], None, dict(roughness=wl.get("roughness", 0.0), metallic=wl.get("metallic", 0.0)))], [obj], [(0, 0, ident, (1, 1, 1))])
+
+
+def oracle_scene(obj, wl, workload="c2", baked=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     orc.build_oracle()
     o = orc.oracle()
     s = orc.OracleScene(o)
-    s.add_material(wl["albedo"], roughness=wl.get("roughness", 0.0), metallic=wl.get("metallic", 0.0))
-    s.add_mesh(o.obj_load(obj))
-    s.add_instance(0, 0)
+    mats, objs, insts = scene_parts(workload, wl, obj, baked)
+    for albedo, tex, extra in mats:
+        s.add_material(albedo, tex, **extra)
+    for path in objs:
+        s.add_mesh(o.obj_load(path))
+    for mesh, mat, pose, scale in insts:
+        s.add_instance(mesh, mat, pose, scale)
     return s
 
 
-def cpu_baseline_stream(obj, wl, W, H, K, D, pose, gpu_stats):
+def cpu_baseline_stream(obj, wl, W, H, K, D, pose, gpu_stats, workload="c2", baked=False):
     """The oracle (oracle/rt_oracle.c, kind "port") timed on this host on the same frame: all cores (row bands, about
     10 s of work) and one core (one full frame).  Also cross-checks the debug kernel's visit counters."""
-    s = oracle_scene(obj, wl)
+    s = oracle_scene(obj, wl, workload, baked)
     cores = min(os.cpu_count() or 1, 32)
     reps, tn, full = 0, 0.0, None
     while tn < 10.0 and reps < 20:
@@ -455,7 +477,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="frames to time (default: 960 for the 1-spp stream, 20 for spp / bounce workloads)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed frames before (default 64 / 3)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "c6"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "c6", "demo"])
+    ap.add_argument("--baked", action="store_true", help="demo: the twin scene with the board's translation folded into its vertices (an identity instance)")
     ap.add_argument("--camera", default="mid", choices=sorted(scenes.C2_CAMERAS))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -482,6 +505,9 @@ def main():
     ap.add_argument("--rccl-max-channels", type=int, default=0,
                     help="N > 1: NCCL_MAX_NCHANNELS for the ranks (0 = RCCL's own choice): bounds the CUs RCCL's kernels take from render_kernel, "
                          "for an A/B of the contention between the exchange of group i and the render of group i + 1")
+    ap.add_argument("--subgroups", type=int, default=0,
+                    help="N > 1 stream workloads whose timed region is ONE group (--steps <= 32, the driver's --steps 20): render it as a pipeline of "
+                         "up to this many sub-groups, the exchange of sub-group k beside the render of k + 1 (0 = auto: 4; 1 = one launch, as rounds 1-5)")
     ap.add_argument("--one-stream", action="store_true", help="N > 1: launch every group on the same compute stream")
     ap.add_argument("--two-streams", action="store_true", help="one GPU: alternate consecutive groups between two streams")
     ap.add_argument("--predict-scaling", default=None, const="2,4,8", nargs="?", metavar="N[,N...]",
@@ -565,8 +591,9 @@ def main():
         STRIPE_ROWS = 4
     K, D = scenes.scaled_K(W), scenes.D_REF
     atrium = args.workload in ("c4", "c6")
-    base_pose = wl["cam_pose"] if atrium else scenes.C2_CAMERAS[args.camera]
-    cam_name = "inside" if atrium else args.camera
+    demo = args.workload == "demo"
+    base_pose = wl["cam_pose"] if (atrium or demo) else scenes.C2_CAMERAS[args.camera]
+    cam_name = "inside" if atrium else (("baked" if args.baked else "posed") if demo else args.camera)
     key = "%s_%s_%dx%d_%d_%d_%d" % (args.workload, cam_name, W, H, spp, bounces, lighting)
     if args.metallic >= 0 or args.roughness >= 0:
         key += "_m%g_r%g" % (wl.get("metallic", 0.0), wl.get("roughness", 0.0))
@@ -576,12 +603,18 @@ def main():
         obj = scene_path(args.workload)
 
     # ---- scene: the reference's call sequence (kernel.cu:166-243) through the host C++ API ----
-    mesh = rt.Mesh.load_obj(obj)
+    mats, objs, insts = scene_parts(args.workload, wl, obj, args.baked)
+    meshes = [rt.Mesh.load_obj(q) for q in objs]
     scene = rt.Scene()
-    scene.add_material(wl["albedo"], roughness=wl.get("roughness", 0.0), metallic=wl.get("metallic", 0.0))
-    scene.add_mesh(mesh)
-    scene.add_mesh_instance(0, 0)
+    for albedo, tex, extra in mats:
+        scene.add_material(albedo, texture_bgr=tex, **extra)
+    for m in meshes:
+        scene.add_mesh(m)
+    for mi, ma, ipose, iscale in insts:
+        scene.add_mesh_instance(mi, ma, ipose, iscale)
     scene.upload_to_device()
+    mesh = meshes[0]
+    scene_tris, scene_nodes = sum(m.num_triangles for m in meshes), sum(m.num_nodes for m in meshes)
     stream = torch.cuda.current_stream().cuda_stream
 
     def make_camera(s=None):
@@ -703,81 +736,90 @@ def run_stream(args, env):
     f_max = args.frames_per_launch if args.frames_per_launch > 0 else 32
     F = max(1, min(f_max, 32, args.steps if args.steps > 0 else 1))
     groups = [F] * (args.steps // F) + ([args.steps % F] if args.steps % F else [])
+    # units = the pipeline steps of the timed region, (first frame within its group, frames) each.  Normally a unit is a group.  When
+    # the region is ONE group on N ranks (the driver's `--steps 20`: 2.5 frames' worth of work per rank at N = 8, then an exchange
+    # with nothing to hide behind), the group is rendered as a pipeline of sub-groups: the all-to-all and un-stripe pass of
+    # sub-group k run on the comm stream while sub-group k + 1 renders on the other compute stream (tiling.sub_groups).
+    subgrouped = dist_on and rotate and len(groups) == 1 and args.subgroups != 1
+    units = tiling.sub_groups(groups[0], world, args.subgroups or 4) if subgrouped else [(0, c) for c in groups]
+    subgrouped = subgrouped and len(units) > 1
     # Warm-up: whole groups, at least the requested W steps -- and at least MIN_WARM_FRAMES frames (about 45 ms of GPU work):
     # a step here is 0.13 ms, and a GPU that has just been idle needs tens of milliseconds of load to reach its steady
     # clock (measured: the same 20 timed steps take 0.153 ms each after 20 warm-up frames, 0.143 after 80, 0.135 after 320
     # or 1280).  Both numbers are in the line ("warmup" = requested, "warmup_frames_done").
     warm_frames = args.warmup if rehearsal else max(args.warmup, MIN_WARM_FRAMES * world)    # (a rank of N renders 1/N of every frame)
-    warm_groups = [F] * ((warm_frames + F - 1) // F)
+    warm_units = (units if subgrouped else [(0, F)]) * ((warm_frames + F - 1) // F)    # (the launch shapes of the timed region)
     poses = camera_path(base_pose, F)                            # frame f of every group uses poses[f]
-    counts = sorted(set(groups + [F]))
+    shapes = sorted(set(units + [(0, F)] + ([] if subgrouped else [(0, c) for c in groups])))
 
     if not dist_on:
         frames_b = [torch.empty((F, H, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]   # groups alternate between two frame sets
         calls = {(b, c): cams[b].prepared_batch(scene, poses[:c], [frames_b[b][f].data_ptr() for f in range(c)], pitch)
-                 for b in range(2) for c in counts}
+                 for b in range(2) for _, c in shapes}
 
-        def step_group(i, count):
+        def step_group(i, unit):
             if two:
                 with torch.cuda.stream(cstreams[i & 1]):
-                    calls[(i & 1, count)]()
+                    calls[(i & 1, unit[1])]()
             else:
-                calls[(i & 1, count)]()
+                calls[(i & 1, unit[1])]()
         timing_call = cam.prepared_batch(scene, poses, [frames_b[0][f].data_ptr() for f in range(F)], pitch)
         pipe = None
-        my_frames = lambda c: list(range(c))                     # frame indices (within the group) this rank holds afterwards
+        my_frames = lambda unit: list(range(unit[0], unit[0] + unit[1]))      # frame indices (within the group) this rank holds afterwards
         frames_of = lambda b: frames_b[b]
     else:
         max_rows = g["max_rows"]
-        slots = tiling.rotating_plan(F, world)[0] if rotate else F
+        slots = max(tiling.rotating_plan(c, world)[0] for _, c in shapes) if rotate else F
         on_dev = exchange.on_device
         mk = lambda shape, zero=False: (torch.zeros if zero else torch.empty)(shape, dtype=torch.uint8, device=dev)
         local_dev = [mk((slots * max_rows, pitch), True) for _ in range(2)]
         if rotate:
-            recv_shape = (world * tiling.rotating_plan(F, world)[1][rank] * max_rows, pitch)
+            recv_shape = (world * max(tiling.rotating_plan(c, world)[1][rank] for _, c in shapes) * max_rows, pitch)
             gathered_dev = [mk(recv_shape) for _ in range(2)]
         else:
             gathered_dev = [mk((world, F * max_rows, pitch)) if rank == 0 else None for _ in range(2)]
         frames_b = [mk((F, H, pitch)) for _ in range(2)]
         local = local_dev if on_dev else [torch.zeros_like(t, device="cpu") for t in local_dev]
         gathered = gathered_dev if on_dev else [torch.empty_like(t, device="cpu") if t is not None else None for t in gathered_dev]
-        local_ptrs = [tiling.batch_local_ptrs(local_dev[b].data_ptr(), F, max_rows, pitch) for b in range(2)]
+        local_ptrs = [tiling.batch_local_ptrs(local_dev[b].data_ptr(), max(slots, F if not rotate else 0), max_rows, pitch) for b in range(2)]
         # the stripe owner rotates over the frames of a group: frame f of the group is rendered as owner (rank + f) % world
+        # (a sub-group that starts at frame `first` of its group goes on where the one before stopped: first_frame = first)
         owner_rotation = not args.no_owner_rotation
-        stripes = (STRIPE_ROWS, rank, world, 0) if owner_rotation else (STRIPE_ROWS, rank, world)
-        calls = {(b, c): cams[b].prepared_batch(scene, poses[:c], local_ptrs[b][:c], pitch, stripes=stripes)
-                 for b in range(2) for c in counts}
-        timing_call = cam.prepared_batch(scene, poses, local_ptrs[0][:F], pitch, stripes=stripes)
-        group_count = [F, F]                                     # frames in the group that currently occupies buffer set b
+        stripes_of = lambda first: (STRIPE_ROWS, rank, world, first) if owner_rotation else (STRIPE_ROWS, rank, world)
+        calls = {(b, first, c): cams[b].prepared_batch(scene, poses[first:first + c], local_ptrs[b][:c], pitch, stripes=stripes_of(first))
+                 for b in range(2) for first, c in shapes}
+        timing_call = cam.prepared_batch(scene, poses[:units[0][1]], local_ptrs[0][:units[0][1]], pitch, stripes=stripes_of(0))
+        group_unit = [units[0], units[0]]                        # the (first frame, frames) that currently occupies buffer set b
 
-        def my_frames(c):                                        # frame indices (within a group of c) this rank assembles
+        def my_frames(unit):                                     # frame indices (within the group) this rank assembles of a unit
+            first, c = unit
             if rotate:
                 _, cnt, off, real = tiling.rotating_plan(c, world)
-                return [off[rank] + k for k in range(real[rank])]
-            return list(range(c)) if rank == 0 else []
+                return [first + off[rank] + k for k in range(real[rank])]
+            return list(range(first, first + c)) if rank == 0 else []
 
         def render_fn(b):
-            calls[(b, group_count[b])]()
+            calls[(b,) + tuple(group_unit[b])]()
             if not on_dev:
                 local[b].copy_(local_dev[b])                    # (synchronous: the rehearsal stages through the host)
 
         def exchange_fn(b):
             if rotate:
-                exchange.rotating(local[b], gathered[b], group_count[b], max_rows)
+                exchange.rotating(local[b], gathered[b], group_unit[b][1], max_rows)
             else:
                 exchange.to_root(local[b], gathered[b] if rank == 0 else None, 0)
 
         def unstripe_fn(b):
-            n = len(my_frames(group_count[b]))
+            n = len(my_frames(group_unit[b]))
             if n == 0:
                 return
             if not on_dev:
                 gathered_dev[b].copy_(gathered[b])
             # rank r's block holds its stripes of my frames (rotate) or of all F frame slots (root0)
-            plan = tiling.rotating_plan(group_count[b], world) if rotate else None
+            plan = tiling.rotating_plan(group_unit[b][1], world) if rotate else None
             rank_stride = (plan[1][rank] if rotate else F) * max_rows * pitch
             if owner_rotation:                                  # my first frame's index in the group: which owner each source rank played
-                first = plan[2][rank] if rotate else 0
+                first = group_unit[b][0] + (plan[2][rank] if rotate else 0)
                 rt.check(hlib.rt_unstripe_batch_rotating(gathered_dev[b].data_ptr(), pitch, rank_stride, max_rows * pitch, frames_b[b].data_ptr(), pitch,
                                                          H * pitch, n, W, H, STRIPE_ROWS, world, first, torch.cuda.current_stream().cuda_stream))
             else:
@@ -787,18 +829,18 @@ def run_stream(args, env):
         pipe = tiling.StripePipeline(render_fn, exchange_fn, unstripe_fn, assembles=rotate or rank == 0,
                                      compute_streams=cstreams, comm_stream=torch.cuda.Stream() if on_dev else None)
 
-        def step_group(i, count):
-            group_count[i & 1] = count                           # (read by the callbacks while they issue group i, i.e. inside step())
+        def step_group(i, unit):
+            group_unit[i & 1] = unit                             # (read by the callbacks while they issue unit i, i.e. inside step())
             pipe.step(i)
         frames_of = lambda b: frames_b[b]
 
     sync = g["sync"]
-    for i, c in enumerate(warm_groups):
-        step_group(i, c)
+    for i, u in enumerate(warm_units):
+        step_group(i, u)
     sync()
     if pipe is not None:
-        # per group: wait for buffer / render / exchange / un-stripe (events created here, only recorded inside the timed region)
-        pipe.stage_timing(True, expect_groups=len(groups) * (REPEATS_SHORT if len(groups) == 1 else 1))
+        # per unit: wait for buffer / render / exchange / un-stripe (events created here, only recorded inside the timed region)
+        pipe.stage_timing(True, expect_groups=len(units) * (REPEATS_SHORT if len(groups) == 1 else 1))
     g["phase"]("timed loop", 4.0)
     # The timed region = the K steps between two barrier + synchronise pairs.  When K fits ONE launch (the driver's
     # --steps 20) that region is a single 2.7 ms sample: it is then measured REPEATS_SHORT times back to back and the line
@@ -807,8 +849,8 @@ def run_stream(args, env):
     dts, t_issue = [], 0.0
     for rep in range(repeats):
         t0 = time.perf_counter()
-        for i, c in enumerate(groups):
-            step_group(i + rep * len(groups), c)
+        for i, u in enumerate(units):
+            step_group(i + rep * len(units), u)
         t_issue = time.perf_counter() - t0                       # host time to issue all groups (must stay below the GPU's)
         if pipe is not None:
             pipe.drain()
@@ -823,7 +865,7 @@ def run_stream(args, env):
     # where a rank's time went, per group of F frames: every rank reports, rank 0 prints all of them
     per_rank = None
     if pipe is not None:
-        mine_t = dict(pipe.stage_times() or {}, rank=rank)
+        mine_t = dict(pipe.stage_times(groups_per_region=len(units)) or {}, rank=rank)
         pipe.stage_timing(False)
         box = [None] * world
         if world > 1:
@@ -842,15 +884,16 @@ def run_stream(args, env):
         for _ in range(n):
             timing_call()
         timer.stop(stream)
-        kernel_ms = timer.elapsed_ms() / n                      # one launch = F frames (this rank's stripes of them)
+        kernel_ms = timer.elapsed_ms() / n                      # one launch = FL frames (this rank's stripes of them)
         if not dist_on and not args.no_latency:
             latency = measure_latency(g, poses, kernel_ms / F)
+    FL = units[0][1] if dist_on else F                           # frames of the launch kernel_ms times
     if dist_on:
         dist.barrier()
 
     # ---- every rank checks frames it assembled in the last group against the debug kernel at the same pose ----
-    last_b, last_c = (repeats * len(groups) - 1) & 1, (groups[-1] if groups else F)
-    mine = my_frames(last_c)
+    last_b = (repeats * len(units) - 1) & 1
+    mine = my_frames(units[-1])
     held = frames_of(last_b).cpu().numpy().reshape(F, H, W, 3)
     frame_ok, ids_ok, dbg0 = True, True, None
     for k, f in enumerate(mine):
@@ -859,7 +902,7 @@ def run_stream(args, env):
         cam.set_pose(poses[f])
         cam.set_stream(stream)
         dbg = rt.render_debug(scene, cam)
-        slot = k if (dist_on and rotate) else f                  # rotating exchange: my k-th frame sits in slot k of my frame set
+        slot = k if (dist_on and rotate) else f - (units[-1][0] if dist_on else 0)    # rotating exchange: my k-th frame sits in slot k of my frame set
         frame_ok = frame_ok and bool(np.array_equal(held[slot], dbg["img"]))
         ids = rt.render_ids(scene, cam)                          # the production kernel's own hit ids
         ids_ok = ids_ok and bool(np.array_equal(ids["hit_tri"], dbg["hit_tri"]) and np.array_equal(ids["hit_inst"], dbg["hit_inst"]))
@@ -876,16 +919,19 @@ def run_stream(args, env):
           "inside": int(dbg["inside"].sum()), "hits": int((dbg["hit_tri"] >= 0).sum())}
     alg = algorithmic_bytes(st)
     mesh, wl = g["mesh"], g["wl"]
-    name = {"c2": "C2 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ", "c6": "C6 atrium OBJ at 16 x the triangles of C4 (records exceed the Infinity Cache)"}.get(args.workload, args.workload)
+    name = {"c2": "C2 bunny-class blob OBJ", "c4": "C4 Sponza-class atrium OBJ", "c6": "C6 atrium OBJ at 16 x the triangles of C4 (records exceed the Infinity Cache)",
+            "demo": "the reference demo's scene shape (kernel.cu:166-240): two OBJ meshes, two textured materials, the second instance %s"
+                    % ("with its translation baked into the vertices (identity instance: the comparison twin)" if args.baked else "translated by (-0.6, 1.48, 0.73)")}.get(args.workload, args.workload)
     config = {"workload": "%s (%d tris, %d BVH nodes), %dx%d, 1 primary ray/pixel, camera '%s' %s; every frame of a group has its own pose "
-                          "(a 4 mm loop around that camera)" % (name, mesh.num_triangles, mesh.num_nodes, W, H, g["cam_name"], str(tuple(base_pose[:3]))),
+                          "(a 4 mm loop around that camera)" % (name, g["scene_tris"], g["scene_nodes"], W, H, g["cam_name"], str(tuple(base_pose[:3]))),
               "key": g["key"] + ("_f1" if F == 1 and not dist_on else ""), "width": W, "height": H, "spp": 1, "bounces": 0, "lighting": 0,
               "parallelism": "replicated scene, %d-row stripes round-robin over %d GPU(s)%s%s"
                              % (STRIPE_ROWS, world, (", the stripe owner rotating over the frames of a group" if dist_on and not args.no_owner_rotation else ""),
                                 (", one RCCL all-to-all per %d frames (the gather's root rotates: each rank assembles 1/N of the frames) through %s" % (F, "rt_all_to_all" if g["comm"] is not None else "torch.distributed") if rotate
                                                   else ", one RCCL gather to rank 0 per %d frames through %s" % (F, "rt_gather" if g["comm"] is not None else "torch.distributed")) if dist_on else ""),
-              "mesh_on_octant_loops": scene.mesh_flags(0) == 0,      # (false: an unordered or NaN child box keeps the mesh on the generic slab loop)
-              "frames_per_launch": F, "host_issue_ms_per_launch": round(t_issue / max(len(groups), 1) * 1e3, 3),
+              "mesh_on_octant_loops": all(scene.mesh_flags(k) == 0 for k in range(len(g["meshes"]))),      # (false: an unordered or NaN child box keeps a mesh on the generic slab loop)
+              "frames_per_launch": FL, "frames_per_group": F, "host_issue_ms_per_launch": round(t_issue / max(len(units), 1) * 1e3, 3),
+              "sub_groups": [list(u) for u in units] if subgrouped else None,
               "single_frame_launch_ms": None if latency is None else latency["f1_kernel_ms"], "latency": latency,
               "coverage": round(st["hits"] / st["rays"], 4),
               "per_ray": {k: round(st[k] / st["rays"], 3) for k in ("pops", "aabb", "tris", "inside")},
@@ -898,11 +944,21 @@ def run_stream(args, env):
     # pre-pass that writes them is part of kernel_ms)
     views = scene.view_stats()
     config["view_records"] = views
-    roof = roofline("render_kernel<false,false,%s,%s,%s>" % ("true" if single else "false", "true" if spill else "false",
+    if not dist_on:
+        # which traversal loop the waves of such a launch run (rt_scene_loop_stats: the same launch through an instrumented copy of the
+        # kernel, after the timings): the hand-written gfx950 loop should carry (nearly) every wave x instance cast
+        loops = scene.loop_stats(cam, poses[:F], [frames_of(0)[f].data_ptr() for f in range(F)], pitch, stream)
+        cam.set_pose(poses[0])
+        config["traversal_loops"] = loops
+        config["asm_loop_frac"] = loops["asm_loop_frac"]
+    # (third template argument: the heavy-first dispatch order -- single frames, and a rank's stripes of fewer than four frames' worth of tiles)
+    thin = dist_on and world > 1 and FL > 1 and os.environ.get("RT_TILE_ORDER_STRIPES", "1")[:1] != "0" and \
+        ((W + 7) // 8) * ((max(tiling.stripe_rows(H, STRIPE_ROWS, r, world) for r in range(world)) + 7) // 8) * FL < 4 * 32768
+    roof = roofline("render_kernel<false,false,%s,%s,%s>" % ("true" if single or thin else "false", "true" if spill else "false",
                                                                "true" if views["launches"] > views["fallbacks"] and F >= 4 else "false"),
-                    g["key"] + ("_f1" if single else ""), kernel_ms, F, 1.0 / world, alg)
+                    g["key"] + ("_f1" if single else ""), kernel_ms, FL, 1.0 / world, alg)
     # ms_per_step is the throughput figure of a batch (F frames per launch); what one frame takes on its own is spelled out next to it
-    extra = {"frames_per_launch": F,
+    extra = {"frames_per_launch": FL,
              "ms_per_frame_single_launch": None if latency is None else latency["f1_kernel_ms"],
              "ms_per_frame_reference_loop": None if latency is None else latency["reference_loop_2_renders_per_sync_wall_ms_per_frame"],
              "frame_matches_debug_kernel": frame_ok, "production_hit_ids_match_debug_kernel": ids_ok}
@@ -910,9 +966,9 @@ def run_stream(args, env):
     if per_rank is not None:
         extra.update(multi_rank_report(per_rank, g["comm"]))
     value = W * H * args.steps / dt / 1e6
-    out = base_line(args, g, value, dt, len(warm_groups) * F, config, roof, extra)
+    out = base_line(args, g, value, dt, sum(c for _, c in warm_units), config, roof, extra)
     if not dist_on and not args.no_cpu_baseline:
-        cb, ref_img = cpu_baseline_stream(g["obj"], wl, W, H, K, D, poses[0], st)
+        cb, ref_img = cpu_baseline_stream(g["obj"], wl, W, H, K, D, poses[0], st, args.workload, args.baked)
         cb["gpu_frame_matches_oracle"] = bool(np.array_equal(ref_img, dbg["img"]))
         out["cpu_baseline"] = cb
     return out
@@ -986,17 +1042,26 @@ def predict_scaling(args, g):
                                      % (args.workload, W, H, g["cam_name"], F),
                          "frames_per_group": F, "groups_timed": G,
                          "one_gpu_ms_per_group": {"one_stream": round(t1_one, 4), "two_alternating_streams": round(t1_two, 4)},
-                         "one_gpu_ms_driver_shape_20_frames": round(t1_20, 4), "per_n": [], "driver_shape_per_n": []}
+                         "one_gpu_ms_driver_shape_20_frames": round(t1_20, 4), "per_n": [], "driver_shape_per_n": [], "driver_shape_one_launch_per_n": []}
         del frames_b
         for N in Ns:
             max_rows = max(tiling.stripe_rows(H, STRIPE_ROWS, r, N) for r in range(N))
             local = [torch.zeros((F * max_rows, pitch), dtype=torch.uint8, device=dev) for _ in range(2)]
             ptrs = [tiling.batch_local_ptrs(local[b].data_ptr(), F, max_rows, pitch) for b in range(2)]
-            two, one, single, more = [], [], [], []
+            two, one, single, more, piped = [], [], [], [], []
             for r in range(N):
                 own = (STRIPE_ROWS, r, N) if args.no_owner_rotation else (STRIPE_ROWS, r, N, 0)
                 calls = [cams[b].prepared_batch(scene, poses, ptrs[b], pitch, stripes=own) for b in range(2)]
                 call20 = cams[0].prepared_batch(scene, poses[:K20], ptrs[0][:K20], pitch, stripes=own)
+                # ... and as the pipeline of sub-groups rank r of N issues for it (run_stream: tiling.sub_groups; alternating compute streams)
+                subs = tiling.sub_groups(K20, N, args.subgroups or 4) if args.subgroups != 1 else [(0, K20)]
+                sub_calls = [cams[j & 1].prepared_batch(scene, poses[first:first + c], ptrs[j & 1][:c], pitch,
+                                                        stripes=(STRIPE_ROWS, r, N) if args.no_owner_rotation else (STRIPE_ROWS, r, N, first))
+                             for j, (first, c) in enumerate(subs)]
+
+                def call20_sub(sub_calls=sub_calls):
+                    for c in sub_calls:
+                        c()
                 two.append(time_groups(lambda b: calls[b](), G, 2))
                 if os.environ.get("PREDICT_STREAMS"):            # experiment: more than two compute streams
                     ns = int(os.environ["PREDICT_STREAMS"])
@@ -1007,6 +1072,7 @@ def predict_scaling(args, g):
                     more.append(time_groups(lambda b: xcalls[b](), G, ns))
                 one.append(time_groups(lambda b: calls[0](), G, 1))
                 single.append(time_single(call20))
+                piped.append(time_single(call20_sub))
             # the one-GPU side of the ratio is what `bench.py --gpus 1` measures (one stream); a real N-rank run renders on two
             pn = scaling_prediction(t1_one, two)
             pn["render_ms_per_rank_one_stream"] = [round(v, 4) for v in one]
@@ -1014,7 +1080,12 @@ def predict_scaling(args, g):
             if more:
                 pn["experiment_%s_streams_ms_per_rank" % os.environ["PREDICT_STREAMS"]] = [round(v, 4) for v in more]
             out["stream"]["per_n"].append(pn)
-            out["stream"]["driver_shape_per_n"].append(scaling_prediction(t1_20, single))
+            # the driver's `--gpus N --steps 20`: one group of 20 frames per timed region.  `driver_shape_per_n` = as a rank renders it now
+            # (sub-groups on two streams, heavy-first order for thin stripes); `driver_shape_one_launch_per_n` = one launch (rounds 1-5)
+            dn = scaling_prediction(t1_20, piped)
+            dn["sub_groups"] = [list(u) for u in subs]
+            out["stream"]["driver_shape_per_n"].append(dn)
+            out["stream"]["driver_shape_one_launch_per_n"].append(scaling_prediction(t1_20, single))
             log("bench.py --predict-scaling: N=%d stream: %s" % (N, json.dumps(pn)))
             del local
         last = out["stream"]["per_n"][-1]

@@ -62,7 +62,7 @@ class RtSceneDesc(C.Structure):
 RT_HIP_SYMBOLS = [
     "rt_abi_version", "rt_build_info", "rt_device_count", "rt_set_device", "rt_malloc", "rt_malloc_pitch", "rt_free", "rt_memcpy_d2h",
     "rt_memcpy_h2d", "rt_memcpy2d_d2h", "rt_stream_synchronize", "rt_device_synchronize", "rt_error_string",
-    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_scene_mesh_flags", "rt_render", "rt_render_overlapped", "rt_render_overlapped_stats", "rt_scene_view_stats", "rt_render_batch",
+    "rt_bvh_build", "rt_scene_upload", "rt_scene_update_instance", "rt_scene_update_instance_async", "rt_scene_refit_mesh", "rt_scene_refit_mesh_device", "rt_scene_rebuild_mesh_device", "rt_scene_debug_read", "rt_scene_destroy", "rt_scene_info", "rt_scene_mesh_capacity", "rt_scene_mesh_flags", "rt_render", "rt_render_overlapped", "rt_render_overlapped_stats", "rt_scene_view_stats", "rt_scene_reserve_views", "rt_scene_memory", "rt_scene_loop_stats", "rt_render_batch",
     "rt_render_debug", "rt_render_ids", "rt_render_ex", "rt_render_ex_stripes", "rt_stripe_rows", "rt_render_stripes", "rt_render_stripes_batch", "rt_render_stripes_batch_rotating", "rt_unstripe", "rt_unstripe_batch", "rt_unstripe_batch_rotating",
     "rt_comm_available", "rt_comm_last_error", "rt_comm_last_error_any", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_init_all", "rt_comm_info", "rt_comm_destroy",
     "rt_group_start", "rt_group_end", "rt_gather", "rt_all_to_all", "rt_render_tiled", "rt_render_tiled_all", "rt_timer_create", "rt_timer_start", "rt_timer_stop",
@@ -164,6 +164,9 @@ def _declare(h, s):
     h.rt_render_overlapped.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t]
     h.rt_render_overlapped_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     h.rt_scene_view_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    h.rt_scene_reserve_views.argtypes = [_vp, C.c_int32]
+    h.rt_scene_memory.argtypes = [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _i, _i]
+    h.rt_scene_loop_stats.argtypes = [_vp, C.POINTER(RtCameraParams), C.POINTER(_vp), C.c_size_t, C.c_int32, _vp, C.POINTER(C.c_uint64)]
     h.rt_render_debug.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, C.POINTER(RtDebugPlanes), _vp, C.c_int]
     h.rt_render_ids.argtypes = [_vp, C.POINTER(RtCameraParams), _vp, C.c_size_t, _vp, _vp, _vp, C.c_int]
     h.rt_stripe_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i]
@@ -434,6 +437,34 @@ class Scene:
         a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
         check(libs()[0].rt_scene_view_stats(self.device_handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "rt_scene_view_stats")
         return dict(launches=a.value, fallbacks=b.value, grows=c.value, slot_frames=d.value)
+
+    def reserve_views(self, frames_per_launch):
+        """rt_scene_reserve_views: size the view pool for launches of up to that many frames (0: back to growing on demand)"""
+        check(libs()[0].rt_scene_reserve_views(self.device_handle, frames_per_launch), "rt_scene_reserve_views")
+
+    def memory(self):
+        """rt_scene_memory: dict(records_bytes=, view_pool_bytes=, device_bytes=, view_slots=, view_slot_frames=)"""
+        a, b, c, d, e = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int32(0), C.c_int32(0)
+        check(libs()[0].rt_scene_memory(self.device_handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)), "rt_scene_memory")
+        return dict(records_bytes=a.value, view_pool_bytes=b.value, device_bytes=c.value, view_slots=d.value, view_slot_frames=e.value)
+
+    LOOP_STATS = ("waves", "asm", "asm_posed", "cpp_octant", "cpp_generic", "deep", "retraced_lanes")     # RT_LOOP_* of include/rt_hip.h
+
+    def loop_stats(self, camera, poses, d_imgs, pitch, stream=None):
+        """rt_scene_loop_stats: renders the batch (poses[i] -> d_imgs[i]) through the instrumented copy of the production kernel and says
+        which traversal loop the waves ran: dict of the RT_LOOP_* counts plus asm_loop_frac = casts on the hand-written loop / all casts."""
+        n = len(poses)
+        cams = (RtCameraParams * n)()
+        for i, pose in enumerate(poses):
+            camera.set_pose(pose)
+            libs()[1].rth_camera_params(camera.h, C.addressof(cams[i]))
+        ptrs = (_vp * n)(*[int(x) if not isinstance(x, _vp) else x.value for x in d_imgs])
+        out = (C.c_uint64 * 8)()
+        check(libs()[0].rt_scene_loop_stats(self.device_handle, cams, ptrs, pitch, n, stream, out), "rt_scene_loop_stats")
+        d = {k: int(out[i]) for i, k in enumerate(self.LOOP_STATS)}
+        casts = d["asm"] + d["cpp_octant"] + d["cpp_generic"] + d["deep"]
+        d["asm_loop_frac"] = round(d["asm"] / casts, 5) if casts else None
+        return d
 
     def info(self):
         b = C.c_size_t(0)

@@ -1069,7 +1069,9 @@ struct RebuildResult {              // what the host needs to know afterwards: o
 extern "C" int rt_scene_rebuild_mesh_device(RtScene* s, int32_t mesh_index, const float* d_vertices, const float* d_normals, const float* d_uvs,
                                             int32_t n, void* stream_)
 {
-    if (!s || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size() || n < 0 || (n > 0 && (!d_vertices || !d_normals))) return RT_E_INVALID;
+    if (!s) return RT_E_INVALID;
+    std::lock_guard<std::recursive_mutex> scene_call_guard(s->call_mu);      // (rt_scene_internal.h: the scene's arrays do not move under this call)
+    if (mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size() || n < 0 || (n > 0 && (!d_vertices || !d_normals))) return RT_E_INVALID;
     RtScene::MeshRefit& rf = s->mesh_refit[(size_t)mesh_index];
     if (n > rf.slot_cap || (n > 0 && n - 1 > rf.int_cap)) return RT_E_INVALID;     // more triangles than the mesh was uploaded with
     hipStream_t stream = (hipStream_t)stream_;

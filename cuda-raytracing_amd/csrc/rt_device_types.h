@@ -50,7 +50,8 @@ struct DevInstance {            // 144 B
     int32_t mesh_index;
     int32_t exact_uv;           // mesh has uv values that could make uv.x == FLT_MAX (raycast.cu:96)
     int32_t identity_inv;       // scale == 1, inv_pose == 0, q_inv_pose == (1,0,0,0): mesh -> world is the identity
-    int32_t pad_[3];
+    int32_t unit_inv;           // scale == 1, q_inv_pose == (1,0,0,0): mesh -> world is a translation (or the identity)
+    int32_t pad_[2];
 };
 
 struct DevMaterial {            // Material.hpp:6-16
@@ -113,6 +114,11 @@ struct RenderParams {
     int32_t px_n, px_count;     // sample slots per pixel in a wave (4..64, a power of two), samples of this launch (<= px_n)
     int32_t px_pw, px_ph;       // pixels of a wave; a workgroup is 2 x 2 waves
     int32_t px_first, px_last;  // first / last chunk of the frame's samples (running sums wait in ex_acc in between)
+    // render_ex_kernel<.., PHASE 1 / 2>: the camera ray's hit per lane, two planes of ex_rec_lanes float4 -- (slot, instance, u, v) and
+    // (location, pops) -- for the workgroups wg_base .. wg_base + gridDim.x of the frame's grid
+    float4* ex_rec;
+    uint32_t ex_rec_lanes;
+    int32_t wg_base;
     // wavefront form of the extension renderer (ex_wave_kernel): path queues between casts, see rt_kernels.hip
     float4* exq_s;              // shadow-ray items: kExPlanesS planes of exq_nseg * 64 float4
     float4* exq_a[3];           // bounce-ray items: kExPlanesA planes each; three arrays in rotation (exq_in1 / in2 / out)
@@ -130,6 +136,7 @@ struct RenderParams {
     // view_base + f * view_frame_stride + view_inst_off[i] + e * 64 from `records` (32-bit arithmetic; RtScene::ViewPool)
     uint32_t view_base, view_frame_stride;
     int32_t view_inst_off[kMaxViewInstances];
+    unsigned long long* loop_stats;     // render_kernel<.., STATS> (rt_scene_loop_stats): RT_LOOP_WORDS counters, null in every other launch
     // parity planes (tight [height][width], frame coordinates), any may be null
     int32_t *hit_instance, *hit_triangle, *node_pops, *aabb_tests, *tri_tests, *inside_hits;
 };

@@ -9,6 +9,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (mandatory: SURVEY.md H3) -fno-slp-vectorize (see _build.py).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -587,8 +588,8 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 // iteration needs two exec regions (the lanes at an interior node, the lanes at a triangle) with the push and the accepted
 // hit as sub-regions, scalar branches for what is wave-uniform, and no flags.
 // Scope: production primary rays (no counters), the LDS-only stack (plain or optimistic, see StackT), an instance without
-// exact-uv mode whose mesh -> world transform is the identity, a wave with a known sign octant (trace_instance's conditions
-// for slab_oct).  Same arithmetic, instruction for instruction, as the C++ loop compiles to: the operations, their order and
+// exact-uv mode (any pose: round 6 -- the accepted candidate's way back to world space is part of the loop, see the candidate
+// block), a wave with a known sign octant (trace_instance's conditions for slab_oct).  Same arithmetic, instruction for instruction, as the C++ loop compiles to: the operations, their order and
 // the IEEE division / square-root expansions are taken from the compiler's own output, so every bit of every result is
 // the same (the parity tests compare this loop's frames and hit ids with the instrumented kernel's and the oracle's).
 //
@@ -829,10 +830,20 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_and_b64 s[40:41], s[40:41], vcc\n\t"             /* a candidate inside its triangle */ \
     "s_and_saveexec_b64 s[44:45], s[40:41]\n\t" \
     "s_cbranch_execz .Lrt_no_candidate%=\n\t" \
-    /* its distance from the ray's world origin (mesh -> world is the identity here), raycast.cu:98-104 */ \
-    "v_subrev_f32_e32 v21, %[orgx], v18\n\t" \
-    "v_subrev_f32_e32 v22, %[orgy], v19\n\t" \
-    "v_subrev_f32_e32 v23, %[orgz], v20\n\t" \
+    /* its world-space location, raycast.cu:98-104: (pt * scale - inv_pose.xyz) rotated by q_inv_pose.  For an instance with scale 1 and the \
+       identity quaternion -- translated or not: the common case, and the reference's own scene (kernel.cu:209-240) -- the product and the rotation \
+       return their operand (up to the sign of a zero, which the squares below cannot see) and only the subtraction is left; any other \
+       instance takes the whole sequence, out of line behind a scalar branch (.Lrt_general, after the loop) */ \
+    "s_cmp_lg_u64 %[ip], 0\n\t" \
+    "s_cbranch_scc1 .Lrt_general%=\n\t" \
+    "v_subrev_f32_e32 v21, %[tx], v18\n\t" \
+    "v_subrev_f32_e32 v22, %[ty], v19\n\t" \
+    "v_subrev_f32_e32 v23, %[tz], v20\n\t" \
+    ".Lrt_have_loc%=:\n\t" \
+    /* its distance from the ray's world origin */ \
+    "v_subrev_f32_e32 v21, %[orgx], v21\n\t" \
+    "v_subrev_f32_e32 v22, %[orgy], v22\n\t" \
+    "v_subrev_f32_e32 v23, %[orgz], v23\n\t" \
     "v_mul_f32_e32 v21, v21, v21\n\t" \
     "v_mul_f32_e32 v22, v22, v22\n\t" \
     "v_add_f32_e32 v21, v21, v22\n\t" \
@@ -903,7 +914,66 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_cbranch_execnz .Lrt_top%=\n\t" \
     ".Lrt_exit%=:\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t"                         /* (the last pop's reload of the top) */ \
-    "s_mov_b64 exec, s[46:47]\n\t"
+    "s_mov_b64 exec, s[46:47]\n\t" \
+    "s_branch .Lrt_end%=\n\t" \
+    /* ---- out of line: mesh -> world of an accepted candidate for an instance that is scaled or rotated (raycast.cu:98-104 with \
+       apply_quat of transforms.hpp:165-176 written out: the same products and sums in the same association, no contraction).  The \
+       record's registers v0..v7 are free here (the triangle test is over), and so are s[48:63]: the instance's inverse pose comes \
+       through the scalar cache where it is needed instead of sitting in ten scalar registers around the loop */ \
+    ".Lrt_general%=:\n\t" \
+    "s_load_dwordx4 s[48:51], %[ip], 0x20\n\t"         /* DevInstance::q_inv_pose */ \
+    "s_load_dwordx2 s[52:53], %[ip], 0x58\n\t"         /* DevInstance::scale x y */ \
+    "s_load_dword s54, %[ip], 0x60\n\t"                /* DevInstance::scale z */ \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_mul_f32_e32 v0, s52, v18\n\t" \
+    "v_mul_f32_e32 v1, s53, v19\n\t" \
+    "v_mul_f32_e32 v2, s54, v20\n\t" \
+    "v_subrev_f32_e32 v0, %[tx], v0\n\t" \
+    "v_subrev_f32_e32 v1, %[ty], v1\n\t" \
+    "v_subrev_f32_e32 v2, %[tz], v2\n\t" \
+    "v_mul_f32_e64 v3, -v0, s49\n\t"                   /* a = -v.x * q.y - v.y * q.z - v.z * q.w */ \
+    "v_mul_f32_e32 v4, s50, v1\n\t" \
+    "v_sub_f32_e32 v3, v3, v4\n\t" \
+    "v_mul_f32_e32 v4, s51, v2\n\t" \
+    "v_sub_f32_e32 v3, v3, v4\n\t" \
+    "v_mul_f32_e32 v4, s48, v0\n\t"                    /* b = v.x * q.x + v.y * q.w - v.z * q.z */ \
+    "v_mul_f32_e32 v5, s51, v1\n\t" \
+    "v_add_f32_e32 v4, v4, v5\n\t" \
+    "v_mul_f32_e32 v5, s50, v2\n\t" \
+    "v_sub_f32_e32 v4, v4, v5\n\t" \
+    "v_mul_f32_e32 v5, s48, v1\n\t"                    /* c = v.y * q.x + v.z * q.y - v.x * q.w */ \
+    "v_mul_f32_e32 v6, s49, v2\n\t" \
+    "v_add_f32_e32 v5, v5, v6\n\t" \
+    "v_mul_f32_e32 v6, s51, v0\n\t" \
+    "v_sub_f32_e32 v5, v5, v6\n\t" \
+    "v_mul_f32_e32 v6, s48, v2\n\t"                    /* d = v.z * q.x + v.x * q.z - v.y * q.y */ \
+    "v_mul_f32_e32 v7, s50, v0\n\t" \
+    "v_add_f32_e32 v6, v6, v7\n\t" \
+    "v_mul_f32_e32 v7, s49, v1\n\t" \
+    "v_sub_f32_e32 v6, v6, v7\n\t" \
+    "v_mul_f32_e32 v21, s48, v4\n\t"                   /* x = q.x * b - q.y * a - q.z * d + q.w * c */ \
+    "v_mul_f32_e32 v7, s49, v3\n\t" \
+    "v_sub_f32_e32 v21, v21, v7\n\t" \
+    "v_mul_f32_e32 v7, s50, v6\n\t" \
+    "v_sub_f32_e32 v21, v21, v7\n\t" \
+    "v_mul_f32_e32 v7, s51, v5\n\t" \
+    "v_add_f32_e32 v21, v21, v7\n\t" \
+    "v_mul_f32_e32 v22, s48, v5\n\t"                   /* y = q.x * c - q.z * a - q.w * b + q.y * d */ \
+    "v_mul_f32_e32 v7, s50, v3\n\t" \
+    "v_sub_f32_e32 v22, v22, v7\n\t" \
+    "v_mul_f32_e32 v7, s51, v4\n\t" \
+    "v_sub_f32_e32 v22, v22, v7\n\t" \
+    "v_mul_f32_e32 v7, s49, v6\n\t" \
+    "v_add_f32_e32 v22, v22, v7\n\t" \
+    "v_mul_f32_e32 v23, s48, v6\n\t"                   /* z = q.x * d - q.w * a - q.y * c + q.z * b */ \
+    "v_mul_f32_e32 v7, s51, v3\n\t" \
+    "v_sub_f32_e32 v23, v23, v7\n\t" \
+    "v_mul_f32_e32 v7, s49, v5\n\t" \
+    "v_sub_f32_e32 v23, v23, v7\n\t" \
+    "v_mul_f32_e32 v7, s50, v4\n\t" \
+    "v_add_f32_e32 v23, v23, v7\n\t" \
+    "s_branch .Lrt_have_loc%=\n\t" \
+    ".Lrt_end%=:\n\t"
 
 // (experiments: -DRT_ASM_PAD_KIND=1|2|3 adds eight scalar / vector / no-op instructions to every iteration, to price an instruction of each kind)
 #define RT_ASM_X8(t) t t t t t t t t
@@ -917,10 +987,16 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 #define RT_ASM_PAD ""
 #endif
 
+// (the byte offsets .Lrt_general reads the instance record at)
+static_assert(offsetof(DevInstance, q_inv_pose) == 0x20 && offsetof(DevInstance, scale) == 0x58 && sizeof(DevInstance) % 16 == 0, "DevInstance layout");
+
 template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW, bool POPS, bool LOC>  // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
 __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_index, const MeshRay& r, V3 org, lds_int* column, int lds_depth,
-                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta, int& pops, V3& point)
+                                               int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta, int& pops, V3& point,
+                                               V3 back, const DevInstance* general)
 {
+    // back = DevInstance::inv_pose_xyz (wave-uniform: scalar operands); general = the instance when its mesh -> world transform scales or
+    // rotates (the candidate block then reads scale and q_inv_pose through the scalar cache), null when it only translates
     static_assert(!LOC || POPS, "the hit point is kept for the extension kernel, which counts pops");
     int32_t rem = -1;
     int32_t tos = kSentinel;                                    // the stack's top entry (row 0 of the LDS column holds a second sentinel, so
@@ -936,7 +1012,8 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
                  : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
                    [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), [col] "v"(column), \
                    [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
-                   [depth] "s"(lds_depth), [inst] "s"(inst_index), [eps] "s"(eps), [shift] "n"(ROW_SHIFT), [vdelta] "s"(vdelta) \
+                   [depth] "s"(lds_depth), [inst] "s"(inst_index), [eps] "s"(eps), [shift] "n"(ROW_SHIFT), [vdelta] "s"(vdelta), \
+                   [tx] "s"(back.x), [ty] "s"(back.y), [tz] "s"(back.z), [ip] "s"(general) \
                  : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
                    "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
                    "s30", "s31", "s64", "s65", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", \
@@ -992,8 +1069,16 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
 // kernel, which carries nothing, gains like the primary kernel (c4 at 16 spp: 8.27 against 8.50 ms).
 // VIEW: `view_off` = byte offset of the frame's view records from p.records (see trace_loop).
 // UNIFORM_ORG: every lane's ray starts at the same point (primary rays; the hand-written loop takes the origin as scalars).
+// STATS (rt_scene_loop_stats: an instrumented copy of the production kernels, never a timed launch): which loop this wave ran for
+// this instance goes to p.loop_stats (RT_LOOP_*), one count per wave and instance.
+__device__ __forceinline__ void loop_stat(const RenderParams& p, int which, unsigned long long n = 1ull)
+{
+    const unsigned long long active = __ballot(true);
+    if ((int)(__lane_id()) == __ffsll((long long)active) - 1) atomicAdd(&p.loop_stats[which], n);
+}
+
 template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true, bool ANYHIT = false,
-          bool VIEW = false, bool UNIFORM_ORG = !EX>
+          bool VIEW = false, bool UNIFORM_ORG = !EX, bool STATS = false>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
                                                int* pops = nullptr, uint32_t view_off = 0)
@@ -1012,7 +1097,8 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
     }
     if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && UNIFORM_ORG && (!EX || POPS) && !(POPS && COUNT) && !ANYHIT && !STK::kSpill) {
         // the hand-written loop (trace_loop_asm) for what it covers; everything else takes the C++ loops below
-        if (oct >= 0 && in.exact_uv == 0 && in.identity_inv != 0) {
+        if (oct >= 0 && in.exact_uv == 0) {
+            if constexpr (STATS) { loop_stat(p, RT_LOOP_ASM); if (in.unit_inv == 0) loop_stat(p, RT_LOOP_ASM_POSED); }
             stack.sp = 0;
             stack.push(kSentinel);
             int32_t cur = in.root_ref, sp = stack.sp;
@@ -1024,8 +1110,13 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             V3 point = v3(0.0f, 0.0f, 0.0f);
             const int32_t instance_before = hit.instance;
             if constexpr (EX) hit.instance = -7;
+            // (wave-uniform values read through the scalar cache: the instance record's address is uniform)
+            const V3 back = v3(in.inv_pose_xyz[0], in.inv_pose_xyz[1], in.inv_pose_xyz[2]);
+            const uintptr_t ia = in.unit_inv != 0 ? (uintptr_t)0 : (uintptr_t)&in;
+            const DevInstance* general = (const DevInstance*)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ia >> 32)) << 32) |
+                                                              (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ia));
 #define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW, POPS, EX>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta, \
-                                                                                              POPS ? *pops : no_pops, point)
+                                                                                              POPS ? *pops : no_pops, point, back, general)
             switch (oct) {
             case 0: RT_TRACE_ASM(0); break;
             case 1: RT_TRACE_ASM(1); break;
@@ -1052,6 +1143,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
     // (the C++ loop reads view records for the primary kernels' rays only; an extension ray that does not qualify for the hand-written
     // loop reads the records themselves)
 #define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O, ANYHIT, (VIEW && !EX)>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops, vdelta)
+    if constexpr (STATS) loop_stat(p, STK::kSpill ? RT_LOOP_DEEP : (oct >= 0 ? RT_LOOP_CPP_OCTANT : RT_LOOP_CPP_GENERIC));
     switch (oct) {                                              // (wave-uniform: a scalar branch)
     case 0: RT_TRACE_LOOP(0); break;
     case 1: RT_TRACE_LOOP(1); break;
@@ -1129,7 +1221,7 @@ template <bool DEBUG, bool PROF, bool SPILL>
 __host__ __device__ inline int lds_block_rows(int stack_depth) { return lds_rows(stack_depth) + (optimistic_stack<DEBUG, PROF, SPILL>() ? 1 : 0); }
 
 // One pixel: camera ray -> cast_ray over all instances -> flat shade -> store (raycast.cu:146-297).
-template <bool DEBUG, bool PROF, bool COUNT = false, bool SPILL = true, bool VIEW = false>
+template <bool DEBUG, bool PROF, bool COUNT = false, bool SPILL = true, bool VIEW = false, bool STATS = false>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameParams& f, int x0, int y0, lds_int* lds_base, lds_int*& lds_column,
                                              int* iters = nullptr, uint32_t view_off = 0)
 {
@@ -1149,25 +1241,27 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
         stack.lds = lds_column; stack.spill = nullptr; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
         int outgrown = 0;                                       // a loop left through the spare row ends with sp != 0
         for (int i = 0; i < p.num_instances; i++) {             // raycast.cu:26
-            trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, false, true>, false, true, false, VIEW>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters,
-                                                                                                            nullptr, view_off);
+            trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, false, true>, false, true, false, VIEW, true, STATS>(p, p.instances[i], i, org, dir, stack, hit, cnt,
+                                                                                                                         iters, nullptr, view_off);
             outgrown |= stack.sp;
         }
+        if constexpr (STATS) { loop_stat(p, RT_LOOP_WAVES); if (__ballot(outgrown != 0) != 0ull) loop_stat(p, RT_LOOP_RETRACED_LANES, (unsigned long long)__popcll(__ballot(outgrown != 0))); }
         if (outgrown != 0) {
             int spill[kMaxStack - kLdsStack];
             StackT<kPrimBlock, true> deep;
             deep.lds = lds_column; deep.spill = spill; deep.lds_depth = lds_rows(p.stack_depth); deep.sp = 0;
             hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
             for (int i = 0; i < p.num_instances; i++)
-                trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, true>, false, false>(p, p.instances[i], i, org, dir, deep, hit, cnt, iters);
+                trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, true>, false, false, false, false, true, STATS>(p, p.instances[i], i, org, dir, deep, hit, cnt, iters);
         }
     } else {
         int spill[SPILL ? kMaxStack - kLdsStack : 1];
         StackT<kPrimBlock, SPILL> stack;
         stack.lds = lds_column; stack.spill = spill; stack.lds_depth = lds_rows(p.stack_depth); stack.sp = 0;
+        if constexpr (STATS) loop_stat(p, RT_LOOP_WAVES);
         for (int i = 0; i < p.num_instances; i++)               // raycast.cu:26
-            trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, SPILL>, false, true, false, VIEW>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters,
-                                                                                                  nullptr, view_off);
+            trace_instance<DEBUG, PROF, false, COUNT, StackT<kPrimBlock, SPILL>, false, true, false, VIEW, true, STATS>(p, p.instances[i], i, org, dir, stack, hit, cnt, iters,
+                                                                                                               nullptr, view_off);
     }
 
     // The pixel's coordinates are not kept across the traversal (three registers in a kernel that has none to spare: they
@@ -1202,7 +1296,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, const FrameP
 // otherwise idle chip; started first, those waves run beside the bulk of the frame instead of after it
 // (measured: -22 % / -12 % / 0 % frame time for the far / mid / near camera).  Which tile a workgroup renders does not
 // change what a pixel computes.
-template <bool DEBUG, bool PROF, bool ORDERED = false, bool SPILL = true, bool VIEW = false>
+template <bool DEBUG, bool PROF, bool ORDERED = false, bool SPILL = true, bool VIEW = false, bool STATS = false>
 __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParams p)
 {
     extern __shared__ int lds_stack[];                          // [lds_block_rows(stack_depth)][kPrimBlock] (+ 2 ints when ORDERED)
@@ -1233,7 +1327,7 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
         int x, ly, y;
         pixel_of(p, p.frames[frame], (int)threadIdx.x, tx * kPrimTile, ty * kPrimTile, x, ly, y);
         if (x < p.width && ly < p.frames[frame].local_rows)
-            render_pixel<DEBUG, PROF, ORDERED, SPILL, VIEW>(p, p.frames[frame], tx * kPrimTile, ty * kPrimTile, (lds_int*)lds_stack, column, &iters,
+            render_pixel<DEBUG, PROF, ORDERED, SPILL, VIEW, STATS>(p, p.frames[frame], tx * kPrimTile, ty * kPrimTile, (lds_int*)lds_stack, column, &iters,
                                                             VIEW ? p.view_base + (uint32_t)frame * p.view_frame_stride : 0u);
     }
     asm volatile("" : "+v"(column));
@@ -1245,8 +1339,13 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
         if (p.tile_cost && lane == 0) {
             __hip_atomic_fetch_max((int*)&group[1], iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int before = __hip_atomic_fetch_add((int*)&group[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (before == kPrimBlock / 64 - 1)                  // this wave is the last of its workgroup
-                p.tile_cost[tile] = __hip_atomic_load((int*)&group[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (before == kPrimBlock / 64 - 1) {                // this wave is the last of its workgroup
+                const int cost = __hip_atomic_load((int*)&group[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // several frames per launch (a rank's stripes of a few frames): a tile's cost is that of its costliest frame -- the
+                // frames differ in pose and, with a rotating stripe owner, in the rows a tile stands for; the sort clears what it has read
+                if (p.num_frames > 1) atomicMax(&p.tile_cost[tile], cost);
+                else p.tile_cost[tile] = cost;
+            }
         }
     }
     if (p.trace && lane == 0) {                                 // diagnostic: per-wave lifetime (RT_TRACE_FILE)
@@ -1373,12 +1472,23 @@ __device__ __forceinline__ Xorwow ex_stream(const RenderParams& p, int x, int y,
 // workgroup used to be.
 constexpr int kExBlock = 64;
 typedef StackT<kExBlock> ExStack;
-template <bool SIMPLE, bool PX = false, bool VIEW = false>
+// PHASE (round 6; bounces / lighting, PX mapping): 0 = the whole path in one kernel, as above.  1 + 2 = the same path in TWO launches
+// with the same grid: phase 1 casts the camera ray -- the hand-written loop, the frame's view records, no path state to carry, like the
+// samples-only kernel -- and stores what survives the cast per lane, (slot, instance, u, v) and (location, pops): 32 B in two planes,
+// the lanes of a wave side by side; phase 2 picks the record up and runs the rest of the path (shade, shadow ray, bounces) with the
+// compiler's loops only.  Why: the camera ray is 38 % of c3's node pops; inside the one-kernel form it takes the hand-written loop at
+// the price of 45 spilled registers around EVERY cast of the path (25 without it).  The casts, their order and every operation on
+// their results are the same, so the frame is the same bit for bit (tests: RT_EX_SPLIT=0 / 1 against each other and the oracle).
+// The launch is cut into chunks of workgroups when the records of all of it would not fit the scratch budget (wg_base).
+template <bool SIMPLE, bool PX = false, bool VIEW = false, int PHASE = 0>
 __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderParams p)
 {
+    static_assert(PHASE == 0 || (PX && !SIMPLE), "the two-launch form is the bounce kernel's, in the pixel-wave mapping");
+    static_assert(PHASE != 2 || !VIEW, "phase 2 casts no camera ray");
     extern __shared__ int lds_stack[];
     const FrameParams& f = p.frames[0];
-    const int tile = (int)(blockIdx.x >> 2), quarter = (int)(blockIdx.x & 3);
+    const unsigned bx = blockIdx.x + (PHASE != 0 ? (unsigned)p.wg_base : 0u);
+    const int tile = (int)(bx >> 2), quarter = (int)(bx & 3);
     int x, ly, y, s;
     bool valid;
     ex_work_item<PX>(p, tile, (int)blockIdx.y, quarter * 64 + (int)threadIdx.x, x, ly, y, s, valid);
@@ -1409,6 +1519,13 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     V3 org = v3(f.origin[0], f.origin[1], f.origin[2]);
     V3 dir = camera_direction(f, px, py);
     V3 weight = v3(1.0f, 1.0f, 1.0f);
+    if constexpr (PHASE == 1) {                                 // the camera ray alone: what survives the cast goes to the lane's record
+        const Hit hit = cast_ray_ex<true, true, false, ExStack, true, VIEW, true>(p, org, dir, stack, pops);
+        asm volatile("" : "+v"(stack.lds));
+        const size_t li = (size_t)blockIdx.x * kExBlock + (size_t)(stack.lds - (lds_int*)lds_stack);
+        p.ex_rec[li] = make_float4(__int_as_float(hit.slot), __int_as_float(hit.instance), hit.u, hit.v);
+        p.ex_rec[(size_t)p.ex_rec_lanes + li] = make_float4(hit.loc.x, hit.loc.y, hit.loc.z, __int_as_float(pops));
+    } else
     if constexpr (SIMPLE) {                                     // the loop below for bounces = 0, lighting = 0, written out
         const Hit hit = cast_ray_ex<false, true, false, ExStack, true, VIEW, true>(p, org, dir, stack, pops);
         if (hit.min == FLT_MAX) sample = sample + weight * v3(1.0f, 0.8f, 0.6f);
@@ -1427,9 +1544,8 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     // records, i.e. when the tree is small beside the frame -- it takes the hand-written loop and the frame's view: c3 / c5 -4.5 %.
     // The other form keeps the compiler's loop for it: without a view the camera ray's gain is smaller than what 18 more spilled
     // registers cost the bounce casts -- c6 with mirror walls, whose 4 M-node tree gets no view, lost 9 % with it.)
-    auto step = [&](auto primary, const int depth) __attribute__((always_inline)) -> bool {
-        constexpr bool kPrimary = RT_EX_PRIMARY_ASM && VIEW && decltype(primary)::value;
-        Hit hit = cast_ray_ex<true, kPrimary, false, ExStack, kPrimary, kPrimary, kPrimary>(p, org, dir, stack, pops);
+    // (after_cast: everything a depth does with the hit of its cast -- phase 2 enters here with the hit phase 1 stored)
+    auto after_cast = [&](Hit hit, const int depth) __attribute__((always_inline)) -> bool {
         if (hit.min == FLT_MAX) { sample = sample + weight * v3(1.0f, 0.8f, 0.6f); return false; }
         float illum = 1.0f;
 #if RT_EX_RECOMPUTE
@@ -1485,6 +1601,23 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
         dir = r;
         return true;
     };
+    auto step = [&](auto primary, const int depth) __attribute__((always_inline)) -> bool {
+        constexpr bool kPrimary = RT_EX_PRIMARY_ASM && VIEW && decltype(primary)::value;
+        Hit hit = cast_ray_ex<true, kPrimary, false, ExStack, kPrimary, kPrimary, kPrimary>(p, org, dir, stack, pops);
+        return after_cast(hit, depth);
+    };
+    if constexpr (PHASE == 2) {
+        // the camera ray was cast by phase 1: its record (the same lane of the same workgroup of the same grid)
+        const size_t li = (size_t)blockIdx.x * kExBlock + (size_t)threadIdx.x;
+        const float4 ra = p.ex_rec[li], rb = p.ex_rec[(size_t)p.ex_rec_lanes + li];
+        Hit hit;
+        hit.slot = __float_as_int(ra.x); hit.instance = __float_as_int(ra.y); hit.u = ra.z; hit.v = ra.w;
+        hit.loc = v3(rb.x, rb.y, rb.z);
+        hit.min = hit.instance < 0 ? FLT_MAX : 0.0f;            // (only "was anything hit" is asked of it from here on)
+        pops = __float_as_int(rb.w);
+        if (after_cast(hit, 0))
+            for (int depth = 1; depth <= p.bounces; depth++) if (!step(std::false_type{}, depth)) break;
+    } else {
 #if RT_EX_PEEL
     // the primary ray's depth written out: weight = 1 and sample = 0 are constants across its cast, not registers to keep
     if (step(std::true_type{}, 0))
@@ -1494,6 +1627,8 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
 #endif
     }
     }
+    }
+    if constexpr (PHASE == 1) return;                           // (nothing to add up yet: phase 2 finishes the path)
     where(x, ly, y, s, valid);
     const int lane = (int)(stack.lds - (lds_int*)lds_stack);
     if constexpr (PX) {
@@ -1837,15 +1972,20 @@ __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pi
 }
 
 // Heavy-first dispatch order of the next single-frame launch: a counting sort of the tiles by the lifetime their workgroup
-// had in the last frame (its longest lane's iteration count, longest first), by ONE workgroup of 1024 threads.  Each cost is read
-// ONCE (a render on another stream may be rewriting the array): whatever the values, the result is a permutation of the tiles.
+// had in the last frame (its longest lane's iteration count, longest first), by ONE workgroup of 1024 threads.  A tile's key is
+// computed once and kept (a render on another stream may be rewriting the costs): whatever the values, the result is a permutation of the tiles.
 // The sort runs on the scene's side stream, but a hipDeviceSynchronize waits for it like for everything else -- the
 // reference's loop synchronises the device every two frames (kernel.cu:279) -- so it has to be short: every thread loads
 // eight costs before it touches any of them (one memory latency per 8192 tiles instead of one per 256; round 4's 256-thread
 // form took 30-50 us for the 8160 tiles of a 1080p frame, this one a fifth of that).
 constexpr int kSortKeys = 1024, kSortThreads = 1024, kSortBatch = 8;
-__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int32_t* __restrict__ cost, int ntiles, int32_t* __restrict__ keys,
-                                                                 int32_t* __restrict__ order)
+// Round 6: a tile's key is the LARGEST cost among the tile and its eight neighbours.  The costly tiles are the ones whose rays graze a
+// silhouette, and which tiles those are changes with the smallest camera motion -- a frame a few millimetres along finds last frame's
+// order one tile off exactly where it matters (measured: single frames along bench.py's 4 mm camera loop 0.134 ms against 0.127 ms for
+// the same pose repeated; profiles/r06_experiments/single_frame_gap.md).  With the neighbourhood's maximum, the tiles NEXT to a costly
+// one start early too.
+__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(int32_t* cost, int ntiles, int tiles_x, int32_t* __restrict__ keys,
+                                                                 int32_t* __restrict__ order, int reset)
 {
     static_assert(kSortKeys == kSortThreads, "one class per thread in the scan below");
     __shared__ int count[kSortKeys], scan[kSortThreads];
@@ -1857,7 +1997,17 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int32_t* 
 #pragma unroll
         for (int j = 0; j < kSortBatch; j++) {
             const int i = base + j * kSortThreads + t;
-            k[j] = i < ntiles ? cost[i] : -1;                   // iterations of the tile's longest lane (a few hundred at most)
+            k[j] = -1;
+            if (i < ntiles) {                                   // iterations of the longest lane (a few hundred at most) of the 3 x 3 tiles around i
+                const int tx = i % tiles_x, x0 = tx > 0 ? -1 : 0, x1 = tx + 1 < tiles_x ? 1 : 0;
+                int m = 0;
+                for (int dy = -tiles_x; dy <= tiles_x; dy += tiles_x) {
+                    const int row = i + dy;
+                    if (row < 0 || row >= ntiles) continue;
+                    for (int dx = x0; dx <= x1; dx++) { const int c = cost[row + dx]; m = c > m ? c : m; }
+                }
+                k[j] = m;
+            }
         }
 #pragma unroll
         for (int j = 0; j < kSortBatch; j++) {
@@ -1871,6 +2021,10 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(const int32_t* 
         }
     }
     __syncthreads();
+    // (multi-frame launches accumulate a maximum per tile: what has been read starts again from zero -- after every thread has read its
+    // neighbourhoods; a launch running beside this sort may lose a cost it had just written: that tile is ordered by its neighbours'
+    // and its other frames' costs, or late, once)
+    if (reset) for (int i = t; i < ntiles; i += kSortThreads) cost[i] = 0;
     // exclusive prefix over the classes (Hillis-Steele on the inclusive sums): count[] becomes the running cursor of each class
     const int mine = count[t];
     scan[t] = mine;
@@ -2051,6 +2205,8 @@ DevInstance make_dev_instance(const RtInstanceDesc& d, const RtScene& s)
     o.identity_inv = 1;
     for (int k = 0; k < 3; k++) if (!(d.scale[k] == 1.0f && d.inv_pose[k] == 0.0f)) o.identity_inv = 0;
     if (!(o.q_inv_pose.x == 1.0f && o.q_inv_pose.y == 0.0f && o.q_inv_pose.z == 0.0f && o.q_inv_pose.w == 0.0f)) o.identity_inv = 0;
+    o.unit_inv = (d.scale[0] == 1.0f && d.scale[1] == 1.0f && d.scale[2] == 1.0f &&
+                  o.q_inv_pose.x == 1.0f && o.q_inv_pose.y == 0.0f && o.q_inv_pose.z == 0.0f && o.q_inv_pose.w == 0.0f) ? 1 : 0;
     o.root_ref = s.mesh_root_ref[d.mesh_index];
     o.exact_uv = s.mesh_exact_uv[d.mesh_index];
     o.material_index = d.material_index;
@@ -2134,10 +2290,28 @@ hipError_t trace_end(RenderParams& p, size_t n, const char* path, hipStream_t st
 // device, except when a FIFTH frame size evicts an idle state (its arrays are freed); a launch that finds no state it
 // may use renders in natural order.
 namespace {
+// whether every ordered launch issued on the entry's stream has finished.  Launches since the stream's last recorded event (dirty):
+// an idle stream has finished them all; on a busy one the event is recorded now, behind them, and tells a later call.
+bool seen_finished(RtScene::TileOrder::Seen& e)
+{
+    if (e.dirty) {
+        const hipError_t q = hipStreamQuery(e.stream);
+        if (q == hipSuccess) { e.dirty = false; return true; }
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) { e.dirty = false; return true; }        // (a stream the application has destroyed: its work is over)
+        e.dirty = false;
+        if (hipEventRecord(e.done, e.stream) != hipSuccess) { (void)hipGetLastError(); return true; }
+        return false;
+    }
+    const bool done = hipEventQuery(e.done) == hipSuccess;
+    if (!done) (void)hipGetLastError();
+    return done;
+}
+
 bool order_state_idle(RtScene::TileOrder& o)
 {
     if (o.pending) { if (hipEventQuery(o.sort_done) != hipSuccess) return false; o.cur = o.target; o.pending = false; }
-    for (auto& e : o.seen) if (e.used && hipEventQuery(e.done) != hipSuccess) return false;
+    for (auto& e : o.seen) if (e.used && !seen_finished(e)) return false;
     return true;
 }
 }  // namespace
@@ -2166,25 +2340,69 @@ int view_mode()
     return mode;
 }
 
-// Decides whether this launch renders through view records; if so: a slot of the pool (grown when needed), the launch's view
-// parameters in `p`, the pre-pass queued on `stream`.  Returns the slot (view_done records its event after the render kernel) or
-// -1: the launch then runs the kernels without views -- same pixels.
+// RT_VIEW_MAX_BYTES: what the pool of ONE scene may take (default 1 GiB; never more than keeps records + pool below 4 GiB)
+size_t view_budget()
+{
+    static const size_t b = [] {
+        const char* e = getenv("RT_VIEW_MAX_BYTES");
+        size_t v = e && *e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 30;
+        return v > kViewMaxBytes ? kViewMaxBytes : v;
+    }();
+    return b;
+}
+
+// static eligibility of the scene (decided once; the caller holds call_mu)
+void view_decide(RtScene* s)
+{
+    RtScene::ViewPool& v = s->view;
+    if (v.decided) return;
+    v.decided = true;
+    int32_t cap = 0;
+    for (const auto& rf : s->mesh_refit) cap = std::max(cap, rf.int_cap);
+    // (an instance may be given another mesh later, rt_scene_update_instance: every instance gets room for the largest)
+    v.frame_records = cap * (int32_t)s->instances.size();
+    v.inst_first.resize(s->instances.size());
+    for (size_t i = 0; i < s->instances.size(); i++) v.inst_first[i] = (int32_t)i * cap;
+    v.usable = cap > 0 && s->records_bytes > 0 && !s->instances.empty() && s->instances.size() <= (size_t)kMaxViewInstances &&
+               s->records_bytes + (size_t)v.frame_records * 64 <= kViewMaxBytes;
+}
+
+// The record array moves into a new allocation with a pool of `slots` x `frames` views as its tail (slots: three, or as many as the
+// budget allows).  The caller holds call_mu -- no other launch of this scene can be prepared meanwhile -- and the device is drained
+// first: nothing reads the old block afterwards, so it is freed here.  RT_OK, RT_E_NOMEM (budget or allocation), or a HIP error.
+int view_resize(RtScene* s, int frames)
+{
+    RtScene::ViewPool& v = s->view;
+    const size_t frame_bytes = (size_t)v.frame_records * 64, base = (s->records_bytes + 255) & ~(size_t)255;
+    const size_t room = std::min(view_budget(), kViewMaxBytes > base ? kViewMaxBytes - base : 0);
+    int slots = 3;
+    while (slots > 1 && frame_bytes * (size_t)slots * (size_t)frames > room) slots--;
+    if (frames < 1 || frame_bytes * (size_t)slots * (size_t)frames > room) return RT_E_NOMEM;
+    const size_t total = base + frame_bytes * (size_t)slots * (size_t)frames;
+    float4* block = nullptr;
+    RT_HIP(hipDeviceSynchronize());
+    if (hipMalloc((void**)&block, total) != hipSuccess) { (void)hipGetLastError(); return RT_E_NOMEM; }
+    hipError_t e = hipMemcpy(block, s->d_records, s->records_bytes, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(block); return (int)e; }
+    (void)hipFree(s->d_records);
+    s->device_bytes += total;
+    s->device_bytes -= std::min(s->device_bytes, s->records_alloc_bytes);
+    s->d_records = block;
+    s->records_alloc_bytes = total;
+    v.base_bytes = base; v.slot_frames = frames; v.slots = slots; v.grows++;
+    for (auto& sl : v.slot) { sl.used = false; sl.stream = nullptr; }
+    return RT_OK;
+}
+
+// Decides whether this launch renders through view records; if so: a slot of the pool (grown when needed and allowed), the launch's
+// view parameters in `p`, the pre-pass queued on `stream`.  Returns the slot (view_done records its event after the render kernel) or
+// -1: the launch then runs the kernels without views -- same pixels.  The caller holds call_mu from here to view_done.
 // `samples`: primary rays per pixel (the samples-only extension kernel: its jittered rays share the frame's origin too).
 int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream, int samples = 1)
 {
     if (!view_mode() || !s || p.num_instances < 1 || p.num_instances > kMaxViewInstances || p.num_ranks < 1) return -1;
     RtScene::ViewPool& v = s->view;
-    std::lock_guard<std::mutex> lock(v.m);
-    if (!v.decided) {
-        v.decided = true;
-        int32_t cap = 0;
-        for (const auto& rf : s->mesh_refit) cap = std::max(cap, rf.int_cap);
-        // (an instance may be given another mesh later, rt_scene_update_instance: every instance gets room for the largest)
-        v.frame_records = cap * (int32_t)s->instances.size();
-        v.inst_first.resize(s->instances.size());
-        for (size_t i = 0; i < s->instances.size(); i++) v.inst_first[i] = (int32_t)i * cap;
-        v.usable = cap > 0 && s->records_bytes > 0 && s->records_bytes + (size_t)v.frame_records * 64 * 3 <= kViewMaxBytes;
-    }
+    view_decide(s);
     if (!v.usable || (size_t)p.num_instances != s->instances.size()) return -1;
     ViewJob job;
     job.n = p.num_instances; job.total = 0;
@@ -2200,50 +2418,48 @@ int view_prepare(RtScene* s, RenderParams& p, hipStream_t stream, int samples = 
                                              job.total, p.num_frames, min_frames, (long long)p.width * p.local_rows, min_rays);
         return -1;
     }
-    v.launches++;
+    auto count = [&](uint64_t RtScene::ViewPool::*field) { std::lock_guard<std::mutex> lock(v.m); (v.*field)++; };
+    count(&RtScene::ViewPool::launches);
     const size_t frame_bytes = (size_t)v.frame_records * 64;
     if (p.num_frames > v.slot_frames) {
-        // grow: 1, 4 or kMaxBatch frames per slot.  The records move into a new allocation with the pool as its tail: every
-        // launch in flight reads the old one, so the device is drained first (three times in a scene's life at most).
-        int want = p.num_frames <= 1 ? 1 : p.num_frames <= 4 ? 4 : kMaxBatch;
-        while (want > p.num_frames && s->records_bytes + frame_bytes * 3 * (size_t)want > kViewMaxBytes) want = p.num_frames;
-        if (s->records_bytes + frame_bytes * 3 * (size_t)want > kViewMaxBytes) { v.fallbacks++; return -1; }
-        const size_t base = (s->records_bytes + 255) & ~(size_t)255;
-        float4* block = nullptr;
-        if (hipDeviceSynchronize() != hipSuccess) { v.fallbacks++; return -1; }
-        if (hipMalloc((void**)&block, base + frame_bytes * 3 * (size_t)want) != hipSuccess) {
-            (void)hipGetLastError();
-            v.usable = false; v.fallbacks++;                    // (no memory for it: this scene renders without views from now on)
+        // the pool is too small for this launch.  Reserved by the application: it stays as it is.  Else it grows to the next of
+        // 1 / 4 / 8 / 16 / 32 frames per slot -- or to exactly this launch's frames where the budget allows no more -- in a call
+        // that blocks until the device is idle (at most five times in a scene's life; see rt_render_batch in rt_hip.h)
+        if (v.reserved) { count(&RtScene::ViewPool::fallbacks); return -1; }
+        int want = 1;
+        while (want < p.num_frames) want = want == 1 ? 4 : want * 2;
+        want = std::min(want, (int)kMaxBatch);
+        int rc = view_resize(s, want);
+        if (rc == RT_E_NOMEM && want != p.num_frames) rc = view_resize(s, p.num_frames);
+        if (rc != RT_OK) {
+            if (rc != RT_E_NOMEM) v.usable = false;             // (a HIP error: this scene renders without views from now on)
+            count(&RtScene::ViewPool::fallbacks);
             return -1;
         }
-        if (hipMemcpy(block, s->d_records, s->records_bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(block); v.usable = false; v.fallbacks++; return -1; }
-        v.retired.push_back(s->d_records);
-        s->device_bytes += base + frame_bytes * 3 * (size_t)want;           // (the earlier block stays allocated until the scene goes)
-        s->d_records = block;
-        v.base_bytes = base; v.slot_frames = want; v.grows++;
-        for (auto& sl : v.slot) { sl.used = false; sl.stream = nullptr; }
     }
     int use = -1;
-    for (int k = 0; k < 3 && use < 0; k++) if (v.slot[k].used && v.slot[k].stream == stream) use = k;       // stream order protects it
-    for (int k = 0; k < 3 && use < 0; k++) if (!v.slot[k].used) use = k;
-    for (int k = 0; k < 3 && use < 0; k++) if (hipEventQuery(v.slot[k].done) == hipSuccess) use = k;        // its last launch has finished
-    if (use < 0) { (void)hipGetLastError(); v.fallbacks++; return -1; }                                      // (all busy on other streams)
-    if (!v.slot[use].done && hipEventCreateWithFlags(&v.slot[use].done, hipEventDisableTiming) != hipSuccess) { v.fallbacks++; return -1; }
+    for (int k = 0; k < v.slots && use < 0; k++) if (v.slot[k].used && v.slot[k].stream == stream) use = k;   // stream order protects it
+    for (int k = 0; k < v.slots && use < 0; k++) if (!v.slot[k].used) use = k;
+    for (int k = 0; k < v.slots && use < 0; k++) {                                                            // its last launch has finished
+        if (hipEventQuery(v.slot[k].done) == hipSuccess) use = k;
+        else (void)hipGetLastError();
+    }
+    if (use < 0) { count(&RtScene::ViewPool::fallbacks); return -1; }                                        // (all busy on other streams)
+    if (!v.slot[use].done && hipEventCreateWithFlags(&v.slot[use].done, hipEventDisableTiming) != hipSuccess) { count(&RtScene::ViewPool::fallbacks); return -1; }
     v.slot[use].used = true; v.slot[use].stream = stream;
     p.records = s->d_records;                                   // (fill_params read it before a possible move)
     p.view_base = (uint32_t)(v.base_bytes + (size_t)use * v.slot_frames * frame_bytes);
     p.view_frame_stride = (uint32_t)frame_bytes;
     for (int i = 0; i < job.n; i++) p.view_inst_off[i] = (int32_t)(((int64_t)job.first[i] - job.node_base[i]) * 64);
     hipLaunchKernelGGL(view_records_kernel, dim3((unsigned)(((size_t)job.total * 4 + 255) / 256), (unsigned)p.num_frames), dim3(256), 0, stream, p, job);
-    if (hipGetLastError() != hipSuccess) { v.fallbacks++; return -1; }
+    if (hipGetLastError() != hipSuccess) { count(&RtScene::ViewPool::fallbacks); return -1; }
     return use;
 }
 
 void view_done(RtScene* s, int slot, hipStream_t stream)
 {
     if (slot < 0) return;
-    std::lock_guard<std::mutex> lock(s->view.m);
-    (void)hipEventRecord(s->view.slot[slot].done, stream);
+    (void)hipEventRecord(s->view.slot[slot].done, stream);     // (still under the call_mu view_prepare was called under)
 }
 
 int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchronize, bool view)
@@ -2263,7 +2479,7 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
                 (void)hipFree(lru->d_cost);
                 lru->d_cost = lru->d_keys = lru->d_order[0] = lru->d_order[1] = nullptr;
                 lru->tiles_x = lru->tiles_y = lru->ntiles = 0; lru->cur = -1; lru->pending = false; lru->launches = lru->sorted_at = 0;
-                for (auto& e : lru->seen) e.used = false;
+                for (auto& e : lru->seen) e.used = e.dirty = false;
                 o = lru;
             }
         }
@@ -2284,9 +2500,9 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
         if (o->pending && hipEventQuery(o->sort_done) == hipSuccess) { o->cur = o->target; o->pending = false; }
         for (auto& e : o->seen) if (e.used && e.stream == stream) mine = &e;
         if (!mine) for (auto& e : o->seen) if (!e.used) { mine = &e; break; }
-        if (!mine) {                                            // all four slots taken: the one whose launch finished longest ago
+        if (!mine) {                                            // all four slots taken: the one whose launches finished longest ago
             for (auto& e : o->seen)
-                if (hipEventQuery(e.done) == hipSuccess && (!mine || e.tick < mine->tick)) mine = &e;
+                if (seen_finished(e) && (!mine || e.tick < mine->tick)) mine = &e;
         }
         if (mine) { mine->used = true; mine->stream = stream; mine->tick = cache.tick; }
     }
@@ -2303,30 +2519,47 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
         else hipLaunchKernelGGL((render_kernel<false, false, true>), grid, dim3(kPrimBlock), lds, stream, p);
     }
     RT_HIP(hipGetLastError());
-    // The next order is sorted from the costs of EARLIER launches: the sort waits for the launches issued before this one (their
-    // events; this launch's own is recorded below, after the sort has been queued), so it runs on the side stream WHILE this frame
-    // renders.  A device-wide synchronise after a frame -- the reference's loop synchronises every two frames, an interactive
-    // application every frame -- waits for the side stream too, and used to find the sort of the frame it had just waited for
-    // still to be run (round 4: 30-50 us; a quarter of that since the 1024-thread sort, every fourth launch).  Costs one frame
-    // older order the tiles as well.  (This launch writes the cost array while the sort reads it: every cost is read once and
-    // whatever the values, the result is a permutation.  This launch reads d_order[cur], the sort writes the other buffer.)
-    static const int interval = [] { const char* e = getenv("RT_TILE_SORT_INTERVAL"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
-    o->launches++;
+    // A new order is sorted every RT_TILE_SORT_INTERVAL-th launch (default 4), on the side stream, from the costs the launches so far
+    // have left; it must not start before every launch that may still read the buffer it writes has finished, i.e. every ordered
+    // launch issued so far on any stream.  Round 6: the events that tell it are recorded WHEN A SORT IS ISSUED, on every stream that
+    // has launched since its last one -- not after every launch as before: a recorded event is a marker packet between two kernels
+    // of the stream, and back-to-back launches with a marker in between start 7 us apart where launches without start 0 us apart
+    // (profiles/r06_experiments/single_frame_gap.md: rocprofv3 kernel-trace timestamps of 60 back-to-back launches, three settings).
+    // (The launch after the sort rewrites the cost array while the sort reads it: every cost is read once and whatever the
+    // values, the result is a permutation.  Launches read d_order[cur], the sort writes the other buffer.)
+    static const int interval = [] { const char* e = getenv("RT_TILE_SORT_INTERVAL"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+    if (o) o->launches++;
+    if (mine) mine->dirty = true;
     if (mine && !o->pending && o->launches > 1 && (o->cur < 0 || o->launches - o->sorted_at >= (uint64_t)interval)) {
         o->sorted_at = o->launches;
         o->target = o->cur < 0 ? 0 : o->cur ^ 1;
-        for (auto& e : o->seen) if (e.used) RT_HIP(hipStreamWaitEvent(cache.sort_stream, e.done, 0));
-        hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, cache.sort_stream, o->d_cost, ntiles, o->d_keys, o->d_order[o->target]);
-        RT_HIP(hipGetLastError());
-        RT_HIP(hipEventRecord(o->sort_done, cache.sort_stream));
-        o->pending = true;
+        bool all = true;
+        for (auto& e : o->seen) {
+            if (!e.used) continue;
+            if (e.dirty) {
+                e.dirty = false;
+                if (hipEventRecord(e.done, e.stream) != hipSuccess) {       // (a stream the application has destroyed since: its work is over)
+                    (void)hipGetLastError();
+                    if (&e == mine) all = false;
+                    e.used = false;
+                    continue;
+                }
+            }
+            RT_HIP(hipStreamWaitEvent(cache.sort_stream, e.done, 0));
+        }
+        if (all) {
+            hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, cache.sort_stream, o->d_cost, ntiles, p.tiles_x, o->d_keys, o->d_order[o->target],
+                               p.num_frames > 1 ? 1 : 0);
+            RT_HIP(hipGetLastError());
+            RT_HIP(hipEventRecord(o->sort_done, cache.sort_stream));
+            o->pending = true;
+        }
     }
-    if (mine) RT_HIP(hipEventRecord(mine->done, stream));
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
 }
 
-int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtScene* scene = nullptr)
+int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtScene* scene = nullptr, bool stats = false)
 {
     if (p.width <= 0 || p.local_rows < 0) return RT_E_INVALID;
     if (p.local_rows == 0) return RT_OK;
@@ -2349,7 +2582,11 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     } view_guard{scene, view_slot, stream};
     if (scene && !debug && (!trace_file || trace_ordered) && !p.hit_instance && !p.hit_triangle && grid.x >= 1024 && (size_t)grid.x * grid.y <= ((size_t)1 << 30)) {
         static const bool enabled = [] { const char* e = getenv("RT_TILE_ORDER"); return !(e && e[0] == '0'); }();
-        if (enabled && p.num_frames == 1 && grid.x >= 8192) {   // (8x8-pixel tiles: half a million pixels)
+        // ... and (round 6) a rank's STRIPES of a few frames: at eight ranks a group of 20 frames is two and a half frames' worth of
+        // work per launch and ends, like a single frame, in a tail of a few long waves (RT_TILE_ORDER_STRIPES=0 turns this part off)
+        static const bool stripes_too = [] { const char* e = getenv("RT_TILE_ORDER_STRIPES"); return !(e && e[0] == '0'); }();
+        const bool thin_stripes = stripes_too && p.num_ranks > 1 && p.num_frames > 1 && (size_t)grid.x * grid.y < (size_t)4 * 32768;
+        if (enabled && !stats && ((p.num_frames == 1 && grid.x >= 8192) || thin_stripes)) {   // (8x8-pixel tiles: half a million pixels)
             if (!trace_ordered) return launch_ordered(scene, p, stream, synchronize, view_slot >= 0);
             const size_t n = (size_t)grid.x * (kPrimBlock / 64) * 16;
             RT_HIP(trace_begin(p, n));
@@ -2362,6 +2599,15 @@ int launch(RenderParams& p, bool debug, hipStream_t stream, int synchronize, RtS
     if (trace_file) RT_HIP(trace_begin(p, trace_n));
     if (trace_file && getenv("RT_TRACE_PROF")) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, stream, p);
     else if (debug) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, stream, p);
+    else if (stats) {                                           // rt_scene_loop_stats: the same choices as below, the instrumented copies
+        if (lds_stack_suffices(p)) {
+            if (view_slot >= 0) hipLaunchKernelGGL((render_kernel<false, false, false, false, true, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, false, false, false, true>), grid, block, lds, stream, p);
+        } else {
+            if (view_slot >= 0) hipLaunchKernelGGL((render_kernel<false, false, false, true, true, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((render_kernel<false, false, false, true, false, true>), grid, block, lds, stream, p);
+        }
+    }
     else if (lds_stack_suffices(p)) {
         if (view_slot >= 0) hipLaunchKernelGGL((render_kernel<false, false, false, false, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((render_kernel<false, false, false, false>), grid, block, lds, stream, p);
@@ -2629,7 +2875,7 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
             return e;
         };
         if ((he = make((void**)&s->d_records, (total + 1) * 4 * sizeof(float4), 0)) != hipSuccess) return fail((int)he);
-        s->records_bytes = (total + 1) * 4 * sizeof(float4);
+        s->records_bytes = s->records_alloc_bytes = (total + 1) * 4 * sizeof(float4);
         if ((he = make((void**)&s->d_tri_uv, total * 6 * sizeof(float), 0)) != hipSuccess) return fail((int)he);
         if ((he = make((void**)&s->d_tri_id, total * sizeof(int32_t), 0xff)) != hipSuccess) return fail((int)he);
         if ((he = make((void**)&s->d_leaf_count, total * sizeof(int32_t), 0)) != hipSuccess) return fail((int)he);
@@ -2690,8 +2936,11 @@ int rt_scene_upload(const RtSceneDesc* desc, RtScene** out)
     return RT_OK;
 }
 
+#define RT_SCENE_CALL(s) if (!(s)) return RT_E_INVALID; std::lock_guard<std::recursive_mutex> scene_call_guard_((s)->call_mu)
+
 int rt_scene_update_instance(RtScene* s, int32_t index, const RtInstanceDesc* instance)
 {
+    RT_SCENE_CALL(s);
     if (!s || !instance || index < 0 || index >= (int)s->instances.size() || !instance_ok(*instance, *s)) return RT_E_INVALID;
     s->instances[index] = make_dev_instance(*instance, *s);
     RT_HIP(hipMemcpy(s->d_instances + index, &s->instances[index], sizeof(DevInstance), hipMemcpyHostToDevice));
@@ -2700,6 +2949,7 @@ int rt_scene_update_instance(RtScene* s, int32_t index, const RtInstanceDesc* in
 
 int rt_scene_update_instance_async(RtScene* s, int32_t index, const RtInstanceDesc* instance, void* stream)
 {
+    RT_SCENE_CALL(s);
     if (!s || !instance || index < 0 || index >= (int)s->instances.size() || !instance_ok(*instance, *s)) return RT_E_INVALID;
     s->instances[index] = make_dev_instance(*instance, *s);
     hipLaunchKernelGGL(set_instance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, s->d_instances + index, s->instances[index]);
@@ -2710,7 +2960,8 @@ int rt_scene_update_instance_async(RtScene* s, int32_t index, const RtInstanceDe
 namespace {
 int refit_mesh(RtScene* s, int32_t mesh_index, const float* vertices, const float* normals, int32_t num_triangles, void* stream, bool on_device)
 {
-    if (!s || !vertices || !normals || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size()) return RT_E_INVALID;
+    RT_SCENE_CALL(s);
+    if (!vertices || !normals || mesh_index < 0 || mesh_index >= (int)s->mesh_refit.size()) return RT_E_INVALID;
     const RtScene::MeshRefit& rf = s->mesh_refit[(size_t)mesh_index];
     if (num_triangles != rf.num_triangles) return RT_E_INVALID;
     if (rf.num_triangles == 0) return RT_OK;
@@ -2782,7 +3033,8 @@ int rt_scene_refit_mesh_device(RtScene* s, int32_t mesh_index, const float* d_ve
 
 int rt_scene_debug_read(RtScene* s, int32_t which, void* host_dst, size_t capacity, size_t* bytes)
 {
-    if (!s || !bytes || which < 0 || which > 4) return RT_E_INVALID;
+    RT_SCENE_CALL(s);
+    if (!bytes || which < 0 || which > 4) return RT_E_INVALID;
     size_t recs = 4;                                            // the padding records at the end
     for (const auto& rf : s->mesh_refit) recs = std::max(recs, (size_t)rf.slot_base + (size_t)rf.slot_cap + 4);
     recs -= 4;
@@ -2818,7 +3070,6 @@ int rt_scene_destroy(RtScene* s)
     for (auto& rf : s->mesh_refit) (void)hipFree(rf.d_sched);
     (void)hipFree(s->d_refit_scratch);
     (void)hipFree(s->d_ex_scratch);
-    for (void* r : s->view.retired) (void)hipFree(r);
     for (auto& sl : s->view.slot) if (sl.done) (void)hipEventDestroy(sl.done);
     (void)hipFree(s->d_records); (void)hipFree(s->d_tri_uv); (void)hipFree(s->d_tri_id);
     (void)hipFree(s->d_leaf_count); (void)hipFree(s->d_mesh_flags); (void)hipFree(s->d_instances); (void)hipFree(s->d_materials);
@@ -2837,12 +3088,39 @@ int rt_scene_info(const RtScene* s, size_t* device_bytes, int32_t* max_stack)
 
 int rt_scene_view_stats(RtScene* s, uint64_t* launches, uint64_t* fallbacks, uint64_t* grows, int32_t* slot_frames)
 {
-    if (!s) return RT_E_INVALID;
+    RT_SCENE_CALL(s);
     std::lock_guard<std::mutex> lock(s->view.m);
     if (launches) *launches = s->view.launches;
     if (fallbacks) *fallbacks = s->view.fallbacks;
     if (grows) *grows = s->view.grows;
     if (slot_frames) *slot_frames = s->view.slot_frames;
+    return RT_OK;
+}
+
+int rt_scene_reserve_views(RtScene* s, int32_t frames_per_launch)
+{
+    RT_SCENE_CALL(s);
+    if (frames_per_launch < 0 || frames_per_launch > kMaxBatch) return RT_E_INVALID;
+    RtScene::ViewPool& v = s->view;
+    view_decide(s);
+    if (!view_mode() || !v.usable) return RT_E_INVALID;         // (more than eight instances, or no interior records: this scene renders without views)
+    if (frames_per_launch == 0) { v.reserved = false; return RT_OK; }      // back to growing on demand (what is there stays)
+    if (frames_per_launch != v.slot_frames) {
+        const int rc = view_resize(s, frames_per_launch);
+        if (rc) return rc;
+    }
+    v.reserved = true;
+    return RT_OK;
+}
+
+int rt_scene_memory(RtScene* s, size_t* records_bytes, size_t* view_pool_bytes, size_t* device_bytes, int32_t* view_slots, int32_t* view_slot_frames)
+{
+    RT_SCENE_CALL(s);
+    if (records_bytes) *records_bytes = s->records_bytes;
+    if (view_pool_bytes) *view_pool_bytes = s->view.slot_frames > 0 ? (size_t)s->view.frame_records * 64 * (size_t)s->view.slots * (size_t)s->view.slot_frames : 0;
+    if (device_bytes) *device_bytes = s->device_bytes;
+    if (view_slots) *view_slots = s->view.slots;
+    if (view_slot_frames) *view_slot_frames = s->view.slot_frames;
     return RT_OK;
 }
 
@@ -2861,13 +3139,40 @@ int rt_scene_mesh_capacity(const RtScene* s, int32_t mesh_index, int32_t* max_tr
     return RT_OK;
 }
 
+// (every render entry point: the scene's call_mu is held while the launch is prepared and queued; a wait the caller asked for
+// happens after it has been released)
+#define RT_WAIT_IF(synchronize, stream) do { if (synchronize) RT_HIP(hipStreamSynchronize((hipStream_t)(stream))); } while (0)
+
 int rt_render_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_imgs, size_t pitch, int32_t count,
                     void* stream, int synchronize)
 {
+    {
+        RT_SCENE_CALL(s);
+        RenderParams p;
+        int rc = fill_params(p, s, cams, d_imgs, count, pitch);
+        if (rc) return rc;
+        if ((rc = launch(p, false, (hipStream_t)stream, 0, s))) return rc;
+    }
+    RT_WAIT_IF(synchronize, stream);
+    return RT_OK;
+}
+
+int rt_scene_loop_stats(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_imgs, size_t pitch, int32_t count, void* stream, uint64_t* stats)
+{
+    if (!stats) return RT_E_INVALID;
+    RT_SCENE_CALL(s);
     RenderParams p;
     int rc = fill_params(p, s, cams, d_imgs, count, pitch);
     if (rc) return rc;
-    return launch(p, false, (hipStream_t)stream, synchronize, s);
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+    unsigned long long* d = nullptr;
+    RT_HIP(hipMalloc((void**)&d, RT_LOOP_WORDS * sizeof(uint64_t)));
+    hipError_t e = hipMemsetAsync(d, 0, RT_LOOP_WORDS * sizeof(uint64_t), (hipStream_t)stream);
+    p.loop_stats = d;
+    if (e == hipSuccess) rc = launch(p, false, (hipStream_t)stream, 1, s, true);
+    if (e == hipSuccess && rc == RT_OK) e = hipMemcpy(stats, d, RT_LOOP_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e != hipSuccess ? (int)e : rc;
 }
 
 int rt_render(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, void* stream, int synchronize)
@@ -2878,6 +3183,7 @@ int rt_render(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitc
 // Camera::render_scene(scene, img, pitch, synchronize = false) on the default stream (Camera.cu:18-41) -- see rt_hip.h.
 int rt_render_overlapped(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch)
 {
+    RT_SCENE_CALL(s);
     RenderParams p;
     int rc = fill_params(p, s, cam, &d_img, 1, pitch);
     if (rc) return rc;
@@ -2946,29 +3252,40 @@ int rt_render_overlapped_stats(const RtScene* s, uint64_t* launches, uint64_t* c
 int rt_render_ids(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch, int32_t* d_hit_instance,
                   int32_t* d_hit_triangle, void* stream, int synchronize)
 {
-    RenderParams p;
-    int rc = fill_params(p, s, cam, &d_img, 1, pitch);
-    if (rc) return rc;
-    p.hit_instance = d_hit_instance; p.hit_triangle = d_hit_triangle;
-    return launch(p, false, (hipStream_t)stream, synchronize, s);        // (with the scene: the kernel whose ids are checked is the one that is timed, views included)
+    {
+        RT_SCENE_CALL(s);
+        RenderParams p;
+        int rc = fill_params(p, s, cam, &d_img, 1, pitch);
+        if (rc) return rc;
+        p.hit_instance = d_hit_instance; p.hit_triangle = d_hit_triangle;
+        if ((rc = launch(p, false, (hipStream_t)stream, 0, s))) return rc;   // (with the scene: the kernel whose ids are checked is the one that is timed, views included)
+    }
+    RT_WAIT_IF(synchronize, stream);
+    return RT_OK;
 }
 
 int rt_render_debug(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, size_t pitch,
                     const RtDebugPlanes* planes, void* stream, int synchronize)
 {
     if (!planes) return RT_E_INVALID;
-    RenderParams p;
-    int rc = fill_params(p, s, cam, &d_img, 1, pitch);
-    if (rc) return rc;
-    p.hit_instance = planes->hit_instance; p.hit_triangle = planes->hit_triangle; p.node_pops = planes->node_pops;
-    p.aabb_tests = planes->aabb_tests; p.tri_tests = planes->tri_tests; p.inside_hits = planes->inside_hits;
-    return launch(p, true, (hipStream_t)stream, synchronize);
+    {
+        RT_SCENE_CALL(s);
+        RenderParams p;
+        int rc = fill_params(p, s, cam, &d_img, 1, pitch);
+        if (rc) return rc;
+        p.hit_instance = planes->hit_instance; p.hit_triangle = planes->hit_triangle; p.node_pops = planes->node_pops;
+        p.aabb_tests = planes->aabb_tests; p.tri_tests = planes->tri_tests; p.inside_hits = planes->inside_hits;
+        if ((rc = launch(p, true, (hipStream_t)stream, 0))) return rc;
+    }
+    RT_WAIT_IF(synchronize, stream);
+    return RT_OK;
 }
 
 // Samples are rendered in chunks of as many sample indices as fit the scratch budget: per chunk either one
 // render_ex_kernel launch with grid.y = chunk (samples only, or RT_EX_WAVEFRONT=0), or the wavefront sequence of
 // ex_wave_kernel launches; then one resolve_ex_kernel.
 constexpr size_t kExScratchBudget = (size_t)2 << 30;           // per-lane form: 16 B per path
+constexpr size_t kExSplitBudget = (size_t)5 << 30;             // two-launch bounce form: 32 B per (pixel, sample) of a chunk of workgroups
 constexpr size_t kExWaveScratchBudget = (size_t)16 << 30;      // wavefront form: 16 B + (7 + 3 x 5) x 16 B of queue room per path
 
 static int ex_env_int(const char* name, int fallback)
@@ -2997,7 +3314,21 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
     const bool pixel_waves = !wavefront && !trace_file && p.spp >= 4 && ex_env_int("RT_EX_PIXEL_WAVES", 1) != 0;
     if (pixel_waves) {
         const bool many = p.spp > 64;                                               // several launches: running sums in ex_acc
-        const size_t need = many ? npix * sizeof(float4) : 0;
+        // bounces / lighting: the camera ray in a launch of its own (render_ex_kernel<.., PHASE>; RT_EX_SPLIT=0: the one-kernel form),
+        // in chunks of workgroups whose records -- 2 KB per one-wave workgroup -- fit the scratch budget (c3: all 2 073 600 waves at once, 4.2 GB)
+        const bool split = !simple && ex_env_int("RT_EX_SPLIT", 1) != 0;
+        const size_t per_wg = (size_t)kExBlock * 2 * sizeof(float4);
+        size_t split_chunk = 0;
+        if (split) {
+            size_t budget = kExSplitBudget;
+            if (const char* e = getenv("RT_EX_SPLIT_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);           // tests: force several chunks
+            int slots0 = 4;
+            while (slots0 < std::min(64, p.spp)) slots0 <<= 1;
+            const int ppw0 = 64 / slots0, pw0 = ppw0 >= 16 ? 4 : (ppw0 >= 4 ? 2 : (ppw0 >= 2 ? 2 : 1)), ph0 = ppw0 / pw0;
+            const size_t wgs0 = (size_t)((p.width + 2 * pw0 - 1) / (2 * pw0)) * (size_t)((p.local_rows + 2 * ph0 - 1) / (2 * ph0)) * 4;   // the first (largest) launch
+            split_chunk = std::max<size_t>(4, std::min(wgs0, budget / per_wg) & ~(size_t)3);
+        }
+        const size_t need = (many ? npix * sizeof(float4) : 0) + split_chunk * per_wg;
         if (s->ex_scratch_bytes < need) {
             (void)hipFree(s->d_ex_scratch);                                         // (synchronises with renders in flight)
             s->d_ex_scratch = nullptr; s->ex_scratch_bytes = 0;
@@ -3026,7 +3357,20 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
             p.tiles_x = (p.width + 2 * p.px_pw - 1) / (2 * p.px_pw);
             p.tiles_y = (p.local_rows + 2 * p.px_ph - 1) / (2 * p.px_ph);
             const dim3 grid((unsigned)((size_t)p.tiles_x * p.tiles_y * 4));         // four one-wave workgroups per tile
-            if (simple && view_slot >= 0) hipLaunchKernelGGL((render_ex_kernel<true, true, true>), grid, dim3(kExBlock), lds, stream, p);
+            if (split) {
+                const size_t chunk = split_chunk;
+                p.ex_rec = s->d_ex_scratch + (many ? npix : 0);
+                p.ex_rec_lanes = (uint32_t)(chunk * kExBlock);
+                for (size_t wg0 = 0; wg0 < grid.x; wg0 += chunk) {
+                    const dim3 part((unsigned)std::min(chunk, (size_t)grid.x - wg0));
+                    p.wg_base = (int32_t)wg0;
+                    if (view_slot >= 0) hipLaunchKernelGGL((render_ex_kernel<false, true, true, 1>), part, dim3(kExBlock), lds, stream, p);
+                    else hipLaunchKernelGGL((render_ex_kernel<false, true, false, 1>), part, dim3(kExBlock), lds, stream, p);
+                    hipLaunchKernelGGL((render_ex_kernel<false, true, false, 2>), part, dim3(kExBlock), lds, stream, p);
+                }
+                p.wg_base = 0;
+            }
+            else if (simple && view_slot >= 0) hipLaunchKernelGGL((render_ex_kernel<true, true, true>), grid, dim3(kExBlock), lds, stream, p);
             else if (simple) hipLaunchKernelGGL((render_ex_kernel<true, true>), grid, dim3(kExBlock), lds, stream, p);
             else if (view_slot >= 0) hipLaunchKernelGGL((render_ex_kernel<false, true, true>), grid, dim3(kExBlock), lds, stream, p);
             else hipLaunchKernelGGL((render_ex_kernel<false, true>), grid, dim3(kExBlock), lds, stream, p);
@@ -3131,23 +3475,33 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
 int rt_render_ex(RtScene* s, const RtCameraParams* cam, const RtRenderOptions* opts, uint8_t* d_img, size_t pitch,
                  int32_t* d_total_pops, void* stream, int synchronize)
 {
-    RenderParams p;
-    int rc = fill_params(p, s, cam, &d_img, 1, pitch);
-    if (rc) return rc;
-    return launch_ex(s, p, opts, d_total_pops, (hipStream_t)stream, synchronize);
+    {
+        RT_SCENE_CALL(s);
+        RenderParams p;
+        int rc = fill_params(p, s, cam, &d_img, 1, pitch);
+        if (rc) return rc;
+        if ((rc = launch_ex(s, p, opts, d_total_pops, (hipStream_t)stream, 0))) return rc;
+    }
+    RT_WAIT_IF(synchronize, stream);
+    return RT_OK;
 }
 
 int rt_render_ex_stripes(RtScene* s, const RtCameraParams* cam, const RtRenderOptions* opts, uint8_t* d_local, size_t local_pitch,
                          int32_t stripe_rows, int32_t rank, int32_t num_ranks, void* stream, int synchronize)
 {
-    RenderParams p;
-    int rc = fill_params(p, s, cam, &d_local, 1, local_pitch);
-    if (rc) return rc;
-    int32_t rows = 0;
-    if ((rc = rt_stripe_rows(p.height, stripe_rows, rank, num_ranks, &rows))) return rc;
-    p.local_rows = rows; p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
-    p.frames[0].rank = rank; p.frames[0].local_rows = rows;
-    return launch_ex(s, p, opts, nullptr, (hipStream_t)stream, synchronize);
+    {
+        RT_SCENE_CALL(s);
+        RenderParams p;
+        int rc = fill_params(p, s, cam, &d_local, 1, local_pitch);
+        if (rc) return rc;
+        int32_t rows = 0;
+        if ((rc = rt_stripe_rows(p.height, stripe_rows, rank, num_ranks, &rows))) return rc;
+        p.local_rows = rows; p.stripe_rows = stripe_rows; p.rank = rank; p.num_ranks = num_ranks;
+        p.frames[0].rank = rank; p.frames[0].local_rows = rows;
+        if ((rc = launch_ex(s, p, opts, nullptr, (hipStream_t)stream, 0))) return rc;
+    }
+    RT_WAIT_IF(synchronize, stream);
+    return RT_OK;
 }
 
 int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t* rows)
@@ -3164,6 +3518,8 @@ int rt_stripe_rows(int32_t height, int32_t stripe_rows, int32_t rank, int32_t nu
 static int render_stripes_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_locals, size_t local_pitch, int32_t count,
                                 int32_t stripe_rows, int32_t rank, int32_t num_ranks, int32_t first_frame, void* stream, int synchronize)
 {
+    {
+    RT_SCENE_CALL(s);
     RenderParams p;
     int rc = fill_params(p, s, cams, d_locals, count, local_pitch);
     if (rc) return rc;
@@ -3179,7 +3535,10 @@ static int render_stripes_batch(RtScene* s, const RtCameraParams* cams, uint8_t*
         most = std::max(most, f.local_rows);
     }
     p.local_rows = most;                                        // the grid covers the tallest frame; shorter ones leave their last tiles empty
-    return launch(p, false, (hipStream_t)stream, synchronize, s);
+    if ((rc = launch(p, false, (hipStream_t)stream, 0, s))) return rc;
+    }
+    RT_WAIT_IF(synchronize, stream);
+    return RT_OK;
 }
 
 int rt_render_stripes_batch(RtScene* s, const RtCameraParams* cams, uint8_t* const* d_locals, size_t local_pitch, int32_t count,

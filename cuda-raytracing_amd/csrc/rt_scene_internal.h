@@ -12,6 +12,11 @@ using rt::DevInstance;
 using rt::DevMaterial;
 
 struct RtScene {
+    // Every entry point that reads or replaces the scene's device arrays holds this from its first look at them until its last kernel
+    // is queued (never across a wait for the device, except where a call's contract is to block: growth of the view pool, scratch
+    // re-allocation): calls on one scene from several host threads are serialised on the HOST side only -- a launch is a few
+    // microseconds -- and their GPU work overlaps as their streams allow.  Recursive: rt_render -> rt_render_batch, rt_render_tiled -> ...
+    std::recursive_mutex call_mu;
     int device = 0;
     float4* d_records = nullptr;                 // interior-node and triangle records, one index space
     float* d_tri_uv = nullptr;
@@ -58,7 +63,9 @@ struct RtScene {
         uint64_t last_used = 0;
         uint64_t launches = 0, sorted_at = 0;    // ordered launches of this size so far / at the last sort issued
         // the last ordered launch on each stream that uses this state (a sort waits for all of them)
-        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; uint64_t tick = 0; } seen[4];
+        // (done = recorded behind the stream's launches when a sort is issued or the slot is wanted for another stream; dirty = the
+        // stream has launched since)
+        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false, dirty = false; uint64_t tick = 0; } seen[4];
     };
     // rt_render_overlapped (Camera::render_scene's asynchronous default-stream form): two library-owned BLOCKING streams that
     // consecutive frames alternate between, so that the next frame's costly tiles fill the chip while the previous frame's
@@ -82,19 +89,25 @@ struct RtScene {
     // launch qualifies, and when a launch brings more frames than a slot holds), so that a lane's fetch stays one 32-bit
     // offset from one base whether it reads a triangle or a view record.  A slot = the views of the frames of one launch;
     // a slot is reused by launches on the stream it was last used on (stream order) or once its event has completed.
+    // Round 6: the pool is sized by rt_scene_reserve_views (an application that batches says so once, after upload) or, without that,
+    // grows to the batch sizes actually seen (4, 8, 16, 32 frames per slot) inside the first launch that needs more -- a call that then
+    // blocks until the device is idle (documented at rt_render_batch).  One to three slots, as many as fit the budget
+    // (RT_VIEW_MAX_BYTES, default 1 GiB).  The block it replaces is freed at once: call_mu keeps other launches of the scene out and
+    // the device has been drained, so nothing can still read it.
     struct ViewPool {
-        std::mutex m;
+        std::mutex m;                            // (statistics only: the pool itself is protected by RtScene::call_mu)
         bool decided = false, usable = false;    // static eligibility of the scene (instances, sizes), decided at the first launch
         int32_t frame_records = 0;               // interior-record capacity of all instances = records of one frame's view
         std::vector<int32_t> inst_first;         // per instance: first view record within a frame's view
         size_t base_bytes = 0;                   // byte offset of the pool from d_records
         int32_t slot_frames = 0;                 // frames a slot holds (0 = no pool yet)
+        int32_t slots = 0;                       // slots of the pool (1..3)
+        bool reserved = false;                   // sized by rt_scene_reserve_views: launches never grow it
         struct Slot { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false; } slot[3];
-        std::vector<void*> retired;              // earlier d_records blocks: freed with the scene (a launch prepared on another
-                                                 // thread may still carry the pointer)
         uint64_t launches = 0, fallbacks = 0, grows = 0;
     } view;
     size_t records_bytes = 0;                    // size of the record array proper (the head of the d_records allocation)
+    size_t records_alloc_bytes = 0;              // size of the d_records allocation: records, padding, view pool
     struct TileOrderCache {
         std::mutex m;
         hipStream_t sort_stream = nullptr;

@@ -146,6 +146,76 @@ def write_atrium_obj(path, seed=4321, cols_x=6, cols_y=10, col_seg=48, col_rings
     return len(faces)
 
 
+def _write_grids_obj(path, comment, grids):
+    """grids: list of (P[rows+1, cols+1, 3], U, V, flip) -- independent tessellated sheets in one OBJ; (a b c)(b d c) per quad when
+    flipped, (a c b)(b c d) otherwise (a = row j col i, b = a + 1, c = a + cols + 1, d = c + 1)."""
+    out = ["# %s\n" % comment]
+    faces, base = [], 0
+    for P, U, V, flip in grids:
+        rows, cols = P.shape[0] - 1, P.shape[1] - 1
+        out.extend("v %.6f %.6f %.6f\n" % tuple(r) for r in P.reshape(-1, 3).tolist())
+        jj, ii = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+        a = (base + jj * (cols + 1) + ii + 1).ravel()
+        b, c = a + 1, a + cols + 1
+        d = c + 1
+        faces.append(np.stack([a, b, c, b, d, c] if flip else [a, c, b, b, c, d], -1).reshape(-1, 3))
+        base += P.shape[0] * P.shape[1]
+    for P, U, V, flip in grids:
+        out.extend("vt %.6f %.6f\n" % tuple(r) for r in np.stack([U, V], -1).reshape(-1, 2).tolist())
+    faces = np.concatenate(faces)
+    out.extend("f %d/%d %d/%d %d/%d\n" % (q[0], q[0], q[1], q[1], q[2], q[2]) for q in faces.tolist())
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        f.writelines(out)
+    os.replace(tmp, path)
+    return len(faces)
+
+
+def write_demo_objs(area_path, board_path, offset=(0.0, 0.0, 0.0), seed=99):
+    """Stand-ins for the two meshes of the reference's demo (kernel.cu:209-210: calibration_area.obj and calibration_board.obj are
+    not in the repository): a "calibration area" -- a floor and three walls, open towards the demo camera at (-1, -4, 2), slightly
+    uneven so that the tree is not degenerate -- of 32 768 triangles, and a "calibration board" -- an upright 1.2 m x 0.9 m sheet
+    facing -y, 3 456 triangles -- in its own coordinates; the demo places it with MeshInstance::pose = (-0.6, 1.48, 0.73)
+    (kernel.cu:229-232).  offset: added to the board's vertices (the baked twin of the scene: the same board as an identity instance)."""
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(0, 6.28, 8)
+    n = 64
+    s = np.linspace(0, 1, n + 1)
+    S, T = np.meshgrid(s, s, indexing="xy")
+    bump = lambda A, B, k: 0.02 * np.sin(11 * A + ph[k]) * np.sin(9 * B + ph[k + 1])
+    X0, X1, Y0, Y1, Z1 = -4.0, 4.0, -1.0, 7.0, 3.0
+    grids = [
+        (np.stack([X0 + S * (X1 - X0), Y0 + T * (Y1 - Y0), bump(S, T, 0)], -1), S, T, True),                      # floor, normal +z
+        (np.stack([X0 + S * (X1 - X0), Y1 + bump(S, T, 2), T * Z1], -1), S, T, True),                             # back wall, normal -y
+        (np.stack([X0 + bump(S, T, 4), Y0 + S * (Y1 - Y0), T * Z1], -1), S, T, True),                             # left wall, normal +x
+        (np.stack([X1 + bump(S, T, 6), Y0 + S * (Y1 - Y0), T * Z1], -1), S, T, False)]                            # right wall, normal -x
+    n_area = _write_grids_obj(area_path, "synthetic calibration area", grids)
+    u = np.linspace(0, 1, 49)
+    v = np.linspace(0, 1, 37)
+    U, V = np.meshgrid(u, v, indexing="xy")
+    board = np.stack([(U - 0.5) * 1.2 + offset[0], 0.0 * U + offset[1], (V - 0.5) * 0.9 + offset[2]], -1)
+    n_board = _write_grids_obj(board_path, "synthetic calibration board", [(board, U, V, True)])
+    return n_area, n_board
+
+
+def demo_textures(seed=5):
+    """BGR stand-ins for calibration_area.jpg / calibration_board.jpg (kernel.cu:192,204): a tiled, shaded pattern and a 9 x 7 checkerboard."""
+    rng = np.random.default_rng(seed)
+    h, w = 1024, 1024
+    yy, xx = np.mgrid[0:h, 0:w]
+    area = np.zeros((h, w, 3), np.uint8)
+    tile = ((xx // 64 + yy // 64) % 2).astype(np.uint8)
+    area[..., 0] = 60 + 120 * tile + (xx * 60 // w)
+    area[..., 1] = 90 + 100 * (1 - tile) + (yy * 50 // h)
+    area[..., 2] = 140 + rng.integers(0, 40, (h, w), dtype=np.uint8)
+    bh, bw = 540, 720
+    yy, xx = np.mgrid[0:bh, 0:bw]
+    sq = (((xx * 9) // bw + (yy * 7) // bh) % 2).astype(np.uint8)
+    board = np.repeat((30 + 210 * sq)[..., None], 3, -1).astype(np.uint8)
+    board[:6, :, :] = 200; board[-6:, :, :] = 200; board[:, :6, :] = 200; board[:, -6:, :] = 200
+    return area, board
+
+
 def write_single_triangle_obj(path):
     """Config C1 geometry as an OBJ (the C1 fixture itself uses the 3-vertex ctor)."""
     with open(path, "w") as f:
@@ -170,4 +240,10 @@ C5 = dict(C3, width=7680, height=4320)
 # c6: the HBM regime.  The atrium generator at 16 x the triangle count of c4 (4 073 472 triangles: 395 MB of 64-B records, more
 # than the 256 MiB Infinity Cache; most triangles are smaller than a pixel at 4K), same camera, 1 primary ray per pixel.
 C6 = dict(C4, spp=1, atrium=dict(col_seg=192, col_rings=100, wall_div=384), n_tris=4073472)
-WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5, "c6": C6}
+# demo: the shape of the ONLY scene the reference itself renders (kernel.cu:155-240): two OBJ meshes, two textured materials, the
+# second instance translated by (-0.6, 1.48, 0.73), camera at (-1, -4, 2) with K / D of kernel.cu:158-164, 1920x1080, 1 ray per pixel.
+# The assets are not in the repository: write_demo_objs / demo_textures are deterministic stand-ins.  `baked` = the twin scene with the
+# translation folded into the board's vertices and an identity instance (what the translated instance is compared with).
+DEMO = dict(width=1920, height=1080, D=D_REF, albedo=(1.0, 1.0, 1.0), cam_pose=(-1.0, -4.0, 2.0, 0.0, 0.0, 0.0),
+            board_pose=(-0.6, 1.48, 0.73, 0.0, 0.0, 0.0), n_tris=32768 + 3456)
+WORKLOADS = {"c2": C2, "c3": C3, "c4": C4, "c5": C5, "c6": C6, "demo": DEMO}

@@ -76,6 +76,21 @@ def rotating_plan(count, world):
     return slots, counts, offsets, real
 
 
+def sub_groups(count, world, parts=4):
+    """A group of `count` frames that is rendered between two synchronises ON ITS OWN (the driver's `--steps 20`) as a pipeline of
+    sub-groups: [(first frame, frames)] -- at most `parts` of them, as even as possible, none smaller than the rank count (a
+    rotating-root exchange moves at least one frame slot per rank; smaller sub-groups would carry stale slots).  The exchange of
+    sub-group k then runs beside the render of k + 1, and only the last sub-group's exchange and un-stripe pass are left exposed
+    behind the render.  20 frames: 8 ranks -> 10 + 10, 4 or 2 ranks -> 4 x 5."""
+    n = max(1, min(parts, count // max(world, 1)))
+    out, first = [], 0
+    for j in range(n):
+        c = count // n + (1 if j < count % n else 0)
+        out.append((first, c))
+        first += c
+    return out
+
+
 # ---- the exchange step ----------------------------------------------------------------------------------
 # to_root(local, gathered, root):   every rank's `local` [rows, pitch] to rank `root`, whose `gathered`
 #                                   [world, rows, pitch] receives rank r's block at index r (None elsewhere)
@@ -230,7 +245,7 @@ class StripePipeline:
         if self.comm is not None:
             self.comm.synchronize()
 
-    def stage_times(self):
+    def stage_times(self, groups_per_region=0):
         """Mean milliseconds per timed group of each stage, after drain():
         wait_for_buffer (the compute stream idle until group i - 2 had left the buffer set), render, exchange (from the end
         of the render: includes any wait for the comm stream to finish the previous group), unstripe, and group_span (first
@@ -246,6 +261,26 @@ class StripePipeline:
             d = [[m[k].elapsed_time(m[k + 1]) for k in range(4)] for m in self._marks]
         n = float(len(d))
         mean = [sum(row[k] for row in d) / n for k in range(4)]
-        return {"groups_timed": len(d), "wait_for_buffer_ms": round(mean[0], 4), "render_ms_per_group": round(mean[1], 4),
-                "exchange_ms_per_group": round(mean[2], 4), "unstripe_ms_per_group": round(mean[3], 4),
-                "group_span_ms": round(sum(mean), 4)}
+        out = {"groups_timed": len(d), "wait_for_buffer_ms": round(mean[0], 4), "render_ms_per_group": round(mean[1], 4),
+               "exchange_ms_per_group": round(mean[2], 4), "unstripe_ms_per_group": round(mean[3], 4),
+               "group_span_ms": round(sum(mean), 4)}
+        # How much of group k's exchange + un-stripe pass ran INSIDE the render of group k + 1 (same timed region: groups_per_region
+        # consecutive groups between two synchronises): the interval [render end of k, un-stripe end of k] against [render start,
+        # render end] of k + 1.  1.0 = the exchange is hidden, 0 = it ran on its own.
+        if groups_per_region > 1:
+            fr, lens = [], []
+            for k in range(len(self._marks) - 1):
+                if (k + 1) % groups_per_region == 0:
+                    continue                                    # (the next group belongs to the next region: a synchronise lies between)
+                a, b = self._marks[k], self._marks[k + 1]
+                if self.comm is None:
+                    ex_end, r0, r1 = (a[4] - a[2]) * 1e3, (b[1] - a[2]) * 1e3, (b[2] - a[2]) * 1e3
+                else:
+                    ex_end, r0, r1 = a[2].elapsed_time(a[4]), a[2].elapsed_time(b[1]), a[2].elapsed_time(b[2])
+                if ex_end > 0:
+                    fr.append(max(0.0, min(ex_end, r1) - max(0.0, r0)) / ex_end)
+                    lens.append(ex_end)
+            if fr:
+                out["exchange_inside_next_render_frac"] = round(sum(fr) / len(fr), 4)
+                out["exchange_plus_unstripe_ms"] = round(sum(lens) / len(lens), 4)
+        return out

@@ -20,7 +20,7 @@
  * RT_RCCL_LIBRARY=<path> makes rt_comm_* load that library instead of librccl.so.1 (tests: an in-process mock); if it cannot
  * be loaded or lacks an entry point, rt_comm_* fail with RT_E_COMM (rt_comm_last_error() has the loader's message);
  * RT_RENDER_OVERLAP=0 makes rt_render_overlapped a plain default-stream launch; RT_TILE_SORT_INTERVAL=<n> sorts a new heavy-first
- * order every n-th single-frame launch (default 4); while RT_TEST_FAIL_UPLOAD=1 is set every rt_scene_upload fails with
+ * order every n-th single-frame launch (default 4: the events that order a sort behind the launches it must wait for are recorded only then); while RT_TEST_FAIL_UPLOAD=1 is set every rt_scene_upload fails with
  * RT_E_NOMEM before it touches anything (tests of the callers' error paths).
  */
 #ifndef RT_HIP_H
@@ -212,16 +212,54 @@ int rt_render_overlapped_stats(const RtScene *scene, uint64_t *launches, uint64_
 /* View records (round 5; no counterpart in the reference, whose kernel subtracts the ray origin from every box at every visit,
  * BVHTree.hpp:40-54 through raycast.cu:69-70): launches of at least four frames whose frames bring enough rays first write, per
  * frame and instance, the interior records with `box - origin` in place of the boxes (the same fp32 subtraction, done once), and
- * the traversal reads those.  The library keeps them behind the scene's records (the record array is re-allocated with a pool
- * of three launches' views the first time a launch qualifies, and when a launch brings more frames than the pool was sized for:
- * a device-wide synchronise, at most three times in a scene's life).  Nothing in a frame depends on it; RT_VIEW_RECORDS=0 turns
- * it off.  This reports how many launches qualified, how many of those rendered without views after all (no free slot: more than
- * three launches in flight on different streams; no memory), how often the pool grew, and the frames a slot holds now; any
- * pointer may be NULL. */
+ * the traversal reads those.  Nothing in a frame depends on it; RT_VIEW_RECORDS=0 turns it off.
+ * MEMORY AND BLOCKING (round 6).  The views live behind the scene's records in ONE allocation (a lane's fetch stays one 32-bit offset
+ * from one base): a pool of one to three slots (launches in flight on different streams), each of `frames` views of
+ * 64 B x (interior-record capacity of the largest mesh) x instances -- for the 70k-triangle c2 scene 4.2 MB per frame, 403 MB for three
+ * slots of 32 frames beside 8.7 MB of records; for a 260k-triangle mesh 16.7 MB per frame.  The pool never exceeds RT_VIEW_MAX_BYTES
+ * (default 1 GiB; slots are dropped, three -> two -> one, before frames are); a launch that finds no room or no free slot renders
+ * without views -- same pixels (`fallbacks` below).
+ *   - An application that batches says so once: rt_scene_reserve_views(scene, frames_per_launch) right after rt_scene_upload sizes
+ *     the pool for launches of up to that many frames (it re-allocates the record array: call it while nothing renders the scene).
+ *     Launches never grow a reserved pool: no render call blocks.  frames_per_launch = 0 hands sizing back to the launches.
+ *     RT_E_NOMEM: not within the budget; RT_E_INVALID: the scene cannot use views (more than eight instances, RT_VIEW_RECORDS=0).
+ *   - Without a reservation the pool grows inside the first qualifying launch that brings more frames than a slot holds, to the
+ *     next of 4 / 8 / 16 / 32 frames: THAT CALL BLOCKS until the device is idle (hipDeviceSynchronize: every stream of the process),
+ *     allocates, copies the records and frees the block they were in -- at most four times in a scene's life.  Render calls are
+ *     otherwise asynchronous.
+ * rt_scene_view_stats reports how many launches qualified, how many of those rendered without views after all, how often the pool
+ * was (re)sized, and the frames a slot holds now; rt_scene_memory the bytes: the record array proper, the pool behind it, everything
+ * the scene holds on the device, and the pool's shape.  Any pointer may be NULL. */
+int rt_scene_reserve_views(RtScene *scene, int32_t frames_per_launch);
+int rt_scene_memory(RtScene *scene, size_t *records_bytes, size_t *view_pool_bytes, size_t *device_bytes, int32_t *view_slots,
+                    int32_t *view_slot_frames);
 int rt_scene_view_stats(RtScene *scene, uint64_t *launches, uint64_t *fallbacks, uint64_t *grows, int32_t *slot_frames);
+/* Which traversal loop ran (round 6; diagnostics, no counterpart in the reference).  The primary kernel picks, per wave and
+ * instance, the hand-written gfx950 loop (any instance without the exact-uv mode, when the wave's rays share a sign octant and
+ * the mesh's boxes are ordered), the compiler's octant-specialised loop, or the compiler's generic loop; a tree deeper than the LDS
+ * part of the stack is traversed optimistically and the lanes that outgrow it are traced again on the general stack.  Parity tests
+ * pass on any of them, so a change that pushes a scene off the fast loop would only show as a slower frame: this call renders the
+ * batch exactly as rt_render_batch would (same launch decisions: stack form, view records) through an INSTRUMENTED copy of the
+ * kernel -- never the timed one -- waits for it, and fills stats[RT_LOOP_WORDS] (host): counts of waves x instances per loop.
+ * The frames are written as by rt_render_batch. */
+enum {
+    RT_LOOP_WAVES = 0,          /* waves that rendered at least one pixel */
+    RT_LOOP_ASM = 1,            /* wave x instance casts on the hand-written loop ... */
+    RT_LOOP_ASM_POSED = 2,      /* ... of which: instances that scale or rotate (the candidate block's out-of-line transform) */
+    RT_LOOP_CPP_OCTANT = 3,     /* casts on the compiler's octant-specialised loop (exact-uv meshes) */
+    RT_LOOP_CPP_GENERIC = 4,    /* casts on the compiler's generic loop (mixed octants in the wave, zero / non-finite direction inverses, unordered boxes) */
+    RT_LOOP_DEEP = 5,           /* casts traced again on the general stack (some lane outgrew the LDS part) */
+    RT_LOOP_RETRACED_LANES = 6, /* rays (lanes) traced again */
+    RT_LOOP_WORDS = 8
+};
+int rt_scene_loop_stats(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_imgs, size_t pitch, int32_t count,
+                        void *stream, uint64_t *stats);
 /* `count` (1..RT_MAX_BATCH) frames of the same size in ONE launch: cams[i] is rendered into d_imgs[i].  A frame
  * stream rendered this way keeps the GPU full while the last long rays of one frame finish (the reference's own
- * loop issues two renders before it synchronises, kernel.cu:277-279). */
+ * loop issues two renders before it synchronises, kernel.cu:277-279).  Asynchronous on `stream`, with one exception: a launch of four
+ * or more frames that has to grow the scene's view pool blocks until the device is idle (see rt_scene_reserve_views, which avoids it).
+ * Host threads: calls on ONE scene are serialised while they prepare and queue their launch (a few microseconds; the GPU work of
+ * different streams still overlaps); different scenes do not meet. */
 #define RT_MAX_BATCH 32
 int rt_render_batch(RtScene *scene, const RtCameraParams *cams, uint8_t *const *d_imgs, size_t pitch, int32_t count,
                     void *stream, int synchronize);

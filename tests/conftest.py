@@ -81,3 +81,13 @@ def atrium_c6(scenes, cache_dir):
     if not os.path.exists(p):
         scenes.write_atrium_obj(p, **scenes.C6["atrium"])
     return p
+
+
+@pytest.fixture(scope="session")
+def demo_objs(scenes, cache_dir):
+    """bench.py --workload demo: (area, board, board with the demo's translation baked in) -- stand-ins for kernel.cu:209-210"""
+    ps = tuple(os.path.join(cache_dir, n) for n in ("demo_area.obj", "demo_board.obj", "demo_board_baked.obj"))
+    if not all(os.path.exists(q) for q in ps):
+        scenes.write_demo_objs(ps[0], ps[1])
+        scenes.write_demo_objs(ps[0], ps[2], offset=scenes.DEMO["board_pose"][:3])
+    return ps

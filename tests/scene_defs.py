@@ -140,3 +140,12 @@ def shiny_scene(scenes, blob_path):
 
 
 SHINY_CAMERA = dict(width=240, height=136, pose=(0.3, -3.2, 0.9, 0.05, -0.2, 0.0))
+
+
+def demo_scene(scenes, objs, baked=False):
+    """The reference demo's scene shape (kernel.cu:166-240; bench.py --workload demo): two OBJ meshes, two textured materials, the
+    second instance translated by (-0.6, 1.48, 0.73) -- or, baked, the same board as an identity instance."""
+    area_tex, board_tex = scenes.demo_textures()
+    w = scenes.DEMO
+    return SceneDesc([(w["albedo"], area_tex), (w["albedo"], board_tex)], [("obj", objs[0]), ("obj", objs[2] if baked else objs[1])],
+                     [(0, 0, (0,) * 6, (1, 1, 1)), (1, 1, (0,) * 6 if baked else w["board_pose"], (1, 1, 1))])

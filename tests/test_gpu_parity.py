@@ -466,7 +466,7 @@ def test_view_records(rt, orc, scenes, blob5k):
     """Round 5: launches of four and more frames render through VIEW records -- per frame and instance the interior records with
     `box - origin` in place of the boxes, written once by a pre-pass into a pool behind the scene's records (rt_scene_view_stats).
     Frames must not change: batches against single-frame launches (which take no views) and the oracle; the pool grows from 4 to
-    32 frames per slot (the record array moves); an instance moved between two batches; a mesh refitted after the array has moved;
+    16 frames per slot (the record array moves; round 6: to the batch sizes seen, not straight to 32); an instance moved between two batches; a mesh refitted after the array has moved;
     more launches in flight on different streams than the pool has slots (the extra ones render without views)."""
     import torch
     W, H = 400, 240                             # (a frame must bring eight rays per view record: 10 297 records in the second scene)
@@ -486,7 +486,7 @@ def test_view_records(rt, orc, scenes, blob5k):
             assert np.array_equal(singles[k], so.render(W, H, K, scenes.D_REF, poses[k], planes=False)["img"])
         so.close()
         bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(32)]
-        for n, slot_frames, grows in ((4, 4, 1), (3, 4, 1), (9, 32, 2), (4, 32, 2)):
+        for n, slot_frames, grows in ((4, 4, 1), (3, 4, 1), (9, 16, 2), (4, 16, 2)):
             cam.render_scene_batch(sp, poses[:n], [b.ptr for b in bufs[:n]], bufs[0].pitch, synchronize=True)
             st = sp.view_stats()
             if n >= 4:
@@ -542,6 +542,92 @@ def test_view_records(rt, orc, scenes, blob5k):
     cam.render_scene_batch(sp, poses[:4], [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)
     assert np.array_equal(bufs[1].to_host().reshape(H, W, 3), want)
     assert sp.view_stats()["launches"] == 2 and sp.view_stats()["fallbacks"] == 0
+
+
+def test_view_pool_reserved_bounded_and_accounted(rt, scenes, blob5k):
+    """Round 6: rt_scene_reserve_views sizes the pool once, after upload -- launches then never grow it (no render
+    call blocks), a launch of more frames than reserved renders without views; handing sizing back lets the pool grow, and the block
+    it leaves is freed: the scene's device bytes are records + pool again.  Two streams batch while a third renders single frames."""
+    import torch
+    W, H = 400, 240
+    K = scenes.scaled_K(W)
+    poses = [(0.05 * i, -1.5 - 0.1 * i, 0.2 + 0.02 * i, 0.02 * i, -0.01 * i, 0.0) for i in range(16)]
+    sp = sd.blob_scene(scenes, blob5k).build_product(rt)
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    singles = []
+    for ps in poses:
+        cam.set_pose(ps)
+        singles.append(rt.render_ids(sp, cam)["img"])
+    m0 = sp.memory()
+    assert m0["view_pool_bytes"] == 0 and m0["view_slots"] == 0 and m0["device_bytes"] == sp.info()["device_bytes"]
+    sp.reserve_views(8)
+    m1 = sp.memory()
+    frame_bytes = m1["view_pool_bytes"] // (3 * 8)
+    assert (m1["view_slots"], m1["view_slot_frames"]) == (3, 8) and frame_bytes * 24 == m1["view_pool_bytes"] and frame_bytes % 64 == 0
+    assert 0 <= m1["device_bytes"] - m0["device_bytes"] - m1["view_pool_bytes"] < 256, (m0, m1)          # (the pool starts on a 256-byte boundary)
+    assert sp.view_stats()["grows"] == 1
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    cams = [rt.Camera(W, H, K, scenes.D_REF) for _ in streams]
+    for c, st in zip(cams, streams):
+        c.set_stream(st.cuda_stream)
+    sets = [[rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(8)] for _ in range(2)]
+    one = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+    batches = 0
+    for rep in range(6):
+        for k in range(2):
+            cams[k].render_scene_batch(sp, poses[rep:rep + 8], [b.ptr for b in sets[k]], sets[k][0].pitch)
+            batches += 1
+        for j in range(3):                                      # single frames on the third stream, beside the batches
+            cams[2].set_pose(poses[rep + j])
+            cams[2].render_scene(sp, one.ptr, one.pitch)
+        torch.cuda.synchronize()
+        assert np.array_equal(one.to_host().reshape(H, W, 3), singles[rep + 2])
+        for bs in sets:
+            for i, b in enumerate(bs):
+                assert np.array_equal(b.to_host().reshape(H, W, 3), singles[rep + i]), (rep, i)
+    st = sp.view_stats()
+    assert (st["launches"], st["fallbacks"], st["grows"], st["slot_frames"]) == (batches, 0, 1, 8), st
+    # more frames than reserved: no growth, no views, the right frames
+    nine = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(9)]
+    cam.render_scene_batch(sp, poses[:9], [b.ptr for b in nine], nine[0].pitch, synchronize=True)
+    st = sp.view_stats()
+    assert (st["fallbacks"], st["grows"], st["slot_frames"]) == (1, 1, 8), st
+    assert all(np.array_equal(b.to_host().reshape(H, W, 3), singles[i]) for i, b in enumerate(nine))
+    # sizing handed back to the launches: the pool grows to 16 frames per slot and the block it leaves is freed
+    sp.reserve_views(0)
+    cam.render_scene_batch(sp, poses[:9], [b.ptr for b in nine], nine[0].pitch, synchronize=True)
+    m2 = sp.memory()
+    assert (m2["view_slots"], m2["view_slot_frames"], m2["view_pool_bytes"]) == (3, 16, frame_bytes * 48), m2
+    assert 0 <= m2["device_bytes"] - m0["device_bytes"] - m2["view_pool_bytes"] < 256, (m0, m2)
+    assert sp.view_stats()["grows"] == 2 and sp.info()["device_bytes"] == m2["device_bytes"]
+    assert all(np.array_equal(b.to_host().reshape(H, W, 3), singles[i]) for i, b in enumerate(nine))
+    h = rt.libs()[0]
+    assert h.rt_scene_reserve_views(sp.device_handle, 33) == -1 and h.rt_scene_reserve_views(None, 4) == -1
+    for b in nine + sets[0] + sets[1] + [one]:
+        b.free()
+
+
+def test_view_pool_budget_in_a_child_process():
+    """RT_VIEW_MAX_BYTES (read once per process): a pool of three slots that does not fit drops to two; a reservation beyond the budget is refused."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, importlib, numpy as np; sys.path.insert(0, 'tests'); import scene_defs as sd\n"
+            "rt = importlib.import_module('cuda-raytracing_amd'); scenes = importlib.import_module('cuda-raytracing_amd.scenes'); rt.build()\n"
+            "blob = os.path.join('.scene_cache', 'blob5k.obj')\n"
+            "os.makedirs('.scene_cache', exist_ok=True)\n"
+            "if not os.path.exists(blob): scenes.write_blob_obj(blob, 50, 51)\n"
+            "W, H = 400, 240; K = scenes.scaled_K(W); sp = sd.blob_scene(scenes, blob).build_product(rt); sp.upload_to_device()\n"
+            "poses = [(0.05 * i, -1.5 - 0.1 * i, 0.2, 0.02 * i, 0.0, 0.0) for i in range(4)]\n"
+            "cam = rt.Camera(W, H, K, scenes.D_REF); bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(4)]\n"
+            "cam.render_scene_batch(sp, poses, [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)\n"
+            "m = sp.memory(); print(m); assert (m['view_slots'], m['view_slot_frames']) == (2, 4) and m['view_pool_bytes'] <= 3000000, m\n"
+            "cam.set_pose(poses[3]); assert np.array_equal(bufs[3].to_host().reshape(H, W, 3), rt.render_ids(sp, cam)['img'])\n"
+            "assert rt.libs()[0].rt_scene_reserve_views(sp.device_handle, 32) == -2\n"
+            "assert sp.memory() == m; print('budget ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RT_VIEW_MAX_BYTES="3000000"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "budget ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_view_records_switched_off_in_a_child_process():

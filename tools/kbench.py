@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ex", default=None, help="spp,bounces,lighting: time the extension kernel (rt_render_ex) instead")
     ap.add_argument("--streams", type=int, default=1, help="issue successive launches round-robin on this many HIP streams (torch streams)")
     ap.add_argument("--check", action="store_true", help="compare the frame hash with the debug kernel's")
+    ap.add_argument("--path", type=int, default=0, help="single-frame launches cycle through this many poses on bench.py's 4 mm loop around the camera (0: one pose)")
     a = ap.parse_args()
     rt.build()
     cache = os.path.join(ROOT, ".scene_cache")
@@ -68,8 +69,20 @@ def main():
                 calls[state["i"] % a.streams]()
                 state["i"] += 1
         else:
+            path_calls, state1 = [], {"i": 0}
+            if a.path > 0 and not a.ex and a.batch == 1:
+                import math
+                for k in range(a.path):
+                    ang = 2.0 * math.pi * k / a.path
+                    q = list(pose)
+                    q[0] += 0.004 * math.sin(ang); q[2] += 0.004 * (math.cos(ang) - 1.0); q[3] += 0.002 * math.sin(ang)
+                    path_calls.append(cam.prepared_batch(scene, [tuple(q)], [ptrs[0]], img.pitch))
+
             def go():
-                if a.ex or a.batch == 1:
+                if path_calls:
+                    path_calls[state1["i"] % len(path_calls)]()
+                    state1["i"] += 1
+                elif a.ex or a.batch == 1:
                     cam.render_scene(scene, img.ptr, img.pitch)
                 else:
                     cam.render_scene_batch(scene, [pose] * a.batch, ptrs, img.pitch)
