@@ -79,7 +79,7 @@ L1_DATA_CLK_PER_WAVE_LOAD = 16.3                  # clocks a CU's L1 spends on o
 SALU_PEAK_GINST = 256 * CLOCK_HZ / 1e9            # one scalar unit per CU (MICROARCH glossary "CU"), one instruction per clock
 STRIPE_ROWS = 16
 MIN_WARM_FRAMES = 320            # 1-spp stream workloads: untimed frames before the timed region, whatever --warmup asks (see run_stream)
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r05_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r06_counters.json")
 _build = importlib.import_module("cuda-raytracing_amd._build")
 
 
@@ -168,11 +168,18 @@ class NodeBarrier:
                 log("bench.py rank %d: cannot map %s (%s)" % (rank, box[0], e))
         flag = torch.tensor([1 if slots is not None else 0], dtype=torch.int32, device="cpu" if on_cpu else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # every rank uses the same kind of barrier
-        if rank == 0:
-            self.path = box[0]
+        if rank == 0 and box[0] is not None:
+            # every rank that could map the page has mapped it (the all-reduce above is behind their mmap): the NAME can go now, the
+            # mappings keep the page alive -- nothing is left under /dev/shm if a rank dies later
+            try:
+                os.remove(box[0])
+            except OSError:
+                pass
         if int(flag.item()) == 1:
             self.slots = slots
             self.kind = "shared-memory rendezvous of the node's %d ranks (/dev/shm)" % world
+        elif not one_node:
+            self.kind += " (LOCAL_WORLD_SIZE = %s is not the world size %d: the ranks are not known to share a node)" % (os.environ.get("LOCAL_WORLD_SIZE", "unset"), world)
 
     def wait(self):
         if self.slots is None:
@@ -184,17 +191,13 @@ class NodeBarrier:
         spins = 0
         while int(self.slots[:, 0].min()) < self.epoch:
             spins += 1
+            if spins > 20000:                                    # (a few milliseconds of spinning: a peer is late, not racing -- stop burning its core)
+                time.sleep(0.0002)
             if spins % 4096 == 0 and time.monotonic() > deadline:
                 raise RuntimeError("bench.py rank %d: a rank never reached barrier %d" % (self.rank, self.epoch))
 
     def close(self):
         self.slots = None
-        if self.path is not None:
-            try:
-                os.remove(self.path)
-            except OSError:
-                pass
-            self.path = None
 
 
 def aggregate_repeats(dts, steps):
@@ -891,21 +894,24 @@ def run_stream(args, env):
     if dist_on:
         dist.barrier()
 
-    # ---- every rank checks frames it assembled in the last group against the debug kernel at the same pose ----
-    last_b = (repeats * len(units) - 1) & 1
-    mine = my_frames(units[-1])
-    held = frames_of(last_b).cpu().numpy().reshape(F, H, W, 3)
+    # ---- every rank checks frames it assembled in the last unit -- and, when the region is a pipeline of sub-groups, in the one before
+    # it, which sits in the other buffer set -- against the debug kernel at the same pose ----
     frame_ok, ids_ok, dbg0 = True, True, None
-    for k, f in enumerate(mine):
-        if k not in (0, len(mine) // 2, len(mine) - 1):
-            continue
-        cam.set_pose(poses[f])
-        cam.set_stream(stream)
-        dbg = rt.render_debug(scene, cam)
-        slot = k if (dist_on and rotate) else f - (units[-1][0] if dist_on else 0)    # rotating exchange: my k-th frame sits in slot k of my frame set
-        frame_ok = frame_ok and bool(np.array_equal(held[slot], dbg["img"]))
-        ids = rt.render_ids(scene, cam)                          # the production kernel's own hit ids
-        ids_ok = ids_ok and bool(np.array_equal(ids["hit_tri"], dbg["hit_tri"]) and np.array_equal(ids["hit_inst"], dbg["hit_inst"]))
+    total_units = repeats * len(units)
+    for back in range(2 if (subgrouped and total_units >= 2) else 1):
+        unit = units[(len(units) - 1 - back) % len(units)]
+        held = frames_of((total_units - 1 - back) & 1).cpu().numpy().reshape(F, H, W, 3)
+        mine = my_frames(unit)
+        for k, f in enumerate(mine):
+            if k not in (0, len(mine) // 2, len(mine) - 1):
+                continue
+            cam.set_pose(poses[f])
+            cam.set_stream(stream)
+            dbg = rt.render_debug(scene, cam)
+            slot = k if (dist_on and rotate) else f - (unit[0] if dist_on else 0)    # rotating exchange: my k-th frame sits in slot k of my frame set
+            frame_ok = frame_ok and bool(np.array_equal(held[slot], dbg["img"]))
+            ids = rt.render_ids(scene, cam)                      # the production kernel's own hit ids
+            ids_ok = ids_ok and bool(np.array_equal(ids["hit_tri"], dbg["hit_tri"]) and np.array_equal(ids["hit_inst"], dbg["hit_inst"]))
     if dist_on:
         flag = torch.tensor([int(frame_ok), int(ids_ok)], dtype=torch.int32, device="cpu" if rehearsal else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -1159,6 +1165,28 @@ def measure_latency(g, poses, f32_ms_per_frame):
         singles[k + 1]()
         torch.cuda.synchronize()
     ref_loop_one_stream = (time.perf_counter() - t0) * 1e3 / n
+    # one frame per launch, consecutive frames on two alternating streams (an application that double-buffers its frames): the next
+    # frame's costly tiles fill the chip while the previous frame's last workgroups drain.  Measured BEFORE the first default-stream
+    # render_scene of this process and again after it: rt_render_overlapped creates a HIGH-PRIORITY stream for the first frame of a
+    # pair, and on this runtime the existence of one slows two normal streams that alternate (0.112 -> 0.125 ms per frame here; see
+    # rt_hip.h, RT_OVERLAP_PRIORITY) -- both figures are in the line
+    make_camera = g["make_camera"]
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cams2 = [make_camera(side[0]), make_camera(side[1])]
+    m = 160
+    alt = [cams2[k & 1].prepared_batch(scene, [poses[k % len(poses)]], [bufs[k & 1].data_ptr()], pitch) for k in range(m)]
+
+    def two_alternating_streams():
+        hold_clock()
+        for c in alt[:8]:
+            c()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in alt:
+            c()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / m
+    f1_two = two_alternating_streams()
     # The reference's loop as its application writes it (kernel.cu:275-279): camera.pose = ...; camera.render_scene(scene, d_img,
     # pitch); camera.render_scene(scene, d_img2, pitch); cudaDeviceSynchronize() -- through Camera::render_scene ITSELF, on the
     # default stream: the library lets the two frames overlap (rt_render_overlapped), nothing here helps it
@@ -1182,21 +1210,7 @@ def measure_latency(g, poses, f32_ms_per_frame):
         singles[k]()
         torch.cuda.synchronize()
     f1_sync = (time.perf_counter() - t0) * 1e3 / n
-    # one frame per launch, consecutive frames on two alternating streams (an application that double-buffers its frames): the next
-    # frame's costly tiles fill the chip while the previous frame's last workgroups drain
-    make_camera = g["make_camera"]
-    side = [torch.cuda.Stream(), torch.cuda.Stream()]
-    cams2 = [make_camera(side[0]), make_camera(side[1])]
-    m = 160
-    alt = [cams2[k & 1].prepared_batch(scene, [poses[k % len(poses)]], [bufs[k & 1].data_ptr()], pitch) for k in range(m)]
-    for c in alt[:8]:
-        c()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for c in alt:
-        c()
-    torch.cuda.synchronize()
-    f1_two = (time.perf_counter() - t0) * 1e3 / m
+    f1_two_after = two_alternating_streams()
     pcie = measure_download(g, poses)
     ref_ok = True
     for k, got in ref_frames.items():
@@ -1205,6 +1219,7 @@ def measure_latency(g, poses, f32_ms_per_frame):
     return {"f1_kernel_ms": round(f1, 4), "f1_launch_plus_sync_wall_ms": round(f1_sync, 4), "f2_batch_ms_per_frame": round(f2, 4),
             "pcie_inclusive": pcie,
             "f1_two_alternating_streams_wall_ms_per_frame": round(f1_two, 4),
+            "f1_two_alternating_streams_after_the_default_stream_frames_wall_ms_per_frame": round(f1_two_after, 4),
             "reference_loop_2_renders_per_sync_wall_ms_per_frame": round(ref_loop, 4),
             "reference_loop_through": "Camera::render_scene(scene, img, pitch) twice into two images on the default stream, then a device synchronise "
                                       "(kernel.cu:277-279); the library alternates such frames between two blocking streams of its own (rt_render_overlapped)",

@@ -109,7 +109,10 @@ def libs():
         # every source).  A mismatch is rebuilt when the compiler is here, else refused; RT_ALLOW_VARIANT_LIB=1
         # (tools/ab_variants.sh) loads the variant as it is -- bench.py's line then carries the variant's own hash.
         from . import _build as _b
-        why = _b.library_mismatch(HIP_SO)
+        try:
+            why = _b.library_mismatch(HIP_SO)
+        except _b.BuildError as e:                               # (the sources next to the library cannot be read: nothing to check it against)
+            raise RtError(str(e))
         if why is not None and not _b.variant_allowed():
             try:
                 _b.build()

@@ -28,15 +28,24 @@ HOST_SRCS = [os.path.join(CSRC, "host", n) for n in ("rt_host.cpp", "rt_host_cap
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 
+class BuildError(RuntimeError):
+    pass
+
+
 def kernel_code_hash(sources=None, flags=None):
-    """What a committed PMC profile of the render kernels describes: sha256 over the kernel translation unit, the two
-    headers it is built from and the compiler flags.  tools/summarize_profile.py stores it with every counters entry and
-    bench.py refuses to price a roofline fraction with counters taken from other code (`profile_stale`)."""
+    """What a committed PMC profile describes and what the loader checks: sha256 over EVERY source librt_hip.so is built from
+    (HIP_DEPS: the three translation units, the headers they share -- rt_scene_internal.h is the scene layout all three agree on --
+    and include/rt_hip.h) and the compiler flags.  tools/summarize_profile.py stores it with every counters entry and bench.py
+    refuses to price a roofline fraction with counters taken from other code (`profile_stale`).  (Rounds 4-5 hashed the kernel
+    translation unit and two headers only: an edit to the scene layout or the build kernels left a stale library looking verified.)"""
     import hashlib
     h = hashlib.sha256()
-    for path in (sources if sources is not None else [os.path.join(CSRC, n) for n in ("rt_kernels.hip", "rt_math.h", "rt_device_types.h")]):
+    for path in (sources if sources is not None else HIP_DEPS):
         h.update(os.path.basename(path).encode() + b"\0")
-        h.update(open(path, "rb").read())
+        try:
+            h.update(open(path, "rb").read())
+        except OSError as e:
+            raise BuildError("cannot read %s to hash the library's sources: %s" % (path, e))
     h.update(" ".join(flags if flags is not None else HIP_FLAGS + os.environ.get("RT_HIPCC_EXTRA", "").split()).encode())
     return h.hexdigest()[:16]
 
@@ -130,7 +139,17 @@ def _build_locked(force, verbose):
 
 
 if __name__ == "__main__":
-    if "--print-hash" in sys.argv:                               # (CMakeLists.txt: the definition it passes to the kernels)
-        print(kernel_code_hash())
+    if "--print-hash" in sys.argv:                               # (CMakeLists.txt, at BUILD time: the definition it passes to the kernels,
+        flags = None                                             #  hashed with the flags CMake itself compiles with: --flags "...")
+        if "--flags" in sys.argv:
+            flags = sys.argv[sys.argv.index("--flags") + 1].split()
+        text = kernel_code_hash(flags=flags)
+        if "--header" in sys.argv:                               # --header <file>: written only when the hash changed (no needless rebuilds)
+            path = sys.argv[sys.argv.index("--header") + 1]
+            line = '#define RT_CODE_HASH "%s"\n' % text
+            if not os.path.exists(path) or open(path).read() != line:
+                open(path, "w").write(line)
+        else:
+            print(text)
         sys.exit(0)
     build(force="--force" in sys.argv, verbose=True)

@@ -1305,7 +1305,6 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
     // XCD sees tiles from the whole frame: measured faster than giving each XCD one contiguous band (better load
     // balance; the working set is L1/L2 resident either way).
     int tile = (int)blockIdx.x, frame = (int)blockIdx.y;
-    lds_int* group = nullptr;                                   // ORDERED: {waves finished, longest lane so far}
     int iters = 0;
     if constexpr (ORDERED) {
         // a one-dimensional grid: workgroup b renders frame b % F of the tile with rank b / F, so the costly tiles of ALL
@@ -1313,9 +1312,6 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
         frame = tile % p.num_frames;
         tile = tile / p.num_frames;
         if (p.tile_order) tile = p.tile_order[tile];
-        group = (lds_int*)lds_stack + lds_block_rows<DEBUG, PROF, SPILL>(p.stack_depth) * kPrimBlock;
-        if (threadIdx.x == 0) { group[0] = 0; group[1] = 0; }
-        __syncthreads();                                        // (at the very start: the four waves arrive together)
     }
     const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
 
@@ -1335,17 +1331,17 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
     if constexpr (ORDERED) {
         // cost of the tile = loop iterations of its longest lane: deterministic, unlike a lifetime, which also measures
         // how full the chip was while the workgroup ran
+        static_assert(!ORDERED || kPrimBlock == 64, "one wave per workgroup: the wave's longest lane is the tile's");
         for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(iters, o); iters = v > iters ? v : iters; }
-        if (p.tile_cost && lane == 0) {
-            __hip_atomic_fetch_max((int*)&group[1], iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int before = __hip_atomic_fetch_add((int*)&group[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (before == kPrimBlock / 64 - 1) {                // this wave is the last of its workgroup
-                const int cost = __hip_atomic_load((int*)&group[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // several frames per launch (a rank's stripes of a few frames): a tile's cost is that of its costliest frame -- the
-                // frames differ in pose and, with a rotating stripe owner, in the rows a tile stands for; the sort clears what it has read
-                if (p.num_frames > 1) atomicMax(&p.tile_cost[tile], cost);
-                else p.tile_cost[tile] = cost;
-            }
+        // Round 6: the cost goes to the tile AND ITS EIGHT NEIGHBOURS, as a maximum (nine lanes, one atomic each; the sort clears what
+        // it has read).  The costly tiles are the ones whose rays graze a silhouette, and which tiles those are changes with the
+        // smallest camera motion: a frame a few millimetres along finds last frame's order one tile off exactly where it matters
+        // (single frames along bench.py's 4 mm camera loop 0.134 ms, the same pose repeated 0.127: single_frame_gap.md).  With the
+        // neighbourhood's maximum the tiles NEXT to a costly one start early too; several frames per launch (a rank's stripes of a
+        // few frames, which differ in pose and, with a rotating owner, in the rows a tile stands for) add up the same way.
+        if (p.tile_cost && lane < 9) {
+            const int nx = tile % p.tiles_x + lane % 3 - 1, ny = tile / p.tiles_x + lane / 3 - 1;
+            if (nx >= 0 && nx < p.tiles_x && ny >= 0 && ny < p.tiles_y) atomicMax(&p.tile_cost[ny * p.tiles_x + nx], iters);
         }
     }
     if (p.trace && lane == 0) {                                 // diagnostic: per-wave lifetime (RT_TRACE_FILE)
@@ -1472,13 +1468,16 @@ __device__ __forceinline__ Xorwow ex_stream(const RenderParams& p, int x, int y,
 // workgroup used to be.
 constexpr int kExBlock = 64;
 typedef StackT<kExBlock> ExStack;
-// PHASE (round 6; bounces / lighting, PX mapping): 0 = the whole path in one kernel, as above.  1 + 2 = the same path in TWO launches
-// with the same grid: phase 1 casts the camera ray -- the hand-written loop, the frame's view records, no path state to carry, like the
-// samples-only kernel -- and stores what survives the cast per lane, (slot, instance, u, v) and (location, pops): 32 B in two planes,
-// the lanes of a wave side by side; phase 2 picks the record up and runs the rest of the path (shade, shadow ray, bounces) with the
-// compiler's loops only.  Why: the camera ray is 38 % of c3's node pops; inside the one-kernel form it takes the hand-written loop at
-// the price of 45 spilled registers around EVERY cast of the path (25 without it).  The casts, their order and every operation on
-// their results are the same, so the frame is the same bit for bit (tests: RT_EX_SPLIT=0 / 1 against each other and the oracle).
+// PHASE (round 6; bounces / lighting, PX mapping): 0 = the whole path in one kernel, as above -- the default.  1 + 2 (RT_EX_SPLIT=1, opt-in)
+// = the same path in TWO launches with the same grid: phase 1 casts the camera ray -- the hand-written loop, the frame's view records,
+// no path state to carry, like the samples-only kernel -- and stores what survives the cast per lane, (slot, instance, u, v) and
+// (location, pops): 32 B in two planes, the lanes of a wave side by side; phase 2 picks the record up and runs the rest of the path
+// (shade, shadow ray, bounces) with the compiler's loops only.  The idea: the camera ray is 38 % of c3's node pops,
+// and inside the one-kernel form it takes the hand-written loop at the price of 45 spilled registers around EVERY cast of the path (25
+// without it).  Measured: SLOWER -- c3 19.5 -> 20.6 ms, c3 from the far camera 7.66 -> 9.14, c5 292 -> 310: the records of a c3 frame
+// are 4.2 GB written and 4.2 GB read, 1.0-1.5 ms at the rate HBM gives them, and that is more than the spills cost
+// (profiles/r06_experiments/ex_split_two_launches.md, with both forms' kernel times and counters).  The casts, their order and every
+// operation on their results are the same, so the frame is the same bit for bit (tests: both forms against each other and the oracle).
 // The launch is cut into chunks of workgroups when the records of all of it would not fit the scratch budget (wg_base).
 template <bool SIMPLE, bool PX = false, bool VIEW = false, int PHASE = 0>
 __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderParams p)
@@ -1971,43 +1970,34 @@ __global__ void unstripe_kernel(const uint8_t* __restrict__ src, size_t local_pi
     d[u] = s[u];
 }
 
-// Heavy-first dispatch order of the next single-frame launch: a counting sort of the tiles by the lifetime their workgroup
-// had in the last frame (its longest lane's iteration count, longest first), by ONE workgroup of 1024 threads.  A tile's key is
-// computed once and kept (a render on another stream may be rewriting the costs): whatever the values, the result is a permutation of the tiles.
-// The sort runs on the scene's side stream, but a hipDeviceSynchronize waits for it like for everything else -- the
-// reference's loop synchronises the device every two frames (kernel.cu:279) -- so it has to be short: every thread loads
-// eight costs before it touches any of them (one memory latency per 8192 tiles instead of one per 256; round 4's 256-thread
-// form took 30-50 us for the 8160 tiles of a 1080p frame, this one a fifth of that).
-constexpr int kSortKeys = 1024, kSortThreads = 1024, kSortBatch = 8;
-// Round 6: a tile's key is the LARGEST cost among the tile and its eight neighbours.  The costly tiles are the ones whose rays graze a
-// silhouette, and which tiles those are changes with the smallest camera motion -- a frame a few millimetres along finds last frame's
-// order one tile off exactly where it matters (measured: single frames along bench.py's 4 mm camera loop 0.134 ms against 0.127 ms for
-// the same pose repeated; profiles/r06_experiments/single_frame_gap.md).  With the neighbourhood's maximum, the tiles NEXT to a costly
-// one start early too.
-__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(int32_t* cost, int ntiles, int tiles_x, int32_t* __restrict__ keys,
-                                                                 int32_t* __restrict__ order, int reset)
+// Heavy-first dispatch order of the next single-frame (or thin striped) launch: a counting sort of the tiles by cost -- the loop
+// iterations of the longest lane among the tile and its neighbours in the launches since the last sort, longest first.  A tile's key is
+// computed once and kept (a render on another stream may be rewriting the costs): whatever the values, the result is a permutation
+// of the tiles.  The sort runs on the scene's side stream, but a hipDeviceSynchronize waits for it like for everything else -- the
+// reference's loop synchronises the device every two frames (kernel.cu:279) -- so it has to be short AND has to get going: every
+// thread loads eight costs before it touches any of them (one memory latency per 2048 tiles).
+constexpr int kSortKeys = 1024, kSortThreads = 256, kSortBatch = 8;
+// Round 6: ONE workgroup of 256 threads (was 1 024).  Primary launches are one-wave workgroups that refill a wave slot the moment it
+// falls free; a 1 024-thread workgroup needs sixteen free slots on ONE compute unit at the same moment, which a saturated chip offers
+// when the frames END -- the sort then ran after them, and a device synchronise (the reference's loop: one every two frames) waited
+// for it.  Four waves find room within microseconds.  The costs arrive as neighbourhood maxima (render_kernel<.., ORDERED>), so the
+// sort reads one value per tile; it clears what it has read (the launches accumulate maxima).
+__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(int32_t* cost, int ntiles, int32_t* __restrict__ keys, int32_t* __restrict__ order)
 {
-    static_assert(kSortKeys == kSortThreads, "one class per thread in the scan below");
+    constexpr int kPer = kSortKeys / kSortThreads;              // classes per thread in the scan
+    static_assert(kSortKeys % kSortThreads == 0, "whole classes per thread");
     __shared__ int count[kSortKeys], scan[kSortThreads];
     const int t = threadIdx.x;
-    count[t] = 0;
+    for (int c = t; c < kSortKeys; c += kSortThreads) count[c] = 0;
     __syncthreads();
     for (int base = 0; base < ntiles; base += kSortThreads * kSortBatch) {
         int k[kSortBatch];
 #pragma unroll
         for (int j = 0; j < kSortBatch; j++) {
             const int i = base + j * kSortThreads + t;
-            k[j] = -1;
-            if (i < ntiles) {                                   // iterations of the longest lane (a few hundred at most) of the 3 x 3 tiles around i
-                const int tx = i % tiles_x, x0 = tx > 0 ? -1 : 0, x1 = tx + 1 < tiles_x ? 1 : 0;
-                int m = 0;
-                for (int dy = -tiles_x; dy <= tiles_x; dy += tiles_x) {
-                    const int row = i + dy;
-                    if (row < 0 || row >= ntiles) continue;
-                    for (int dx = x0; dx <= x1; dx++) { const int c = cost[row + dx]; m = c > m ? c : m; }
-                }
-                k[j] = m;
-            }
+            k[j] = i < ntiles ? cost[i] : -1;                   // iterations of the longest lane (a few hundred at most) of the 3 x 3 tiles around i
+            if (i < ntiles) cost[i] = 0;                        // (a launch running beside this sort may lose a cost it had just written: that
+                                                                // tile is ordered by its neighbours' and earlier frames' costs, or late, once)
         }
 #pragma unroll
         for (int j = 0; j < kSortBatch; j++) {
@@ -2021,12 +2011,11 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(int32_t* cost, 
         }
     }
     __syncthreads();
-    // (multi-frame launches accumulate a maximum per tile: what has been read starts again from zero -- after every thread has read its
-    // neighbourhoods; a launch running beside this sort may lose a cost it had just written: that tile is ordered by its neighbours'
-    // and its other frames' costs, or late, once)
-    if (reset) for (int i = t; i < ntiles; i += kSortThreads) cost[i] = 0;
-    // exclusive prefix over the classes (Hillis-Steele on the inclusive sums): count[] becomes the running cursor of each class
-    const int mine = count[t];
+    // exclusive prefix over the classes (each thread its kPer consecutive classes, Hillis-Steele over the threads' sums): count[]
+    // becomes the running cursor of each class
+    int own[kPer], mine = 0;
+#pragma unroll
+    for (int c = 0; c < kPer; c++) { own[c] = count[t * kPer + c]; mine += own[c]; }
     scan[t] = mine;
     __syncthreads();
     for (int o = 1; o < kSortThreads; o <<= 1) {
@@ -2035,7 +2024,9 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(int32_t* cost, 
         scan[t] += v;
         __syncthreads();
     }
-    count[t] = scan[t] - mine;
+    int at = scan[t] - mine;
+#pragma unroll
+    for (int c = 0; c < kPer; c++) { count[t * kPer + c] = at; at += own[c]; }
     __syncthreads();
     for (int base = 0; base < ntiles; base += kSortThreads * kSortBatch) {
         int k[kSortBatch];
@@ -2296,13 +2287,15 @@ bool seen_finished(RtScene::TileOrder::Seen& e)
 {
     if (e.dirty) {
         const hipError_t q = hipStreamQuery(e.stream);
-        if (q == hipSuccess) { e.dirty = false; return true; }
+        if (q == hipSuccess) { e.dirty = e.recorded = false; return true; }
         (void)hipGetLastError();
-        if (q != hipErrorNotReady) { e.dirty = false; return true; }        // (a stream the application has destroyed: its work is over)
+        if (q != hipErrorNotReady) { e.dirty = e.recorded = false; return true; }   // (a stream the application has destroyed: its work is over)
         e.dirty = false;
         if (hipEventRecord(e.done, e.stream) != hipSuccess) { (void)hipGetLastError(); return true; }
+        e.recorded = true;
         return false;
     }
+    if (!e.recorded) return true;                               // (never launched, or everything it launched was seen finished)
     const bool done = hipEventQuery(e.done) == hipSuccess;
     if (!done) (void)hipGetLastError();
     return done;
@@ -2467,6 +2460,7 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     RtScene::TileOrderCache& cache = s->order;
     std::lock_guard<std::mutex> lock(cache.m);
     const int ntiles = p.tiles_x * p.tiles_y;
+    // (a high-priority side stream was tried: frames alternating between two streams went from 0.111 to 0.126 ms with it)
     if (!cache.sort_stream) RT_HIP(hipStreamCreateWithFlags(&cache.sort_stream, hipStreamNonBlocking));
     RtScene::TileOrder* o = nullptr;
     for (auto& e : cache.entry) if (e.ntiles && e.tiles_x == p.tiles_x && e.tiles_y == p.tiles_y) o = &e;
@@ -2479,7 +2473,7 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
                 (void)hipFree(lru->d_cost);
                 lru->d_cost = lru->d_keys = lru->d_order[0] = lru->d_order[1] = nullptr;
                 lru->tiles_x = lru->tiles_y = lru->ntiles = 0; lru->cur = -1; lru->pending = false; lru->launches = lru->sorted_at = 0;
-                for (auto& e : lru->seen) e.used = e.dirty = false;
+                for (auto& e : lru->seen) e.used = e.dirty = e.recorded = false;
                 o = lru;
             }
         }
@@ -2508,6 +2502,39 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
     }
     p.tile_order = (mine && o->cur >= 0) ? o->d_order[o->cur] : nullptr;
     p.tile_cost = mine ? o->d_cost : nullptr;
+    // A new order is sorted every RT_TILE_SORT_INTERVAL-th launch (default 4), on the side stream, from the costs the launches so far
+    // have left.  It must not start before every launch that may still read the buffer it writes has finished -- every ordered launch
+    // issued BEFORE this one, on any stream (this one reads d_order[cur], the sort writes the other buffer) -- so it runs WHILE this
+    // frame renders: a device-wide synchronise after the frame (the reference's loop synchronises every two frames) finds it done.
+    // Round 6: the events that tell it are recorded WHEN A SORT IS ISSUED, on every stream that has launched since its last one --
+    // not after every launch as before: a recorded event is a marker packet between two kernels of the stream, and back-to-back
+    // launches with a marker in between start 7 us apart where launches without start 0 us apart
+    // (profiles/r06_experiments/single_frame_gap.md: rocprofv3 kernel-trace timestamps of 60 back-to-back launches, three settings).
+    // (This launch rewrites the cost array while the sort reads it: a tile's key is computed once and kept, and whatever the
+    // values, the result is a permutation.)
+    static const int interval = [] { const char* e = getenv("RT_TILE_SORT_INTERVAL"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+    if (mine && !o->pending && o->launches >= 1 && (o->cur < 0 || o->launches + 1 - o->sorted_at >= (uint64_t)interval)) {
+        for (auto& e : o->seen) {
+            if (!e.used || !e.dirty) continue;
+            e.dirty = false;
+            if (hipEventRecord(e.done, e.stream) != hipSuccess) {           // (a stream the application has destroyed since: its work is over)
+                (void)hipGetLastError();
+                if (&e != mine) e.used = false;
+                e.recorded = false;
+                continue;
+            }
+            e.recorded = true;
+        }
+        // ... and the sort is QUEUED before the frame (after a synchronise it finds an empty chip); its workgroup is four waves, which
+        // find room on a saturated chip too (see tile_sort_kernel)
+        o->sorted_at = o->launches + 1;
+        o->target = o->cur < 0 ? 0 : o->cur ^ 1;
+        for (auto& e : o->seen) if (e.used && e.recorded) RT_HIP(hipStreamWaitEvent(cache.sort_stream, e.done, 0));
+        hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, cache.sort_stream, o->d_cost, ntiles, o->d_keys, o->d_order[o->target]);
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipEventRecord(o->sort_done, cache.sort_stream));
+        o->pending = true;
+    }
     const size_t lds = (size_t)(lds_stack_suffices(p) ? lds_block_rows<false, false, false>(p.stack_depth) : lds_block_rows<false, false, true>(p.stack_depth)) *
                        kPrimBlock * sizeof(int) + 2 * sizeof(int);
     const dim3 grid((unsigned)ntiles * (unsigned)p.num_frames);
@@ -2519,42 +2546,8 @@ int launch_ordered(RtScene* s, RenderParams& p, hipStream_t stream, int synchron
         else hipLaunchKernelGGL((render_kernel<false, false, true>), grid, dim3(kPrimBlock), lds, stream, p);
     }
     RT_HIP(hipGetLastError());
-    // A new order is sorted every RT_TILE_SORT_INTERVAL-th launch (default 4), on the side stream, from the costs the launches so far
-    // have left; it must not start before every launch that may still read the buffer it writes has finished, i.e. every ordered
-    // launch issued so far on any stream.  Round 6: the events that tell it are recorded WHEN A SORT IS ISSUED, on every stream that
-    // has launched since its last one -- not after every launch as before: a recorded event is a marker packet between two kernels
-    // of the stream, and back-to-back launches with a marker in between start 7 us apart where launches without start 0 us apart
-    // (profiles/r06_experiments/single_frame_gap.md: rocprofv3 kernel-trace timestamps of 60 back-to-back launches, three settings).
-    // (The launch after the sort rewrites the cost array while the sort reads it: every cost is read once and whatever the
-    // values, the result is a permutation.  Launches read d_order[cur], the sort writes the other buffer.)
-    static const int interval = [] { const char* e = getenv("RT_TILE_SORT_INTERVAL"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
     if (o) o->launches++;
     if (mine) mine->dirty = true;
-    if (mine && !o->pending && o->launches > 1 && (o->cur < 0 || o->launches - o->sorted_at >= (uint64_t)interval)) {
-        o->sorted_at = o->launches;
-        o->target = o->cur < 0 ? 0 : o->cur ^ 1;
-        bool all = true;
-        for (auto& e : o->seen) {
-            if (!e.used) continue;
-            if (e.dirty) {
-                e.dirty = false;
-                if (hipEventRecord(e.done, e.stream) != hipSuccess) {       // (a stream the application has destroyed since: its work is over)
-                    (void)hipGetLastError();
-                    if (&e == mine) all = false;
-                    e.used = false;
-                    continue;
-                }
-            }
-            RT_HIP(hipStreamWaitEvent(cache.sort_stream, e.done, 0));
-        }
-        if (all) {
-            hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(kSortThreads), 0, cache.sort_stream, o->d_cost, ntiles, p.tiles_x, o->d_keys, o->d_order[o->target],
-                               p.num_frames > 1 ? 1 : 0);
-            RT_HIP(hipGetLastError());
-            RT_HIP(hipEventRecord(o->sort_done, cache.sort_stream));
-            o->pending = true;
-        }
-    }
     if (synchronize) RT_HIP(hipStreamSynchronize(stream));
     return RT_OK;
 }
@@ -3195,10 +3188,18 @@ int rt_render_overlapped(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, 
         // hipStreamDefault = a BLOCKING stream: work on the null stream waits for everything issued here before it, and
         // everything issued here waits for earlier null-stream work -- the ordering a default-stream launch has with the
         // caller's copies, memsets, instance updates and hipDeviceSynchronize
+        // Round 6: stream 0 has the HIGHER priority.  The reference's loop issues two frames and then synchronises the device: two
+        // equal streams share the chip, both frames run at half speed and END TOGETHER -- their tails coincide and nothing is hidden
+        // (two overlapped frames 245 us, each alone 125: rocprofv3 timeline in profiles/r06_experiments/single_frame_gap.md).  With
+        // priorities the first frame of a pair takes the chip, the second fills the slots its tail leaves free and then runs alone:
+        // one tail exposed instead of two.  (RT_OVERLAP_PRIORITY=0: two equal streams, for the A/B.)
+        static const bool prio = [] { const char* e = getenv("RT_OVERLAP_PRIORITY"); return !(e && e[0] == '0'); }();
+        int least = 0, greatest = 0;
+        if (!prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
         hipStream_t st[2] = {nullptr, nullptr};
         hipEvent_t ev[2] = {nullptr, nullptr};
-        hipError_t e = hipStreamCreateWithFlags(&st[0], hipStreamDefault);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[1], hipStreamDefault);
+        hipError_t e = hipStreamCreateWithPriority(&st[0], hipStreamDefault, greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&st[1], hipStreamDefault, least);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -3212,7 +3213,10 @@ int rt_render_overlapped(RtScene* s, const RtCameraParams* cam, uint8_t* d_img, 
         for (const auto& w : v) if (w.lo < r.hi && r.lo < w.hi) return true;
         return false;
     };
-    int use = ov.next, other = use ^ 1;
+    // (the high-priority stream takes the frame whenever it is idle -- after every synchronise, so the first frame of a pair)
+    int use = ov.next;
+    if (use == 1) { if (hipStreamQuery(ov.stream[0]) == hipSuccess) use = 0; else (void)hipGetLastError(); }
+    int other = use ^ 1;
     const bool hit_other = meets(ov.written[other]);
     if (hit_other && !meets(ov.written[use])) {
         std::swap(use, other);                                  // same image as the frame in flight over there: stream order does it
@@ -3314,9 +3318,9 @@ static int launch_ex(RtScene* s, RenderParams& p, const RtRenderOptions* opts, i
     const bool pixel_waves = !wavefront && !trace_file && p.spp >= 4 && ex_env_int("RT_EX_PIXEL_WAVES", 1) != 0;
     if (pixel_waves) {
         const bool many = p.spp > 64;                                               // several launches: running sums in ex_acc
-        // bounces / lighting: the camera ray in a launch of its own (render_ex_kernel<.., PHASE>; RT_EX_SPLIT=0: the one-kernel form),
+        // bounces / lighting, RT_EX_SPLIT=1: the camera ray in a launch of its own (render_ex_kernel<.., PHASE>; measured slower, see there),
         // in chunks of workgroups whose records -- 2 KB per one-wave workgroup -- fit the scratch budget (c3: all 2 073 600 waves at once, 4.2 GB)
-        const bool split = !simple && ex_env_int("RT_EX_SPLIT", 1) != 0;
+        const bool split = !simple && ex_env_int("RT_EX_SPLIT", 0) != 0;
         const size_t per_wg = (size_t)kExBlock * 2 * sizeof(float4);
         size_t split_chunk = 0;
         if (split) {

@@ -63,9 +63,9 @@ struct RtScene {
         uint64_t last_used = 0;
         uint64_t launches = 0, sorted_at = 0;    // ordered launches of this size so far / at the last sort issued
         // the last ordered launch on each stream that uses this state (a sort waits for all of them)
-        // (done = recorded behind the stream's launches when a sort is issued or the slot is wanted for another stream; dirty = the
-        // stream has launched since)
-        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false, dirty = false; uint64_t tick = 0; } seen[4];
+        // (done = recorded behind the stream's launches when a sort is issued or the slot is wanted for another stream; recorded = it
+        // has been, and is worth waiting for; dirty = the stream has launched since)
+        struct Seen { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool used = false, dirty = false, recorded = false; uint64_t tick = 0; } seen[4];
     };
     // rt_render_overlapped (Camera::render_scene's asynchronous default-stream form): two library-owned BLOCKING streams that
     // consecutive frames alternate between, so that the next frame's costly tiles fill the chip while the previous frame's

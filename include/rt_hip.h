@@ -12,6 +12,7 @@
  * Environment (diagnostics and tests only): RT_TRACE_FILE=<path> makes every render launch synchronise and write
  * per-wave start / end stamps there (tools/trace_one.py), with RT_TRACE_PROF=1 through a stamped copy of the kernel;
  * RT_EX_SCRATCH_BYTES=<n> overrides the scratch budget of rt_render_ex (forces the chunked path);
+ * RT_EX_SPLIT=1 renders the camera ray of a path with bounces or lighting in a launch of its own (bit-identical, measured slower);
  * RT_EX_WAVEFRONT=1 renders bounces / lighting with one cast per launch and path queues in between (bit-identical, slower
  * on the measured workloads: DESIGN.md section 3), RT_EX_GROUP=<4..32> sets its queue group size;
  * RT_TILE_ORDER=0 turns the heavy-first dispatch order of single-frame launches off; RT_BVH_LIBRARY_SCAN=1 makes
@@ -22,6 +23,9 @@
  * RT_RENDER_OVERLAP=0 makes rt_render_overlapped a plain default-stream launch; RT_TILE_SORT_INTERVAL=<n> sorts a new heavy-first
  * order every n-th single-frame launch (default 4: the events that order a sort behind the launches it must wait for are recorded only then); while RT_TEST_FAIL_UPLOAD=1 is set every rt_scene_upload fails with
  * RT_E_NOMEM before it touches anything (tests of the callers' error paths).
+ * Round 6: RT_OVERLAP_PRIORITY=0 gives rt_render_overlapped two streams of equal priority (see there); RT_TILE_ORDER_STRIPES=0 keeps a
+ * rank's thin striped batches in natural tile order; RT_VIEW_MAX_BYTES=<n> bounds a scene's view pool (default 1 GiB, see
+ * rt_scene_reserve_views); RT_EX_SPLIT_BYTES=<n> bounds the records of the two-launch bounce form (tests: forces chunks).
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
@@ -204,7 +208,13 @@ int rt_render(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t 
  * fill the chip while the previous frame's last workgroups drain (c2: 0.146 -> 0.13 ms per frame in the reference's loop).
  * Calls whose images share memory run in call order (the later frame wins).  Not implied, unlike a real default-stream launch:
  * ordering against work on OTHER blocking streams of the application; a caller with such streams passes its stream to
- * rt_render instead.  RT_RENDER_OVERLAP=0 makes this call rt_render(.., NULL, 0). */
+ * rt_render instead.  RT_RENDER_OVERLAP=0 makes this call rt_render(.., NULL, 0).
+ * Round 6: the first of the two streams has the HIGHER stream priority, and the frame issued when it is idle -- the first frame after
+ * a synchronise -- goes there: two equal streams share the chip, both frames of a pair run at half speed and end TOGETHER, so neither
+ * tail is hidden (245 us for the pair, 125 us for a frame alone); with priorities the first frame takes the chip and the second fills
+ * the slots its tail leaves free (the reference's loop on c2: 0.136 -> 0.131 ms per frame).  Side effect, measured on this runtime:
+ * once a high-priority stream exists in the process, two NORMAL streams that alternate single frames run 11 % slower (0.112 -> 0.125 ms
+ * per frame) -- an application that does both uses RT_OVERLAP_PRIORITY=0 (two equal streams, round 5's behaviour). */
 int rt_render_overlapped(RtScene *scene, const RtCameraParams *cam, uint8_t *d_img, size_t pitch);
 /* how many frames went through rt_render_overlapped on this scene and how many of them had to wait for the other stream
  * (an image overlapping one written there and one written here); either pointer may be NULL */

@@ -1307,7 +1307,10 @@ def test_ex_forms_are_bit_identical(rt, orc, scenes, blob5k, monkeypatch, spp, b
     cam.set_options(spp, bounces, lighting)
     # (the default from 4 samples on: a pixel's samples share a wave and are summed there; RT_EX_PIXEL_WAVES=0: one sample index per
     # launch row, sample planes and a resolve pass)
-    variants = [{"RT_EX_PIXEL_WAVES": "0"}, {"RT_EX_PIXEL_WAVES": "0", "RT_EX_SCRATCH_BYTES": str(3 * W * H * 16)}, {"RT_EX_WAVEFRONT": "1"}, {"RT_EX_WAVEFRONT": "1", "RT_EX_GROUP": "4"},
+    # (round 6: RT_EX_SPLIT=1 renders the camera ray of a path with bounces or lighting in a launch of its own, render_ex_kernel<..,
+    # PHASE 1 / 2>; RT_EX_SPLIT_BYTES forces that form into chunks of 4 and of 12 workgroups)
+    variants = [{"RT_EX_SPLIT": "1"}, {"RT_EX_SPLIT": "1", "RT_EX_SPLIT_BYTES": "8192"}, {"RT_EX_SPLIT": "1", "RT_EX_SPLIT_BYTES": str(12 * 2048)},
+                {"RT_EX_PIXEL_WAVES": "0"}, {"RT_EX_PIXEL_WAVES": "0", "RT_EX_SCRATCH_BYTES": str(3 * W * H * 16)}, {"RT_EX_WAVEFRONT": "1"}, {"RT_EX_WAVEFRONT": "1", "RT_EX_GROUP": "4"},
                 {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": str(2 * (W + 16) * (H + 16) * 380)},
                 {"RT_EX_WAVEFRONT": "1", "RT_EX_SCRATCH_BYTES": "1"}]
     for env in variants:
@@ -1566,6 +1569,9 @@ def test_fuzz_extension_modes(rt, orc, scenes, blob5k, seed, monkeypatch):
     opts = (int(rng.integers(1, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 2)))
     desc = sd.SceneDesc(mats, meshes, inst)
     _compare_ex(rt, orc, desc, W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02), *opts)
+    monkeypatch.setenv("RT_EX_SPLIT", "1")                                 # (the two-launch form of the bounce kernel)
+    _compare_ex(rt, orc, desc, W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02), *opts)
+    monkeypatch.delenv("RT_EX_SPLIT")
     monkeypatch.setenv("RT_EX_WAVEFRONT", "1")
     _compare_ex(rt, orc, desc, W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02), *opts)
 

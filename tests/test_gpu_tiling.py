@@ -173,6 +173,11 @@ def mock_rccl(tmp_path_factory):
 @pytest.mark.parametrize("extra", [["--gpus", "2", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "40", "--warmup", "8"],
                                    ["--gpus", "4", "--workload", "c2", "--width", "322", "--height", "203", "--steps", "21", "--warmup", "5", "--frames-per-launch", "7"],
                                    ["--gpus", "3", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "12", "--warmup", "3", "--gather", "root0"],
+                                   # the driver's shape: ONE group per timed region, rendered as a pipeline of sub-groups (round 6)
+                                   ["--gpus", "2", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "20", "--warmup", "5"],
+                                   ["--gpus", "4", "--workload", "c2", "--width", "322", "--height", "203", "--steps", "20", "--warmup", "5"],
+                                   ["--gpus", "3", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "7", "--warmup", "3"],
+                                   ["--gpus", "2", "--workload", "c2", "--width", "480", "--height", "272", "--steps", "20", "--warmup", "5", "--subgroups", "1"],
                                    ["--gpus", "2", "--workload", "c5", "--width", "480", "--height", "272", "--spp", "6", "--bounces", "1", "--steps", "2", "--warmup", "1"],
                                    ["--gpus", "4", "--workload", "c3", "--width", "322", "--height", "203", "--spp", "3", "--bounces", "2", "--steps", "3", "--warmup", "1"],
                                    ["--gpus", "3", "--workload", "c3", "--width", "322", "--height", "203", "--spp", "70", "--bounces", "1", "--steps", "2", "--warmup", "1"]])
@@ -196,6 +201,18 @@ def test_bench_ranks_as_processes_over_mock_transport(mock_rccl, extra):
     assert "rt_" in line["config"]["parallelism"]
     if "c2" in extra:
         _check_per_rank_report(line, int(extra[1]))
+        steps, world = int(extra[extra.index("--steps") + 1]), int(extra[1])
+        if steps <= 32 and "--gather" not in extra and "--frames-per-launch" not in extra:
+            # one group per timed region: sub-groups unless switched off; every frame of the group in exactly one of them, none smaller
+            # than the rank count; the ranks' report says how much of a sub-group's exchange ran inside the next one's render
+            sub = line["config"]["sub_groups"]
+            if "--subgroups" in extra:
+                assert sub is None
+            else:
+                assert sub is not None and len(sub) >= 2 and sum(c for _, c in sub) == steps and all(c >= world for _, c in sub), sub
+                assert [f for f, _ in sub] == [sum(c for _, c in sub[:k]) for k in range(len(sub))]
+                assert all("exchange_inside_next_render_frac" in r for r in line["per_rank"]), line["per_rank"]
+                assert line["config"]["frames_per_launch"] == sub[0][1] and line["config"]["frames_per_group"] == steps
 
 
 def _check_per_rank_report(line, world):

@@ -1,4 +1,4 @@
-"""bench.py prices `roofline.frac` with instruction counts from a committed rocprofv3 PMC pass (profiles/r05_counters.json).
+"""bench.py prices `roofline.frac` with instruction counts from a committed rocprofv3 PMC pass (profiles/r06_counters.json).
 Those counts describe one build of the kernels: every entry carries the hash of the kernel source + build flags it was taken
 from, and a line printed by other code says `profile_stale` instead of a fraction (CPU-only: no kernel runs here)."""
 import glob
@@ -14,7 +14,8 @@ build = importlib.import_module("cuda-raytracing_amd._build")
 
 
 def test_one_character_kernel_edit_marks_profile_stale(tmp_path, monkeypatch):
-    srcs = [os.path.join(build.CSRC, n) for n in ("rt_kernels.hip", "rt_math.h", "rt_device_types.h")]
+    srcs = list(build.HIP_DEPS)                                          # every source of librt_hip.so (round 6: not the kernel unit alone)
+    assert {os.path.basename(p) for p in srcs} >= {"rt_kernels.hip", "rt_bvh_build.hip", "rt_comm.hip", "rt_scene_internal.h", "rt_hip.h"}
     copies = [shutil.copy(p, tmp_path / os.path.basename(p)) for p in srcs]
     h0 = build.kernel_code_hash()
     assert build.kernel_code_hash(sources=copies) == h0                 # the hash is of content, not of paths or times
@@ -24,6 +25,14 @@ def test_one_character_kernel_edit_marks_profile_stale(tmp_path, monkeypatch):
     h1 = build.kernel_code_hash(sources=copies)
     assert h1 != h0
     assert build.kernel_code_hash(flags=[f for f in build.HIP_FLAGS if f != "-fno-slp-vectorize"]) != h0    # flags count too
+    # an edit to the scene layout the three translation units share changes it as well
+    at = [i for i, p in enumerate(copies) if str(p).endswith("rt_scene_internal.h")][0]
+    open(copies[at], "a").write("// edited\n")
+    assert build.kernel_code_hash(sources=copies) not in (h0, h1)
+    # sources that cannot be read: an error that says so (the loader turns it into RtError), not a bare FileNotFoundError
+    import pytest
+    with pytest.raises(build.BuildError):
+        build.kernel_code_hash(sources=[str(tmp_path / "missing.hip")])
 
     import bench
     table = tmp_path / "counters.json"
@@ -40,14 +49,14 @@ def test_one_character_kernel_edit_marks_profile_stale(tmp_path, monkeypatch):
 
 
 def test_committed_counters_carry_their_code_hash():
-    path = os.path.join(ROOT, "profiles", "r05_counters.json")
+    path = os.path.join(ROOT, "profiles", "r06_counters.json")
     table = json.load(open(path))
     assert table, "no committed PMC profile"
     for key, e in table.items():
         assert isinstance(e.get("code_hash"), str) and len(e["code_hash"]) == 16, key
         assert e.get("valu_insts_per_frame", 0) > 0, key
     # every bench line committed beside the counters was priced (tools/summarize_profile.py fills the block from the same run)
-    for f in glob.glob(os.path.join(ROOT, "profiles", "r05_*_bench_line.json")):
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r06_*_bench_line.json")):
         roof = json.load(open(f))["roofline"]
         assert roof["frac"] is not None and roof["profile_stale"] is False, f
 
@@ -57,7 +66,7 @@ def test_headline_profile_is_of_the_code_in_the_tree():
     """The driver runs bench.py on this tree: the committed PMC profile of the headline workload (c2, mid camera) must have been
     taken from the kernels as they are now, or the line would say `profile_stale` and carry no roofline fraction.  A kernel
     edit therefore fails here until tools/profile_bench.sh + tools/summarize_profile.py have been run on the new code."""
-    table = json.load(open(os.path.join(ROOT, "profiles", "r05_counters.json")))
+    table = json.load(open(os.path.join(ROOT, "profiles", "r06_counters.json")))
     assert table["c2_mid_1920x1080_1_0_0"]["code_hash"] == build.kernel_code_hash()
 
 
@@ -66,6 +75,7 @@ def _variant_package(tmp_path):
     tools/ab_variants.sh leaves behind if it is interrupted, or a library built from an edited tree and copied in."""
     pkg = tmp_path / "cuda-raytracing_amd"
     shutil.copytree(os.path.join(ROOT, "cuda-raytracing_amd"), pkg, ignore=shutil.ignore_patterns("__pycache__", "_variants", ".build.lock"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")       # (include/rt_hip.h is one of the library's hashed sources)
     so = pkg / "librt_hip.so"
     data = so.read_bytes()
     real = build.library_code_hash()

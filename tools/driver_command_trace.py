@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 --kernel-trace --stats of the driver's exact command (`python3 bench.py --gpus 1 --steps 20 --warmup 5`, run by
 tools/profile_campaign.sh <out> aux) -> profiles/<tag>_driver_command_kernel_stats.csv and _kernel_trace.json: the durations of
-the command's 20-frame launches beside the kernel time the line itself reports.   python tools/driver_command_trace.py <out>/driver r05"""
+the command's 20-frame launches beside the kernel time the line itself reports.   python tools/driver_command_trace.py <out>/driver r06"""
 import collections, csv, glob, json, os, shutil, statistics, sys
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

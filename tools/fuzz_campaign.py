@@ -39,7 +39,7 @@ skipped = [c.get("name") for c in cases if any(ch.tag == "skipped" for ch in c)]
 res = {"campaign": "differential fuzz, HIP path vs CPU oracle, all parity planes", "date": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
        "kernel_code_hash": importlib.import_module("cuda-raytracing_amd").library_hash(),
        "test_fuzz_random_scenes": {"seeds": [first, first + n], "rng": "numpy.random.default_rng(1000 + seed)", "gpu_built_tree": "seed % 3 == 2"},
-       "test_fuzz_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(7000 + seed)", "forms": ["per-lane", "wavefront"]},
+       "test_fuzz_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(7000 + seed)", "forms": ["per-lane", "two-launch (RT_EX_SPLIT=1)", "wavefront"]},
        "cases": len(cases), "passed": len(cases) - len(bad) - len(skipped), "failed": bad, "skipped": skipped,
        "pytest_exit_code": r.returncode, "pytest_summary": r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "", "seconds": round(time.time() - t0, 1)}
 json.dump(res, open(out, "w"), indent=1)

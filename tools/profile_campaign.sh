@@ -1,8 +1,8 @@
 #!/bin/bash
 # The round's profile campaign on the GPU box, in parts that fit one gpurun call each:
-#   bash tools/profile_campaign.sh <outdir> <part>     part = c2 | ex | big | aux
+#   bash tools/profile_campaign.sh <outdir> <part>     part = c2 | demo | ex | big | aux
 # Every workload: tools/profile_bench.sh (one rocprofv3 --kernel-trace --stats run of the bench command + separate PMC passes).
-# Afterwards, in the build container:  python tools/summarize_profile.py <outdir>/<name> r05_<name>   for every <name>.
+# Afterwards, in the build container:  python tools/summarize_profile.py <outdir>/<name> r06_<name>   for every <name>.
 out=$1; part=$2
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
@@ -12,6 +12,8 @@ c2)  run c2_mid 96 32
      run c2_far 96 32 --camera far
      run c2_near 96 32 --camera near
      run c2_mid_f1 48 16 --frames-per-launch 1 --steps 400 ;;
+demo) run demo 96 32 --workload demo
+     run demo_baked 96 32 --workload demo --baked ;;
 ex)  run c3 3 1 --workload c3 --steps 20 --warmup 3
      run c4_16spp 3 1 --workload c4 --steps 20 --warmup 3
      run c4_1spp 64 32 --workload c4 --spp 1 --steps 256 --warmup 32 ;;

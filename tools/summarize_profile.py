@@ -2,7 +2,7 @@
 """Turns a tools/profile_bench.sh output directory into the committed summaries under profiles/:
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
   profiles/<tag>_bench_line.json    the line bench.py printed under the profiler
-  profiles/r05_counters.json        [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
+  profiles/<round>_counters.json    [workload key] -> PMC counters of the dominant kernel, normalised PER FRAME, with the
                                     hash of the kernel source + build flags they were taken from (bench.py checks it)
 A frame = width x height x spp primary rays.  A dispatch of G work-items renders G / (work-items per frame) frames (one 64-thread
 workgroup per 8x8 tile per frame of the batch; the extension kernel: 256 threads per 16x16 tile per sample), so counters are summed over every dispatch of
@@ -19,6 +19,8 @@ _b = importlib.import_module("cuda-raytracing_amd._build")
 code_hash = _b.library_code_hash()
 assert code_hash == _b.kernel_code_hash(), "librt_hip.so (%s) is not the build of the sources in the tree (%s)" % (code_hash, _b.kernel_code_hash())
 dst = os.path.join(ROOT, "profiles")
+import bench
+bench_counters = bench.COUNTERS_JSON
 bench_line = None
 for line in open(os.path.join(src, "stats.log"), errors="ignore"):
     if line.startswith("{\"metric\""):
@@ -87,7 +89,8 @@ if kt:
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-tp = os.path.join(dst, "r05_counters.json")
+tp = os.path.join(dst, "%s_counters.json" % tag.split("_")[0])       # (the round is the tag's prefix: r06_c2_mid -> r06_counters.json)
+assert os.path.abspath(tp) == os.path.abspath(bench_counters), "bench.py prices its lines with %s: the tag's round must match" % bench_counters
 out = json.load(open(tp)) if os.path.exists(tp) else {}
 out[key] = entry
 json.dump(out, open(tp, "w"), indent=1, sort_keys=True)
