@@ -33,6 +33,8 @@ if kernel == "render_kernel<false, false>":                 # (lines printed bef
     kernel = "render_kernel<false, false, false>"
 if kernel.startswith("render_kernel<") and kernel.count(",") == 2:      # (lines printed before the SPILL parameter existed: either form)
     kernel = kernel[:-1] + ", "
+if kernel.startswith("render_kernel<") and kernel.endswith(">"):        # (round 6: a sixth template parameter, STATS, follows the five the line names)
+    kernel = kernel[:-1] + ","
 # (round 5: the primary kernels' workgroup is one wave = one 8x8-pixel tile; the extension kernel's tile is still 16x16 pixels,
 # rendered by four one-wave workgroups)
 tiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -56,7 +58,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if kernel in r["Kernel_Name"]:
             frames_by_pass[r["Counter_Name"]] = frames
 pf = {k: v / frames_by_pass[k] for k, v in tot.items() if frames_by_pass.get(k)}
-entry = {"tag": tag, "code_hash": code_hash, "kernel": kernel, "dispatch": meta, "frames_profiled": {k: round(v, 2) for k, v in frames_by_pass.items()},
+entry = {"tag": tag, "code_hash": code_hash, "kernel": (kernel[:-1] + ", false>") if kernel.endswith(",") else kernel, "dispatch": meta, "frames_profiled": {k: round(v, 2) for k, v in frames_by_pass.items()},
          "per_frame": pf, "bench_line_under_rocprof": {k: bench_line[k] for k in ("value", "ms_per_step", "steps")}}
 if "SQ_INSTS_VALU" in pf:
     entry["valu_insts_per_frame"] = pf["SQ_INSTS_VALU"]
