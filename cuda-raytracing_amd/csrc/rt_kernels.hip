@@ -244,6 +244,8 @@ template <bool DEBUG, class STK, int OCT = -1, bool NEED_POP = false, class W>
 __device__ __forceinline__ bool interior_apply_words(const W& w, const MeshRay& r, float hit_min,
                                                      int32_t& cur, STK& stack, Counters<DEBUG>& cnt)
 {
+    int32_t ra = __float_as_int(w[12]), rb = __float_as_int(w[13]);
+    if constexpr (DEBUG) cnt.aabb += 2;
     float da, db;                                                       // w[0..11]: box - origin (box_differences, or a view record)
     if constexpr (OCT < 0) {
         da = slab(w[0], w[1], w[2], w[3], w[4], w[5], r.dinv);
@@ -252,8 +254,6 @@ __device__ __forceinline__ bool interior_apply_words(const W& w, const MeshRay& 
         da = slab_oct<OCT>(w[0], w[1], w[2], w[3], w[4], w[5], r.dinv);
         db = slab_oct<OCT>(w[6], w[7], w[8], w[9], w[10], w[11], r.dinv);
     }
-    int32_t ra = __float_as_int(w[12]), rb = __float_as_int(w[13]);
-    if constexpr (DEBUG) cnt.aabb += 2;
     // push order of raycast.cu:72-79: the farther child is pushed first, the nearer one last (= popped next); each only if
     // its distance passes `dist < hit.min`.  With pa / pb = "child a / b passes": both pass -> push the far one (b when
     // da < db, else a -- a tie takes the else branch) and go on with the near one; one passes -> go on with that one (it is
@@ -593,7 +593,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 // the IEEE division / square-root expansions are taken from the compiler's own output, so every bit of every result is
 // the same (the parity tests compare this loop's frames and hit ids with the instrumented kernel's and the oracle's).
 //
-// Registers: v0..v15 the record, v16..v27 temporaries, s[48:63] the record of a wave-uniform fetch, s[30:45] masks and
+// Registers: v0..v15 the record, v16..v27 temporaries, s[48:63] the record of a wave-uniform fetch, s[30:45] and s[64:69] masks and
 // scalars, s[46:47] the exec mask the loop was entered with; the ray, the hit and the stack state are operands.
 // Hazards (gfx940 family): a VALU-written SGPR / VCC needs two wait states before a VALU reads it (none before a SALU read),
 // four before v_div_fmas reads VCC; a transcendental result one before a non-transcendental VALU uses it.
@@ -602,6 +602,14 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 #endif
 #ifndef RT_ASM_GUARD
 #define RT_ASM_GUARD 0
+#endif
+// RT_ASM_V2 (round 6, second session; 0 = the loop as round 5 wrote it, kept for A/B): the same decisions from fewer vector
+// instructions -- masks that only the per-lane path reads are made there (and one of them by the scalar unit), "which child passes"
+// is taken from the slab distances themselves instead of from FLT_MAX-patched copies of them, "the nearer child is next" is folded
+// into one select, and the stack's top is kept as an LDS ADDRESS (push and pop add a constant to it instead of shifting an index).
+// No floating-point operation changes or moves; profiles/r06_experiments/asm_loop_v2.md.
+#ifndef RT_ASM_V2
+#define RT_ASM_V2 1
 #endif
 
 // RT_ASM_BACKFACE: when no lane of the wave holds a triangle that faces its ray (denom < 0, raycast.cu:107-109) the rest of
@@ -621,6 +629,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 
 // one interior node: v0..v11 hold box - origin, v12 / v13 the two child entries; exec = the lanes at this node.
 // N* / F* = the registers holding the near / far plane of the axis for this octant (slab_oct's operand choice).
+#if !RT_ASM_V2
 #define RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
     "v_mul_f32 v16, " AXN ", %[dix]\n\t"  "v_mul_f32 v17, " AYN ", %[diy]\n\t"  "v_mul_f32 v18, " AZN ", %[diz]\n\t" \
     "v_mul_f32 v19, " AXF ", %[dix]\n\t"  "v_mul_f32 v20, " AYF ", %[diy]\n\t"  "v_mul_f32 v21, " AZF ", %[diz]\n\t" \
@@ -655,6 +664,45 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_cndmask_b32_e64 v18, -2, v18, s[44:45]\n\t" \
     "s_or_b64 exec, exec, s[38:39]\n\t" \
     "v_cndmask_b32_e32 %[cur], -1, v18, vcc\n\t"        /* nothing passes: this lane pops */
+#else
+// (v2) pa = hit(a) and near(a) < hit.min, pb likewise: the reference's `dist < hit.min` on a distance that is FLT_MAX for a miss
+// (BVHTree.hpp:40-54, raycast.cu:72-79) -- FLT_MAX < hit.min is false for every hit.min, so the mask is the same without the select;
+// "a is the nearer" is only read where both pass, i.e. where both distances are the slab's own.  s[38:39] = pa, s[40:41] = pb,
+// s[68:69] = near(a) < near(b), s[42:43] = the lanes that go on with a, vcc = the lanes that go on at all.
+#define RT_ASM_INTERIOR(AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+    "v_mul_f32 v16, " AXN ", %[dix]\n\t"  "v_mul_f32 v17, " AYN ", %[diy]\n\t"  "v_mul_f32 v18, " AZN ", %[diz]\n\t" \
+    "v_mul_f32 v19, " AXF ", %[dix]\n\t"  "v_mul_f32 v20, " AYF ", %[diy]\n\t"  "v_mul_f32 v21, " AZF ", %[diz]\n\t" \
+    "v_max3_f32 v16, v16, v17, v18\n\t"                 /* near of a */ \
+    "v_min3_f32 v19, v19, v20, v21\n\t"                 /* far of a */ \
+    "v_mul_f32 v22, " BXN ", %[dix]\n\t"  "v_mul_f32 v23, " BYN ", %[diy]\n\t"  "v_mul_f32 v24, " BZN ", %[diz]\n\t" \
+    "v_mul_f32 v25, " BXF ", %[dix]\n\t"  "v_mul_f32 v26, " BYF ", %[diy]\n\t"  "v_mul_f32 v27, " BZF ", %[diz]\n\t" \
+    "v_max3_f32 v22, v22, v23, v24\n\t"                 /* near of b */ \
+    "v_min3_f32 v25, v25, v26, v27\n\t"                 /* far of b */ \
+    "v_cmp_ge_f32_e32 vcc, v19, v16\n\t" \
+    "v_cmp_lt_f32_e64 s[38:39], 0, v19\n\t" \
+    "v_cmp_lt_f32_e64 s[44:45], v16, %[hmin]\n\t" \
+    "v_cmp_ge_f32_e64 s[40:41], v25, v22\n\t" \
+    "v_cmp_lt_f32_e64 s[42:43], 0, v25\n\t" \
+    "v_cmp_lt_f32_e64 s[66:67], v22, %[hmin]\n\t" \
+    "v_cmp_lt_f32_e64 s[68:69], v16, v22\n\t"           /* a is the nearer */ \
+    "s_and_b64 vcc, vcc, s[38:39]\n\t" \
+    "s_and_b64 s[40:41], s[40:41], s[42:43]\n\t" \
+    "s_and_b64 s[38:39], vcc, s[44:45]\n\t"             /* pa */ \
+    "s_and_b64 s[40:41], s[40:41], s[66:67]\n\t"        /* pb */ \
+    "s_orn2_b64 s[42:43], s[68:69], s[40:41]\n\t" \
+    "s_and_b64 s[44:45], s[38:39], s[40:41]\n\t"        /* both pass: one is pushed */ \
+    "s_and_b64 s[42:43], s[42:43], s[38:39]\n\t"        /* a is next: it passes, and b does not or is the farther */ \
+    "s_or_b64 vcc, s[38:39], s[40:41]\n\t"              /* any passes */ \
+    "v_cndmask_b32_e64 v18, v13, v12, s[42:43]\n\t" \
+    "s_and_saveexec_b64 s[38:39], s[44:45]\n\t" \
+    "ds_write_b32 %[sa], %[tos]\n\t"                   /* the stack's top lives in a register: the one below it goes to LDS ... */ \
+    "v_cmp_gt_i32_e64 s[44:45], %[lim], %[sa]\n\t"     /* the push fits (else it landed in the spare row and the lane stops, see StackT) */ \
+    "v_add_u32_e32 %[sa], %[stride], %[sa]\n\t" \
+    "v_cndmask_b32_e64 %[tos], v12, v13, s[68:69]\n\t" /* ... and the farther child becomes the top */ \
+    "v_cndmask_b32_e64 v18, -2, v18, s[44:45]\n\t" \
+    "s_or_b64 exec, exec, s[38:39]\n\t" \
+    "v_cndmask_b32_e32 %[cur], -1, v18, vcc\n\t"        /* nothing passes: this lane pops */
+#endif
 
 // The pieces that differ between the plain loop and the VIEW loop (RtScene::ViewPool: interior records whose box words already are
 // box - origin, `vdelta` bytes behind the records themselves):
@@ -699,13 +747,72 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 // world-space hit location with the reference's own sequence (raycast.cu:98-104), once, for the hit that was kept
 #define RT_ASM_LOC "v_mov_b32_e32 %[px], v18\n\tv_mov_b32_e32 %[py], v19\n\tv_mov_b32_e32 %[pz], v20\n\t"
 
+// RT_ASM_LAYOUT (round 6): fewer TAKEN branches on the common paths -- a taken branch restarts the wave's instruction fetch.  The
+// count lookup of a leaf above 30 triangles moves out of line (the branch over it was taken at almost every triangle), and the
+// wave-uniform interior step ends in its own copy of the pop / latch block instead of a branch to the shared one.
+#ifndef RT_ASM_LAYOUT
+#define RT_ASM_LAYOUT RT_ASM_V2
+#endif
+#define RT_ASM_LONG_LEAF_BODY \
+    "s_and_saveexec_b64 s[40:41], s[38:39]\n\t" \
+    "v_and_b32_e32 v17, 0x3ffffff, %[cur]\n\t" \
+    "v_lshlrev_b32_e32 v17, 2, v17\n\t" \
+    "global_load_dword %[rem], v17, %[lc]\n\t" \
+    "s_waitcnt vmcnt(0)\n\t" \
+    "s_or_b64 exec, exec, s[40:41]\n\t"
+#if RT_ASM_LAYOUT
+#define RT_ASM_LONG_LEAF_INLINE "s_cbranch_scc1 .Lrt_long%=\n\t"
+#define RT_ASM_LONG_LEAF_OUT_OF_LINE ".Lrt_long%=:\n\t" RT_ASM_LONG_LEAF_BODY "s_branch .Lrt_short%=\n\t"
+#define RT_ASM_UNI_TAIL \
+    "v_cmp_eq_u32_e32 vcc, -1, %[cur]\n\t" \
+    "s_and_saveexec_b64 s[36:37], vcc\n\t" \
+    "s_cbranch_execz .Lrt_latch_u%=\n\t" \
+    RT_ASM_POP \
+    ".Lrt_latch_u%=:\n\t" \
+    "s_or_b64 exec, exec, s[36:37]\n\t" \
+    "v_cmp_ne_u32_e32 vcc, -2, %[cur]\n\t" \
+    "s_and_b64 exec, exec, vcc\n\t" \
+    "s_cbranch_execnz .Lrt_top%=\n\t" \
+    "s_branch .Lrt_exit%=\n\t"
+#else
+#define RT_ASM_LONG_LEAF_INLINE "s_cbranch_scc0 .Lrt_short%=\n\t" RT_ASM_LONG_LEAF_BODY
+#define RT_ASM_LONG_LEAF_OUT_OF_LINE ""
+#define RT_ASM_UNI_TAIL "s_branch .Lrt_pop%=\n\t"
+#endif
+#if RT_ASM_V2
+#define RT_ASM_POP \
+    "v_subrev_u32_e32 %[sa], %[stride], %[sa]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"                         /* (the top's reload of an earlier pop: long done) */ \
+    "v_mov_b32_e32 %[cur], %[tos]\n\t"                 /* the popped entry is in a register: the lane goes on at once ... */ \
+    "ds_read_b32 %[tos], %[sa]\n\t"                    /* ... and the new top arrives while it works on it */
+#else
+#define RT_ASM_POP \
+    "v_add_u32_e32 %[sp], -1, %[sp]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t"                         /* (the top's reload of an earlier pop: long done) */ \
+    "v_lshl_add_u32 v16, %[sp], %[shift], %[col]\n\t" \
+    "v_mov_b32_e32 %[cur], %[tos]\n\t"                 /* the popped entry is in a register: the lane goes on at once ... */ \
+    "ds_read_b32 %[tos], v16\n\t"                      /* ... and the new top arrives while it works on it */
+#endif
+// s[64:65] = the lanes at an interior node, s[34:35] = the lanes at a triangle: read by the per-lane path only.  v2 makes them there
+// (the second one is exec without the first: an entry of a live lane is a node or a triangle); the two wait states a vector read of
+// s30 needs after v_readfirstlane are an s_nop then (v1: the two compares).  VEC_ADDR_VIEW reads s[64:65] two instructions later.
+#if RT_ASM_V2
+#define RT_ASM_MASKS_AT_TOP "s_nop 1\n\t"
+#define RT_ASM_MASKS_AT_VECTOR \
+    "v_cmp_lt_i32_e64 s[64:65], -1, %[cur]\n\t" \
+    "s_andn2_b64 s[34:35], exec, s[64:65]\n\t"
+#else
+#define RT_ASM_MASKS_AT_TOP \
+    "v_cmp_lt_i32_e64 s[64:65], -1, %[cur]\n\t"         /* lanes at an interior node */ \
+    "v_cmp_gt_i32_e64 s[34:35], 0, %[cur]\n\t"          /* lanes at a triangle */
+#define RT_ASM_MASKS_AT_VECTOR ""
+#endif
 #define RT_ASM_LOOP_TEXT(COUNT_TEXT, POPS_INT, POPS_LEAF, LOC_TEXT, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
     "s_mov_b64 s[46:47], exec\n\t" \
     ".Lrt_top%=:\n\t" \
     COUNT_TEXT \
     "v_readfirstlane_b32 s30, %[cur]\n\t" \
-    "v_cmp_lt_i32_e64 s[64:65], -1, %[cur]\n\t"         /* lanes at an interior node */ \
-    "v_cmp_gt_i32_e64 s[34:35], 0, %[cur]\n\t"          /* lanes at a triangle */ \
+    RT_ASM_MASKS_AT_TOP \
     "v_cmp_ne_u32_e32 vcc, s30, %[cur]\n\t" \
     "s_cbranch_vccnz .Lrt_vector%=\n\t" \
     /* ---- every lane holds the same entry: the record comes through the scalar cache */ \
@@ -718,7 +825,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_mov_b32_e32 v13, s61\n\t" \
     POPS_INT \
     UNI_INTERIOR \
-    "s_branch .Lrt_pop%=\n\t" \
+    RT_ASM_UNI_TAIL \
     ".Lrt_one_leaf%=:\n\t" \
     "v_mov_b32_e32 v0, s48\n\t"  "v_mov_b32_e32 v1, s49\n\t"  "v_mov_b32_e32 v2, s50\n\t"  "v_mov_b32_e32 v3, s51\n\t" \
     "v_mov_b32_e32 v4, s52\n\t"  "v_mov_b32_e32 v5, s53\n\t"  "v_mov_b32_e32 v6, s54\n\t"  "v_mov_b32_e32 v7, s55\n\t" \
@@ -728,6 +835,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_branch .Lrt_leaf%=\n\t" \
     /* ---- lanes hold different entries: one 64-byte record per lane, node or triangle, from one array */ \
     ".Lrt_vector%=:\n\t" \
+    RT_ASM_MASKS_AT_VECTOR \
     VEC_ADDR \
     "global_load_dwordx4 v[0:3], v16, %[rec]\n\t" \
     "global_load_dwordx4 v[4:7], v16, %[rec] offset:16\n\t" \
@@ -752,13 +860,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_cndmask_b32_e32 %[rem], %[rem], v16, vcc\n\t" \
     POPS_LEAF \
     "s_and_b64 s[38:39], s[38:39], vcc\n\t"             /* a leaf of more than 30 triangles: its count is in leaf_count */ \
-    "s_cbranch_scc0 .Lrt_short%=\n\t" \
-    "s_and_saveexec_b64 s[40:41], s[38:39]\n\t" \
-    "v_and_b32_e32 v17, 0x3ffffff, %[cur]\n\t" \
-    "v_lshlrev_b32_e32 v17, 2, v17\n\t" \
-    "global_load_dword %[rem], v17, %[lc]\n\t" \
-    "s_waitcnt vmcnt(0)\n\t" \
-    "s_or_b64 exec, exec, s[40:41]\n\t" \
+    RT_ASM_LONG_LEAF_INLINE \
     ".Lrt_short%=:\n\t" \
     /* TrianglePrimitive::ray_intersect: denom = rd . n, tt = ((v0 - ro) . n) / denom */ \
     "v_mul_f32_e32 v16, %[rdx], v3\n\t" \
@@ -902,11 +1004,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_cmp_eq_u32_e32 vcc, -1, %[cur]\n\t" \
     "s_and_saveexec_b64 s[36:37], vcc\n\t" \
     "s_cbranch_execz .Lrt_latch%=\n\t" \
-    "v_add_u32_e32 %[sp], -1, %[sp]\n\t" \
-    "s_waitcnt lgkmcnt(0)\n\t"                         /* (the top's reload of an earlier pop: long done) */ \
-    "v_lshl_add_u32 v16, %[sp], %[shift], %[col]\n\t" \
-    "v_mov_b32_e32 %[cur], %[tos]\n\t"                 /* the popped entry is in a register: the lane goes on at once ... */ \
-    "ds_read_b32 %[tos], v16\n\t"                      /* ... and the new top arrives while it works on it */ \
+    RT_ASM_POP \
     ".Lrt_latch%=:\n\t" \
     "s_or_b64 exec, exec, s[36:37]\n\t" \
     "v_cmp_ne_u32_e32 vcc, -2, %[cur]\n\t" \
@@ -973,6 +1071,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_mul_f32_e32 v7, s50, v4\n\t" \
     "v_add_f32_e32 v23, v23, v7\n\t" \
     "s_branch .Lrt_have_loc%=\n\t" \
+    RT_ASM_LONG_LEAF_OUT_OF_LINE \
     ".Lrt_end%=:\n\t"
 
 // (experiments: -DRT_ASM_PAD_KIND=1|2|3 adds eight scalar / vector / no-op instructions to every iteration, to price an instruction of each kind)
@@ -999,25 +1098,38 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
     // rotates (the candidate block then reads scale and q_inv_pose through the scalar cache), null when it only translates
     static_assert(!LOC || POPS, "the hit point is kept for the extension kernel, which counts pops");
     int32_t rem = -1;
+#if RT_ASM_V2
+    // the stack pointer as the LDS address of the next free row of the lane's column, and the address of the first row that is not there
+    // -- as a SCALAR: a column starts less than one row pitch behind its wave's first column (4 bytes per lane), so `row < depth` is
+    // `address < first column of the wave + depth * pitch` for every lane
+    lds_int* sa = column + (sp << (ROW_SHIFT - 2));
+    const int32_t limit = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(size_t)(column - (int)__lane_id())) + (lds_depth << ROW_SHIFT);
+#define RT_ASM_STACK_OUT [sa] "+v"(sa)
+#define RT_ASM_STACK_IN [lim] "s"(limit), [stride] "n"(1 << ROW_SHIFT)
+#else
+#define RT_ASM_STACK_OUT [sp] "+v"(sp)
+#define RT_ASM_STACK_IN [col] "v"(column), [depth] "s"(lds_depth), [shift] "n"(ROW_SHIFT)
+#endif
     int32_t tos = kSentinel;                                    // the stack's top entry (row 0 of the LDS column holds a second sentinel, so
                                                                 // that the last pop's reload reads a row that exists and leaves sp == 0)
     const float eps = __int_as_float(0x358637be);
 #define RT_ASM_OUT_PLAIN
-#define RT_ASM_OUT_LOC , [px] "+v"(point.x), [py] "+v"(point.y), [pz] "+v"(point.z)
+#define RT_ASM_OUT_POPS , [pops] "+v"(pops)           /* (only the variants that count pops hold a register for them) */
+#define RT_ASM_OUT_LOC , [pops] "+v"(pops), [px] "+v"(point.x), [py] "+v"(point.y), [pz] "+v"(point.z)
 #define RT_ASM_GO(TEXT) RT_ASM_GO2(TEXT, RT_ASM_OUT_PLAIN)
 #define RT_ASM_GO2(TEXT, ...)        /* (... = more output operands, with their leading comma, or nothing) */ \
     asm volatile(TEXT \
-                 : [cur] "+v"(cur), [sp] "+v"(sp), [rem] "+v"(rem), [tos] "+v"(tos), [hmin] "+v"(hit.min), [hslot] "+v"(hit.slot), [hinst] "+v"(hit.instance), \
-                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters), [pops] "+v"(pops) __VA_ARGS__ \
+                 : [cur] "+v"(cur), RT_ASM_STACK_OUT, [rem] "+v"(rem), [tos] "+v"(tos), [hmin] "+v"(hit.min), [hslot] "+v"(hit.slot), [hinst] "+v"(hit.instance), \
+                   [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters) __VA_ARGS__ \
                  : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
-                   [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), [col] "v"(column), \
+                   [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), RT_ASM_STACK_IN, \
                    [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
-                   [depth] "s"(lds_depth), [inst] "s"(inst_index), [eps] "s"(eps), [shift] "n"(ROW_SHIFT), [vdelta] "s"(vdelta), \
+                   [inst] "s"(inst_index), [eps] "s"(eps), [vdelta] "s"(vdelta), \
                    [tx] "s"(back.x), [ty] "s"(back.y), [tz] "s"(back.z), [ip] "s"(general) \
                  : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
                    "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
                    "s30", "s31", "s64", "s65", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", \
-                   "vcc", "scc", "memory")
+                   "s66", "s67", "s68", "s69", "vcc", "scc", "memory")
 #if RT_ASM_GUARD    // (bring-up only: a loop that does not end leaves after a million iterations instead of hanging the GPU)
 #define RT_ASM_COUNT "s_add_u32 %[iters], %[iters], 1\n\ts_cmp_gt_u32 %[iters], 0x100000\n\ts_cbranch_scc1 .Lrt_exit%=\n\t"
 #define RT_ASM_NOCOUNT RT_ASM_COUNT
@@ -1035,7 +1147,7 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
     // (COUNT -- the tile cost of single-frame primary launches -- and POPS -- the extension kernel's pop plane -- never meet)
 #define RT_ASM_CASE(N, VN, SN) \
     if constexpr (OCT == N) { if constexpr (LOC) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, RT_ASM_LOC, RT_ASM_OUT_LOC, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
-                              else if constexpr (POPS) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else if constexpr (POPS) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, "", RT_ASM_OUT_POPS, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
                               else if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
                               else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
     RT_ASM_CASE(0, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s50", "s53", "s54", "s57", "s55", "s58", "s56", "s59"))
@@ -1054,7 +1166,13 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
 #undef RT_ASM_GO
 #undef RT_ASM_GO2
 #undef RT_ASM_OUT_PLAIN
+#undef RT_ASM_OUT_POPS
 #undef RT_ASM_OUT_LOC
+#undef RT_ASM_STACK_OUT
+#undef RT_ASM_STACK_IN
+#if RT_ASM_V2
+    sp = (int32_t)(sa - column) >> (ROW_SHIFT - 2);
+#endif
 }
 
 // Octant-specialised loops (RT_OCTANTS=0 at compile time keeps only the generic one).  The rays of a wave -- an 8x8-pixel
