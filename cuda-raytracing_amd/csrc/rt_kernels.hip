@@ -55,6 +55,17 @@ using namespace rt;
 #define RT_OPTIMISTIC_STACK 1   // deep trees: the timed kernels run the LDS-only stack and a lane whose stack would outgrow it starts again on the
                                 // general stack afterwards (render_pixel), instead of every push and pop asking "which memory"
 #endif
+// Measured and off (round 6, profiles/r06_experiments/ex_secondary_asm.md): the bounce kernel's secondary rays through the hand-written loop
+// (bit 0: shadow rays, bit 1: bounce rays; trace_instance's SEC) and the kernel compiled for fewer waves per SIMD (8: 64 registers,
+// 7: 72, 6: 80).  The loop saves instructions (-4.5 % vector, -16 % scalar on c3 with bit 1) and 5 % of the frame at EQUAL occupancy,
+// but at eight waves its 53 registers push the path state into scratch (writes x 2.5, fetches x 10: c3 +5 %), and every wave given up
+// for registers costs more than the loop returns (c3: 8 waves 19.4 ms, 7: 19.8, 6: 20.9; 6 waves with the loop: 19.8).
+#ifndef RT_EX_BOUNCE_WAVES
+#define RT_EX_BOUNCE_WAVES 8
+#endif
+#ifndef RT_EX_SECONDARY_ASM
+#define RT_EX_SECONDARY_ASM 0
+#endif
 #ifndef RT_EX_PRIMARY_ASM
 #define RT_EX_PRIMARY_ASM 1     // the bounce kernel's camera ray through the hand-written loop and the view records
 #endif
@@ -745,6 +756,12 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 
 // LOC (the bounce kernel's primary ray): the accepted candidate's point on its plane, in mesh space -- the caller turns it into the
 // world-space hit location with the reference's own sequence (raycast.cu:98-104), once, for the hit that was kept
+// ANYHIT (a shadow ray of the extension kernel, raycast.cu:129-133: the cast returns at its first accepted hit): s[66:67] = the lanes
+// that accepted a hit in this triangle step (cleared at the step's start, set in the accepted-candidate block where exec = those
+// lanes and v21 = the distance); they take the sentinel after the step's own bookkeeping and leave the loop at the latch
+#define RT_ASM_ANYHIT_CLEAR "s_mov_b64 s[66:67], 0\n\t"
+#define RT_ASM_ANYHIT_MARK "v_cmp_lt_f32_e64 s[66:67], v21, %[fmax]\n\t"
+#define RT_ASM_ANYHIT_LEAVE "v_cndmask_b32_e64 %[cur], %[cur], -2, s[66:67]\n\t"
 #define RT_ASM_LOC "v_mov_b32_e32 %[px], v18\n\tv_mov_b32_e32 %[py], v19\n\tv_mov_b32_e32 %[pz], v20\n\t"
 
 // RT_ASM_LAYOUT (round 6): fewer TAKEN branches on the common paths -- a taken branch restarts the wave's instruction fetch.  The
@@ -807,7 +824,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "v_cmp_gt_i32_e64 s[34:35], 0, %[cur]\n\t"          /* lanes at a triangle */
 #define RT_ASM_MASKS_AT_VECTOR ""
 #endif
-#define RT_ASM_LOOP_TEXT(COUNT_TEXT, POPS_INT, POPS_LEAF, LOC_TEXT, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
+#define RT_ASM_LOOP_TEXT(COUNT_TEXT, POPS_INT, POPS_LEAF, LOC_TEXT, LEAF_TAIL, UNI_OFFSET, UNI_INTERIOR, VEC_ADDR, VEC_SUBS, AXN, AXF, AYN, AYF, AZN, AZF, BXN, BXF, BYN, BYF, BZN, BZF) \
     "s_mov_b64 s[46:47], exec\n\t" \
     ".Lrt_top%=:\n\t" \
     COUNT_TEXT \
@@ -997,6 +1014,7 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
     "s_nop 1\n\t" \
     "v_cndmask_b32_e32 %[cur], -1, v16, vcc\n\t" \
     "v_cndmask_b32_e32 %[rem], -1, %[rem], vcc\n\t" \
+    LEAF_TAIL \
     ".Lrt_leaf_done%=:\n\t" \
     "s_or_b64 exec, exec, s[36:37]\n\t" \
     /* ---- raycast.cu:60-61: lanes with nothing to go on with pop (the sentinel when nothing is left) */ \
@@ -1089,7 +1107,8 @@ __device__ __forceinline__ void trace_loop(const RenderParams& p, const DevInsta
 // (the byte offsets .Lrt_general reads the instance record at)
 static_assert(offsetof(DevInstance, q_inv_pose) == 0x20 && offsetof(DevInstance, scale) == 0x58 && sizeof(DevInstance) % 16 == 0, "DevInstance layout");
 
-template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW, bool POPS, bool LOC>  // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
+// ORGV: the ray's world origin differs per lane (secondary rays of the extension kernel): vector operands, and never a VIEW
+template <int OCT, bool COUNT, int ROW_SHIFT, bool VIEW, bool POPS, bool LOC, bool ORGV = false, bool ANYHIT = false>  // ROW_SHIFT = log2 of the bytes between two entries of a lane's LDS stack column
 __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_index, const MeshRay& r, V3 org, lds_int* column, int lds_depth,
                                                int32_t& cur, int32_t& sp, Hit& hit, int& wave_iters, uint32_t vdelta, int& pops, V3& point,
                                                V3 back, const DevInstance* general)
@@ -1097,6 +1116,8 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
     // back = DevInstance::inv_pose_xyz (wave-uniform: scalar operands); general = the instance when its mesh -> world transform scales or
     // rotates (the candidate block then reads scale and q_inv_pose through the scalar cache), null when it only translates
     static_assert(!LOC || POPS, "the hit point is kept for the extension kernel, which counts pops");
+    static_assert(!(ORGV && VIEW) && !(ANYHIT && (LOC || !POPS || !ORGV)), "secondary rays: no view; a shadow ray keeps no location");
+    const float fmax = FLT_MAX;
     int32_t rem = -1;
 #if RT_ASM_V2
     // the stack pointer as the LDS address of the next free row of the lane's column, and the address of the first row that is not there
@@ -1123,7 +1144,7 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
                    [hu] "+v"(hit.u), [hv] "+v"(hit.v), [iters] "+s"(wave_iters) __VA_ARGS__ \
                  : [rox] "v"(r.ro.x), [roy] "v"(r.ro.y), [roz] "v"(r.ro.z), [rdx] "v"(r.rd.x), [rdy] "v"(r.rd.y), [rdz] "v"(r.rd.z), \
                    [dix] "v"(r.dinv.x), [diy] "v"(r.dinv.y), [diz] "v"(r.dinv.z), RT_ASM_STACK_IN, \
-                   [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] "s"(org.x), [orgy] "s"(org.y), [orgz] "s"(org.z), \
+                   [rec] "s"(p.records), [lc] "s"(p.leaf_count), [orgx] RT_ASM_ORG_C(org.x), [orgy] RT_ASM_ORG_C(org.y), [orgz] RT_ASM_ORG_C(org.z) RT_ASM_XIN, \
                    [inst] "s"(inst_index), [eps] "s"(eps), [vdelta] "s"(vdelta), \
                    [tx] "s"(back.x), [ty] "s"(back.y), [tz] "s"(back.z), [ip] "s"(general) \
                  : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
@@ -1141,23 +1162,44 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
     // VN = the registers of the record's planes as the per-lane fetch leaves them (x: v0 / v3 for box a, v6 / v9 for box b; y: v1 / v4,
     // v7 / v10; z: v2 / v5, v8 / v11 -- min, max), SN = the scalar registers a wave-uniform fetch leaves them in (s48 ..): per axis
     // (near, far) for this octant -- bit k of OCT set = direction component k negative = the max plane is the near one (slab_oct).
-#define RT_ASM_VARIANT(CT, PI, PL, LT, OUT, VN, SN) \
-    if constexpr (VIEW) RT_ASM_GO2(RT_ASM_LOOP_TEXT(CT, PI, PL, LT, RT_ASM_UNI_OFFSET_VIEW, RT_ASM_INTERIOR(SN), RT_ASM_VEC_ADDR_VIEW, "", VN), OUT); \
-    else RT_ASM_GO2(RT_ASM_LOOP_TEXT(CT, PI, PL, LT, RT_ASM_UNI_OFFSET_PLAIN, RT_ASM_UNI_SUBS RT_ASM_INTERIOR(VN), RT_ASM_VEC_ADDR_PLAIN, RT_ASM_VEC_SUBS, VN), OUT)
+#define RT_ASM_VARIANT(CT, PI, PL, LT, TL, OUT, VN, SN) \
+    if constexpr (VIEW) RT_ASM_GO2(RT_ASM_LOOP_TEXT(CT, PI, PL, LT, TL, RT_ASM_UNI_OFFSET_VIEW, RT_ASM_INTERIOR(SN), RT_ASM_VEC_ADDR_VIEW, "", VN), OUT); \
+    else RT_ASM_GO2(RT_ASM_LOOP_TEXT(CT, PI, PL, LT, TL, RT_ASM_UNI_OFFSET_PLAIN, RT_ASM_UNI_SUBS RT_ASM_INTERIOR(VN), RT_ASM_VEC_ADDR_PLAIN, RT_ASM_VEC_SUBS, VN), OUT)
     // (COUNT -- the tile cost of single-frame primary launches -- and POPS -- the extension kernel's pop plane -- never meet)
 #define RT_ASM_CASE(N, VN, SN) \
-    if constexpr (OCT == N) { if constexpr (LOC) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, RT_ASM_LOC, RT_ASM_OUT_LOC, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
-                              else if constexpr (POPS) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, "", RT_ASM_OUT_POPS, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
-                              else if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
-                              else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
-    RT_ASM_CASE(0, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s50", "s53", "s54", "s57", "s55", "s58", "s56", "s59"))
-    RT_ASM_CASE(1, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v2", "v5", "v9", "v6", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s50", "s53", "s57", "s54", "s55", "s58", "s56", "s59"))
-    RT_ASM_CASE(2, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v2", "v5", "v6", "v9", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s50", "s53", "s54", "s57", "s58", "s55", "s56", "s59"))
-    RT_ASM_CASE(3, RT_ASM_ARGS("v3", "v0", "v4", "v1", "v2", "v5", "v9", "v6", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s52", "s49", "s50", "s53", "s57", "s54", "s58", "s55", "s56", "s59"))
-    RT_ASM_CASE(4, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v5", "v2", "v6", "v9", "v7", "v10", "v11", "v8"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s53", "s50", "s54", "s57", "s55", "s58", "s59", "s56"))
-    RT_ASM_CASE(5, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v5", "v2", "v9", "v6", "v7", "v10", "v11", "v8"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s53", "s50", "s57", "s54", "s55", "s58", "s59", "s56"))
-    RT_ASM_CASE(6, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v5", "v2", "v6", "v9", "v10", "v7", "v11", "v8"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s53", "s50", "s54", "s57", "s58", "s55", "s59", "s56"))
+    if constexpr (OCT == N) { if constexpr (LOC) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, RT_ASM_LOC, "", RT_ASM_OUT_LOC, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              RT_ASM_CASE_ANYHIT(RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)) \
+                              else if constexpr (POPS) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF, "", "", RT_ASM_OUT_POPS, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else if constexpr (COUNT) { RT_ASM_VARIANT(RT_ASM_COUNT, "", "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } \
+                              else { RT_ASM_VARIANT(RT_ASM_NOCOUNT, "", "", "", "", RT_ASM_OUT_PLAIN, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); } }
+#define RT_ASM_ALL_CASES \
+    RT_ASM_CASE(0, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v2", "v5", "v6", "v9", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s50", "s53", "s54", "s57", "s55", "s58", "s56", "s59")) \
+    RT_ASM_CASE(1, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v2", "v5", "v9", "v6", "v7", "v10", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s50", "s53", "s57", "s54", "s55", "s58", "s56", "s59")) \
+    RT_ASM_CASE(2, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v2", "v5", "v6", "v9", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s50", "s53", "s54", "s57", "s58", "s55", "s56", "s59")) \
+    RT_ASM_CASE(3, RT_ASM_ARGS("v3", "v0", "v4", "v1", "v2", "v5", "v9", "v6", "v10", "v7", "v8", "v11"), RT_ASM_ARGS("s51", "s48", "s52", "s49", "s50", "s53", "s57", "s54", "s58", "s55", "s56", "s59")) \
+    RT_ASM_CASE(4, RT_ASM_ARGS("v0", "v3", "v1", "v4", "v5", "v2", "v6", "v9", "v7", "v10", "v11", "v8"), RT_ASM_ARGS("s48", "s51", "s49", "s52", "s53", "s50", "s54", "s57", "s55", "s58", "s59", "s56")) \
+    RT_ASM_CASE(5, RT_ASM_ARGS("v3", "v0", "v1", "v4", "v5", "v2", "v9", "v6", "v7", "v10", "v11", "v8"), RT_ASM_ARGS("s51", "s48", "s49", "s52", "s53", "s50", "s57", "s54", "s55", "s58", "s59", "s56")) \
+    RT_ASM_CASE(6, RT_ASM_ARGS("v0", "v3", "v4", "v1", "v5", "v2", "v6", "v9", "v10", "v7", "v11", "v8"), RT_ASM_ARGS("s48", "s51", "s52", "s49", "s53", "s50", "s54", "s57", "s58", "s55", "s59", "s56")) \
     RT_ASM_CASE(7, RT_ASM_ARGS("v3", "v0", "v4", "v1", "v5", "v2", "v9", "v6", "v10", "v7", "v11", "v8"), RT_ASM_ARGS("s51", "s48", "s52", "s49", "s53", "s50", "s57", "s54", "s58", "s55", "s59", "s56"))
+    // (the same eight loops with the ray's world origin in vector registers and FLT_MAX at hand: secondary rays)
+    if constexpr (ORGV) {
+#define RT_ASM_ORG_C "v"
+#define RT_ASM_XIN , [fmax] "s"(fmax)
+#define RT_ASM_CASE_ANYHIT(VN, SN) else if constexpr (ANYHIT) { RT_ASM_VARIANT(RT_ASM_NOCOUNT, RT_ASM_POPS_INTERIOR, RT_ASM_POPS_LEAF RT_ASM_ANYHIT_CLEAR, RT_ASM_ANYHIT_MARK, RT_ASM_ANYHIT_LEAVE, RT_ASM_OUT_POPS, RT_ASM_ARGS(VN), RT_ASM_ARGS(SN)); }
+        RT_ASM_ALL_CASES
+#undef RT_ASM_ORG_C
+#undef RT_ASM_XIN
+#undef RT_ASM_CASE_ANYHIT
+    } else {
+#define RT_ASM_ORG_C "s"
+#define RT_ASM_XIN
+#define RT_ASM_CASE_ANYHIT(VN, SN)
+        RT_ASM_ALL_CASES
+#undef RT_ASM_ORG_C
+#undef RT_ASM_XIN
+#undef RT_ASM_CASE_ANYHIT
+    }
+#undef RT_ASM_ALL_CASES
 #undef RT_ASM_CASE
 #undef RT_ASM_VARIANT
 #undef RT_ASM_ARGS
@@ -1196,7 +1238,7 @@ __device__ __forceinline__ void loop_stat(const RenderParams& p, int which, unsi
 }
 
 template <bool DEBUG, bool PROF, bool EX = false, bool COUNT = false, class STK = Stack, bool POPS = false, bool OCTANTS = true, bool ANYHIT = false,
-          bool VIEW = false, bool UNIFORM_ORG = !EX, bool STATS = false>
+          bool VIEW = false, bool UNIFORM_ORG = !EX, bool STATS = false, bool SEC = false>
 __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevInstance& in, int inst_index,
                                                V3 org, V3 dir, STK& stack, Hit& hit, Counters<DEBUG>& cnt, int* iters = nullptr,
                                                int* pops = nullptr, uint32_t view_off = 0)
@@ -1213,9 +1255,15 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
         const int first = __builtin_amdgcn_readfirstlane(mine);
         if ((p.mesh_flags[in.mesh_index] & 1) == 0 && __ballot(!usable || mine != first) == 0ull) oct = first;
     }
-    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && UNIFORM_ORG && (!EX || POPS) && !(POPS && COUNT) && !ANYHIT && !STK::kSpill) {
+    // SEC (round 6: a secondary ray of the extension kernel -- origin per lane, a shadow ray done at its first hit -- on the optimistic
+    // stack): the hand-written loop or nothing.  A wave it does not cover (mixed sign octants, an exact-uv mesh) leaves with sp != 0,
+    // which is what an outgrown stack looks like: cast_ray_ex then casts the ray again on the general stack and the compiler's loop, so
+    // a cast site holds the eight hand-written loops and ONE compiled loop.
+    static_assert(!SEC || (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && POPS && !VIEW && !UNIFORM_ORG && !STK::kSpill && !DEBUG && !PROF && !COUNT), "SEC");
+    if constexpr (SEC) { if (!(oct >= 0 && in.exact_uv == 0)) { stack.sp = 1; return; } }
+    if constexpr (RT_ASM_LOOP && RT_SENTINEL && RT_OCTANTS && OCTANTS && !DEBUG && !PROF && (UNIFORM_ORG || SEC) && (!EX || POPS) && !(POPS && COUNT) && (!ANYHIT || SEC) && !STK::kSpill) {
         // the hand-written loop (trace_loop_asm) for what it covers; everything else takes the C++ loops below
-        if (oct >= 0 && in.exact_uv == 0) {
+        if (SEC || (oct >= 0 && in.exact_uv == 0)) {
             if constexpr (STATS) { loop_stat(p, RT_LOOP_ASM); if (in.unit_inv == 0) loop_stat(p, RT_LOOP_ASM_POSED); }
             stack.sp = 0;
             stack.push(kSentinel);
@@ -1233,7 +1281,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             const uintptr_t ia = in.unit_inv != 0 ? (uintptr_t)0 : (uintptr_t)&in;
             const DevInstance* general = (const DevInstance*)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ia >> 32)) << 32) |
                                                               (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ia));
-#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW, POPS, EX>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta, \
+#define RT_TRACE_ASM(O) trace_loop_asm<O, COUNT, (STK::kStride == 64 ? 8 : 10), VIEW, POPS, EX, SEC, ANYHIT>(p, inst_index, r, org, stack.lds, stack.lds_depth, cur, sp, hit, wave_iters, vdelta, \
                                                                                               POPS ? *pops : no_pops, point, back, general)
             switch (oct) {
             case 0: RT_TRACE_ASM(0); break;
@@ -1258,6 +1306,8 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
             return;
         }
     }
+    if constexpr (SEC) return;                                  // (never reached: both ways out are above)
+    else {
     // (the C++ loop reads view records for the primary kernels' rays only; an extension ray that does not qualify for the hand-written
     // loop reads the records themselves)
 #define RT_TRACE_LOOP(O) trace_loop<DEBUG, PROF, EX, COUNT, STK, POPS, O, ANYHIT, (VIEW && !EX)>(p, in, inst_index, r, org, stack, hit, cnt, iters, pops, vdelta)
@@ -1274,6 +1324,7 @@ __device__ __forceinline__ void trace_instance(const RenderParams& p, const DevI
     default: RT_TRACE_LOOP(-1); break;
     }
 #undef RT_TRACE_LOOP
+    }
 }
 
 __device__ __forceinline__ uint8_t to_u8(float f) { return (uint8_t)(int)f; }
@@ -1485,10 +1536,12 @@ __global__ __launch_bounds__(kPrimBlock, 8) void render_kernel(const RenderParam
 // (profiles/r05_experiments/ex_one_wave_workgroups.log).
 // VIEW (the samples-only kernel's primary rays: they share the frame's origin): the cast reads view records, see trace_loop.
 // PRIMARY: the ray starts at the camera in every lane (trace_instance's UNIFORM_ORG).
-template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false, class STK = Stack, bool OPTIMISTIC = false, bool VIEW = false, bool PRIMARY = false>
+// SEC: a secondary ray through the hand-written loop (trace_instance); with OCTANTS and OPTIMISTIC.
+template <bool LOC = true, bool OCTANTS = false, bool ANYHIT = false, class STK = Stack, bool OPTIMISTIC = false, bool VIEW = false, bool PRIMARY = false, bool SEC = false>
 __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir, STK& stack, int& pops)
 {
     static_assert(!VIEW || OPTIMISTIC, "view records are read by the LDS-only loops");
+    static_assert(!SEC || (OCTANTS && OPTIMISTIC && !VIEW && !PRIMARY), "SEC");
     Hit hit;
     hit.min = FLT_MAX; hit.slot = -1; hit.instance = -1; hit.u = 0.0f; hit.v = 0.0f;
     hit.loc = v3(0.0f, 0.0f, 0.0f);
@@ -1502,9 +1555,10 @@ __device__ __forceinline__ Hit cast_ray_ex(const RenderParams& p, V3 org, V3 dir
         int outgrown = 0;
         for (int i = 0; i < p.num_instances; i++) {
             if constexpr (ANYHIT) { if (hit.min < FLT_MAX) continue; }
-            trace_instance<false, false, LOC, false, StackT<STK::kStride, false, true>, true, OCTANTS, ANYHIT, VIEW, PRIMARY>(p, p.instances[i], i, org, dir, fast, hit, none, nullptr,
-                                                                                                                           &pops, p.view_base);
-            outgrown |= fast.sp;
+            trace_instance<false, false, LOC, false, StackT<STK::kStride, false, true>, true, OCTANTS, ANYHIT, VIEW, PRIMARY, false, SEC>(p, p.instances[i], i, org, dir, fast, hit, none,
+                                                                                                                                        nullptr, &pops, p.view_base);
+            // (a shadow ray that found its hit left the loop with entries on its stack: it is done, not outgrown)
+            outgrown |= (ANYHIT && SEC && hit.min < FLT_MAX) ? 0 : fast.sp;
         }
         if (outgrown == 0) return hit;
         pops = pops_before;
@@ -1598,7 +1652,7 @@ typedef StackT<kExBlock> ExStack;
 // operation on their results are the same, so the frame is the same bit for bit (tests: both forms against each other and the oracle).
 // The launch is cut into chunks of workgroups when the records of all of it would not fit the scratch budget (wg_base).
 template <bool SIMPLE, bool PX = false, bool VIEW = false, int PHASE = 0>
-__global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderParams p)
+__global__ __launch_bounds__(kExBlock, (SIMPLE ? 8 : RT_EX_BOUNCE_WAVES)) void render_ex_kernel(const RenderParams p)
 {
     static_assert(PHASE == 0 || (PX && !SIMPLE), "the two-launch form is the bounce kernel's, in the pixel-wave mapping");
     static_assert(PHASE != 2 || !VIEW, "phase 2 casts no camera ray");
@@ -1690,7 +1744,8 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
             const float cos_illum = dot(n, sun);
             illum = (float)(0.4 * (double)cos_illum);
             if (dot(n, sun) > 0) {
-                const Hit sh = cast_ray_ex<false, false, true, ExStack>(p, hit.loc + sun * (float)1e-4, sun, stack, pops);
+                const Hit sh = cast_ray_ex<false, (RT_EX_SECONDARY_ASM & 1) != 0, true, ExStack, (RT_EX_SECONDARY_ASM & 1) != 0, false, false, (RT_EX_SECONDARY_ASM & 1) != 0>(
+                    p, hit.loc + sun * (float)1e-4, sun, stack, pops);
                 if (sh.min == FLT_MAX) illum = (float)(1.0 * (double)cos_illum);
             }
         }
@@ -1720,7 +1775,8 @@ __global__ __launch_bounds__(kExBlock, 8) void render_ex_kernel(const RenderPara
     };
     auto step = [&](auto primary, const int depth) __attribute__((always_inline)) -> bool {
         constexpr bool kPrimary = RT_EX_PRIMARY_ASM && VIEW && decltype(primary)::value;
-        Hit hit = cast_ray_ex<true, kPrimary, false, ExStack, kPrimary, kPrimary, kPrimary>(p, org, dir, stack, pops);
+        constexpr bool kSec = (RT_EX_SECONDARY_ASM & 2) != 0 && !decltype(primary)::value;       // (a bounce ray)
+        Hit hit = cast_ray_ex<true, kPrimary || kSec, false, ExStack, kPrimary || kSec, kPrimary, kPrimary, kSec>(p, org, dir, stack, pops);
         return after_cast(hit, depth);
     };
     if constexpr (PHASE == 2) {
