@@ -1124,7 +1124,9 @@ __device__ __forceinline__ void trace_loop_asm(const RenderParams& p, int inst_i
     // -- as a SCALAR: a column starts less than one row pitch behind its wave's first column (4 bytes per lane), so `row < depth` is
     // `address < first column of the wave + depth * pitch` for every lane
     lds_int* sa = column + (sp << (ROW_SHIFT - 2));
-    const int32_t limit = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(size_t)(column - (int)__lane_id())) + (lds_depth << ROW_SHIFT);
+    // (scalar arithmetic on the first active lane's column: a per-lane `column - lane` would be one more value to keep across the loop)
+    const int32_t limit = __builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(size_t)column) - 4 * (int32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) +
+                          (lds_depth << ROW_SHIFT);
 #define RT_ASM_STACK_OUT [sa] "+v"(sa)
 #define RT_ASM_STACK_IN [lim] "s"(limit), [stride] "n"(1 << ROW_SHIFT)
 #else
