@@ -38,5 +38,6 @@ out["note"] = ("the command's 20-frame launches are: the warm-up, the nine timed
                "PCIe-inclusive measurement, whose launches run beside a device-to-host copy of the previous batch (the slow ones); the median is the figure to compare with the line")
 shutil.copy(ks, os.path.join(ROOT, "profiles", "%s_driver_command_kernel_stats.csv" % tag))
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_driver_command_kernel_trace.json" % tag), "w"), indent=1)
-json.dump(line, open(os.path.join(ROOT, "profiles", "%s_final_bench_driver.json" % tag), "w"), indent=1)
+# (the line printed UNDER the profiler: its own file -- profiles/<tag>_final_bench_driver.json is the line of tools/final_lines.sh, taken without one)
+json.dump(line, open(os.path.join(ROOT, "profiles", "%s_driver_command_bench_line_under_rocprof.json" % tag), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
