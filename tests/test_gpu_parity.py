@@ -1583,6 +1583,140 @@ def test_fuzz_extension_modes(rt, orc, scenes, blob5k, seed, monkeypatch):
     _compare_ex(rt, orc, desc, W, H, scenes.scaled_K(W), (0.2, -3.5, 0.5, 0.05, -0.1, 0.02), *opts)
 
 
+def _adversarial_mesh(o, rng):
+    """One mesh of a randomly chosen awkward kind, as [n,18] triangles (uv random).  Kinds: vertices on a coarse lattice (flat boxes,
+    shared edges, coplanar and coincident triangles), zero-area triangles (NaN normals), piles of coincident triangles (leaves above
+    30, equal-distance candidates), coordinates scaled to 1e6..1e18 or 1e-6..1e-20, needle-thin slivers (huge invDenom), a few
+    non-finite vertices (a flagged mesh: generic loop only), or a plain soup."""
+    kind = str(rng.choice(["lattice", "degenerate", "piles", "huge", "tiny", "sliver", "nonfinite", "soup", "soup"]))
+
+    def tris_from(v):
+        out = np.stack([o.tri_from_vertices(np.asarray(t, np.float32).ravel()) for t in v])
+        out[:, 12:18] = rng.uniform(0, 1, (len(out), 6)).astype(np.float32)
+        return out
+
+    soup = sd.random_triangles(int(rng.integers(1, 60)), seed=int(rng.integers(1 << 30)), spread=float(rng.uniform(0.3, 1.2)), size=float(rng.uniform(0.1, 0.6)))
+    if kind == "soup":
+        return kind, soup
+    if kind == "lattice":
+        step = float(rng.choice([0.25, 0.5, 1.0]))
+        n = int(rng.integers(4, 70))
+        v = rng.integers(-3, 4, (n, 3, 3)).astype(np.float32) * np.float32(step)
+        for i in range(n):
+            if rng.random() < 0.6:                                       # the triangle lies in a plane x / y / z = const
+                v[i, :, int(rng.integers(3))] = np.float32(rng.integers(-2, 3)) * np.float32(step)
+        return kind, tris_from(v)
+    if kind == "degenerate":
+        n = int(rng.integers(6, 40))
+        v = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32)
+        a, b = n // 3, 2 * n // 3
+        v[:a, 1] = v[:a, 0]                                              # two equal vertices
+        v[a:b, 2] = v[a:b, 0] + np.float32(rng.choice([2.0, 0.5, -1.0])) * (v[a:b, 1] - v[a:b, 0])   # collinear
+        v[b:b + 2] = v[b:b + 2, :1]                                      # a point
+        return kind, np.concatenate([tris_from(v), soup])
+    if kind == "piles":
+        base = sd.random_triangles(int(rng.integers(2, 6)), seed=int(rng.integers(1 << 30)), spread=0.5, size=0.6)
+        reps = [int(rng.choice([1, 2, 5, 31, 34, 45])) for _ in base]
+        return kind, np.concatenate([np.repeat(base[i:i + 1], r, axis=0) for i, r in enumerate(reps)])
+    if kind in ("huge", "tiny"):
+        e = float(rng.integers(6, 19)) if kind == "huge" else -float(rng.integers(6, 21))
+        m = np.float32(10.0 ** e)
+        v = (rng.uniform(-1, 1, (int(rng.integers(4, 30)), 3, 3)) * m).astype(np.float32)
+        v[:, :, 1] += np.float32(2.0) * m                                # in front of a camera that looks along +y from near the origin
+        return kind, (np.concatenate([tris_from(v), soup]) if rng.random() < 0.5 else tris_from(v))
+    if kind == "sliver":
+        n = int(rng.integers(4, 30))
+        v = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32)
+        t = rng.uniform(0.1, 0.9, (n, 1)).astype(np.float32)
+        v[:, 2] = v[:, 0] + t * (v[:, 1] - v[:, 0]) + rng.uniform(-1, 1, (n, 3)).astype(np.float32) * np.float32(10.0 ** -float(rng.integers(3, 8)))
+        return kind, np.concatenate([tris_from(v), soup])
+    bad = soup.copy()                                                    # nonfinite
+    for i in rng.integers(0, len(bad), int(rng.integers(1, 4))):
+        bad[i, int(rng.integers(9))] = np.float32(rng.choice([np.nan, np.inf, -np.inf]))
+        bad[i, :12] = o.tri_from_vertices(bad[i, :9])[:12]
+    return kind, bad
+
+
+def _adversarial_scene(scenes, rng, shiny=False):
+    """-> (SceneDesc, W, H, K, camera pose, description).  shiny: materials carry random roughness / metallic (extension modes)."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    kinds, meshes = [], []
+    for _ in range(int(rng.integers(1, 4))):
+        k, t = _adversarial_mesh(o, rng)
+        kinds.append(k); meshes.append(("tris", t))
+    materials = [(tuple(rng.uniform(0, 1, 3)), sd.checker_texture(int(rng.integers(2, 40)), int(rng.integers(2, 30)), seed=int(rng.integers(1 << 30))) if rng.random() < 0.5 else None)
+                 for _ in range(int(rng.integers(1, 3)))]
+    if shiny:
+        materials = [m + (dict(roughness=float(rng.choice([0.0, 0.05, 0.3])), metallic=float(rng.choice([0.0, 0.3, 0.8]))),) for m in materials]
+    half_pi = float(np.float32(np.pi / 2))
+    instances = []
+    for _ in range(int(rng.integers(1, 5))):
+        form = str(rng.choice(["identity", "translated", "lattice_step", "signed_zero", "quarter_turn", "any"]))
+        if form == "identity":
+            pose = (0.0,) * 6
+        elif form == "translated":
+            pose = tuple(rng.uniform(-1.5, 1.5, 3)) + (0.0, 0.0, 0.0)
+        elif form == "lattice_step":
+            pose = tuple(float(v) * 0.25 for v in rng.integers(-6, 7, 3)) + (0.0, 0.0, 0.0)
+        elif form == "signed_zero":
+            pose = tuple(float(np.float32(-0.0)) if rng.random() < 0.5 else 0.0 for _ in range(6))
+        elif form == "quarter_turn":
+            pose = tuple(rng.uniform(-1, 1, 3)) + tuple(half_pi * float(v) for v in rng.integers(-2, 3, 3))
+        else:
+            pose = tuple(np.concatenate([rng.uniform(-1.5, 1.5, 3), rng.uniform(-3.1, 3.1, 3)]))
+        sform = str(rng.choice(["unit", "unit", "pow2", "mirror", "large", "small", "any"]))
+        scale = {"unit": (1.0, 1.0, 1.0),
+                 "pow2": tuple(float(2.0 ** v) for v in rng.integers(-2, 3, 3)),
+                 "mirror": tuple(float(v) for v in rng.choice([-1.0, 1.0, -0.5, 2.0], 3)),
+                 "large": tuple(float(v) for v in rng.uniform(1e2, 1e4, 3)),
+                 "small": tuple(float(v) for v in rng.uniform(1e-4, 1e-2, 3)),
+                 "any": tuple(rng.uniform(0.3, 1.8, 3))}[sform]
+        instances.append((int(rng.integers(len(meshes))), int(rng.integers(len(materials))), pose, scale))
+    W, H = int(rng.integers(16, 97)), int(rng.integers(16, 65))
+    K = scenes.scaled_K(W)
+    view = str(rng.choice(["any", "axis", "on_lattice", "inside"]))
+    if view == "any":
+        cam_pose = tuple(np.concatenate([rng.uniform(-1, 1, 1), rng.uniform(-5, -2, 1), rng.uniform(-1, 1, 1), rng.uniform(-0.4, 0.4, 3)]))
+    elif view == "inside":
+        cam_pose = tuple(np.concatenate([rng.uniform(-0.5, 0.5, 3), rng.uniform(-3.1, 3.1, 3)]))
+    else:
+        # the principal point on a pixel centre and no rotation: the centre column / row of rays have direction components that are 0
+        W, H = W & ~1, H & ~1
+        K = (K[0], 0.0, W / 2.0, 0.0, K[4], H / 2.0, 0.0, 0.0, 1.0)
+        cam_pose = ((0.0, -3.0, 0.0) if view == "axis" else tuple(float(v) * 0.25 for v in (rng.integers(-4, 5), rng.integers(-16, -7), rng.integers(-4, 5)))) + (0.0, 0.0, 0.0)
+    info = "meshes %s instances %s view %s %s" % (kinds, [(i[0], i[2], i[3]) for i in instances], view, (W, H))
+    return sd.SceneDesc(materials, meshes, instances), W, H, K, cam_pose, info
+
+
+# RT_FUZZ_ADV_SEEDS=n / RT_FUZZ_ADV_FIRST=k: a campaign of the adversarial fuzz below (the suite runs 12 seeds)
+_ADV_FIRST = int(os.environ.get("RT_FUZZ_ADV_FIRST", 0))
+@pytest.mark.parametrize("seed", range(_ADV_FIRST, _ADV_FIRST + int(os.environ.get("RT_FUZZ_ADV_SEEDS", 12))))
+def test_fuzz_adversarial_scenes(rt, orc, scenes, seed):
+    """Differential fuzzing where the arithmetic is least comfortable (round 6, third session): test_degenerate_and_extreme_geometry
+    and test_non_finite_vertices_... hold one fixed scene per kind, every one a single instance; here the kinds are drawn at random and
+    COMBINED with the instance forms the hand-written loop distinguishes -- identity, translated only (also by lattice steps and signed
+    zeros), quarter turns, any rotation; unit, power-of-two, mirrored (a negative component), very large and very small scales -- and
+    with cameras whose central rays have direction components that are exactly zero (infinite inverses: the generic loop for those
+    waves), that sit on the lattice the triangles use (rays along edges and in triangle planes), or inside the geometry.  Every plane
+    and the RGB against the oracle, production and instrumented kernel, single frame and a batch of four through view records."""
+    desc, W, H, K, cam_pose, info = _adversarial_scene(scenes, np.random.default_rng(31000 + seed))
+    print("seed", seed, info)
+    _compare(rt, orc, desc, W, H, K, scenes.D_REF, cam_pose, threads=4, gpu_build=seed % 3 == 2)
+
+
+@pytest.mark.parametrize("seed", range(_ADV_FIRST, _ADV_FIRST + max(4, int(os.environ.get("RT_FUZZ_ADV_SEEDS", 12)) // 3)))
+def test_fuzz_adversarial_extension_modes(rt, orc, scenes, seed):
+    """The same awkward scenes through the extension kernel (random spp / bounces / lighting, rough and metallic materials): secondary rays
+    that start at hits on zero-area triangles (NaN normals), mirrored and extreme scales, origins on the lattice.  Semantics are this
+    project's own: image and total pops against its oracle."""
+    rng = np.random.default_rng(47000 + seed)
+    desc, W, H, K, cam_pose, info = _adversarial_scene(scenes, rng, shiny=True)
+    opts = (int(rng.integers(1, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 2)))
+    print("seed", seed, info, "spp / bounces / lighting", opts)
+    _compare_ex(rt, orc, desc, W, H, K, cam_pose, *opts, threads=4)
+
+
 def test_million_triangle_mesh(rt, orc, scenes, tmp_path):
     """Scale check: a 999 680-triangle blob (1.9 M BVH nodes, 32 levels -- the builder's depth cap, so deep leaves hold
     several triangles and the traversal stack spills).  GPU-built tree == host-built tree; a 24-row band of the 1080p

@@ -215,6 +215,60 @@ def test_host_bvh_random_soups(rt, oracle):
     assert same(single["tris"], oracle.mesh_dump(oracle.mesh_single_triangle([-1, 0, -1, 1, 0, -1, 0, 0, 1]))["tris"])
 
 
+def _same_or_both_nan(a, b):
+    a = np.ascontiguousarray(a, np.float32).ravel()
+    b = np.ascontiguousarray(b, np.float32).ravel()
+    return a.shape == b.shape and bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_host_bvh_awkward_meshes_vs_oracle(rt, oracle):
+    """The product's host builder against the oracle's (which test_oracle_pins.py holds against the reference's own BVHTree::fill on the
+    same meshes): lattice vertices, zero-area triangles, piles of coincident triangles, 1e18 / 1e-20 coordinates, slivers, NaN and
+    infinite vertices (NaN boxes compared as NaN) -- the mesh kinds of the adversarial GPU fuzz."""
+    import test_gpu_parity as gp
+    for seed in range(400):
+        kind, tris = gp._adversarial_mesh(oracle, np.random.default_rng(52000 + seed))
+        d, e = rt.Mesh.from_triangles(tris).dump(), oracle.mesh_dump(oracle.mesh_from_triangles(tris))
+        assert _same_or_both_nan(d["boxes"], e["boxes"]) and _same_or_both_nan(d["tris"], e["tris"]), (seed, kind)
+        for k in ("child", "leaf_count", "leaf_idx"):
+            assert np.array_equal(d[k], e[k]), (seed, kind, k)
+
+
+def test_host_math_on_special_values_vs_oracle(rt, oracle):
+    """Pose algebra and MeshInstance::build_inv of the host library against the oracle on zeros of both signs, denormals, FLT_MAX,
+    infinities, NaN, 1e-20 / 1e18 mixed with ordinary values (the oracle against the reference's own code on such values:
+    test_oracle_pins.py::test_oracle_vs_reference_live_on_special_values)."""
+    import test_oracle_pins as op
+    _, s = rt.libs()
+    f = C.POINTER(C.c_float)
+
+    def call(fn, n_out, *ins):
+        out = np.zeros(n_out, np.float32)
+        fn(*[np.ascontiguousarray(a, np.float32).ctypes.data_as(f) for a in ins], out.ctypes.data_as(f))
+        return out
+    import orc as orc_mod
+    ref = orc_mod.ref_probe()
+    rng = np.random.default_rng(777)
+    with np.errstate(all="ignore"):
+        for it in range(4000):
+            ps = (0.0, 0.15, 0.5, 0.5)[it % 4]
+            v, p = op._draw(rng, 3, ps), np.concatenate([op._draw(rng, 3, ps), op._draw(rng, 3, ps, 3.0)])
+            m9 = op._draw(rng, 9, ps)
+            assert _same_or_both_nan(call(s.rth_normalize, 3, v), oracle.normalize(v)), ("normalize", v)
+            assert _same_or_both_nan(call(s.rth_invert_lre, 6, p), oracle.invert_lre(p)), ("invert_lre", p)
+            assert _same_or_both_nan(call(s.rth_euler2quat, 4, p[3:]), oracle.euler2quat(p[3:])), ("euler2quat", p)
+            assert _same_or_both_nan(call(s.rth_apply_lre, 3, p, v), oracle.apply_lre(p, v)), ("apply_lre", p, v)
+            assert _same_or_both_nan(call(s.rth_invert_intrinsic, 9, m9), oracle.invert_intrinsic(m9)), ("invert_intrinsic", m9)
+            x = float(op._draw(rng, 1, ps)[0])
+            assert _same_or_both_nan(s.rth_q_rsqrt(x), oracle.q_rsqrt(x)), ("q_rsqrt", x)
+            # MeshInstance::build_inv (MeshInstance.hpp): against the reference's own constructor where oracle/_ref was built
+            if ref is not None:
+                sc = op._draw(rng, 3, ps, 1.0)
+                buf = np.zeros(26, np.float32)
+                ref.lib.ref_instance_build(0, 0, np.ascontiguousarray(p, np.float32).ctypes.data_as(f), sc.ctypes.data_as(f), buf.ctypes.data)
+                assert _same_or_both_nan(call(s.rth_instance_build, 24, p, sc), buf[2:]), ("instance_build", p, sc)
+
+
 def test_obj_loader_error_behaviour(rt, tmp_path):
     with pytest.raises(rt.RtError, match="Could not open file"):
         rt.Mesh.load_obj(str(tmp_path / "missing.obj"))
