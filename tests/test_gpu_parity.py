@@ -1706,14 +1706,17 @@ def test_fuzz_adversarial_scenes(rt, orc, scenes, seed):
 
 
 @pytest.mark.parametrize("seed", range(_ADV_FIRST, _ADV_FIRST + max(4, int(os.environ.get("RT_FUZZ_ADV_SEEDS", 12)) // 3)))
-def test_fuzz_adversarial_extension_modes(rt, orc, scenes, seed):
+def test_fuzz_adversarial_extension_modes(rt, orc, scenes, seed, monkeypatch):
     """The same awkward scenes through the extension kernel (random spp / bounces / lighting, rough and metallic materials): secondary rays
     that start at hits on zero-area triangles (NaN normals), mirrored and extreme scales, origins on the lattice.  Semantics are this
-    project's own: image and total pops against its oracle."""
+    project's own: image and total pops against its oracle -- the default form, then one of the two opt-in forms
+    (two launches, RT_EX_SPLIT=1, on even seeds; the wavefront form, RT_EX_WAVEFRONT=1, on odd ones)."""
     rng = np.random.default_rng(47000 + seed)
     desc, W, H, K, cam_pose, info = _adversarial_scene(scenes, rng, shiny=True)
     opts = (int(rng.integers(1, 9)), int(rng.integers(0, 5)), int(rng.integers(0, 2)))
     print("seed", seed, info, "spp / bounces / lighting", opts)
+    _compare_ex(rt, orc, desc, W, H, K, cam_pose, *opts, threads=4)
+    monkeypatch.setenv("RT_EX_SPLIT" if seed % 2 == 0 else "RT_EX_WAVEFRONT", "1")
     _compare_ex(rt, orc, desc, W, H, K, cam_pose, *opts, threads=4)
 
 

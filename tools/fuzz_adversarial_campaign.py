@@ -34,7 +34,7 @@ res = {"campaign": "adversarial differential fuzz, HIP path vs CPU oracle: awkwa
        "kernel_code_hash": importlib.import_module("cuda-raytracing_amd").library_hash(),
        "test_fuzz_adversarial_scenes": {"seeds": [first, first + n], "rng": "numpy.random.default_rng(31000 + seed)", "gpu_built_tree": "seed % 3 == 2",
                                         "checked": "RGB + hit ids of the production kernel, six planes of the instrumented kernel, a batch of four frames through view records"},
-       "test_fuzz_adversarial_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(47000 + seed)", "checked": "RGB + total pops"},
+       "test_fuzz_adversarial_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(47000 + seed)", "checked": "RGB + total pops; the default form, then the two-launch form (even seeds) or the wavefront form (odd seeds)"},
        "cases": passed + len(failed), "passed": passed, "failed": failed, "pytest_exit_code": proc.returncode, "pytest_summary": summary,
        "seconds": round(time.time() - t0, 1)}
 json.dump(res, open(out, "w"), indent=1)
