@@ -1720,6 +1720,48 @@ def test_fuzz_adversarial_extension_modes(rt, orc, scenes, seed, monkeypatch):
     _compare_ex(rt, orc, desc, W, H, K, cam_pose, *opts, threads=4)
 
 
+@pytest.mark.parametrize("seed", range(_ADV_FIRST, _ADV_FIRST + max(4, int(os.environ.get("RT_FUZZ_ADV_SEEDS", 12)) // 3)))
+def test_fuzz_adversarial_refit_and_rebuild(rt, orc, scenes, seed):
+    """An awkward scene whose first mesh is then (a) REFITTED to the triangles of another awkward mesh of the same count (the tree keeps its
+    topology, every node gets the bounds of whatever its triangles became: flat, infinite, NaN -- the mesh flag of the octant loops is
+    decided anew) and (b) REBUILT on the device from a third one with at most as many triangles: all planes against the oracle after each
+    step (orc_mesh_refit on the same tree; a fresh oracle mesh for the rebuild)."""
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    rng = np.random.default_rng(59000 + seed)
+    desc, W, H, K, cam_pose, info = _adversarial_scene(scenes, rng)
+    n0 = len(desc.meshes[0][1])
+    kind_b, b = _adversarial_mesh(o, rng)
+    b = b[np.arange(n0) % len(b)]                               # the same count, in some order (a refit is any new set of n triangles)
+    kind_c, c = _adversarial_mesh(o, rng)
+    c = c[:n0]
+    print("seed", seed, info, "refit to", kind_b, "rebuild from", kind_c, len(c))
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    cam.set_pose(cam_pose)
+
+    def check(sp, so, what):
+        ref = so.render(W, H, K, scenes.D_REF, cam_pose, threads=4)
+        dbg = rt.render_debug(sp, cam)
+        for n in ("img",) + PLANES:
+            assert np.array_equal(dbg[n], ref[n]), (what, n, int((dbg[n] != ref[n]).sum()))
+        ids = rt.render_ids(sp, cam)
+        assert np.array_equal(ids["img"], ref["img"]) and np.array_equal(ids["hit_tri"], ref["hit_tri"]) and np.array_equal(ids["hit_inst"], ref["hit_inst"]), what
+
+    so = desc.build_oracle(orc)
+    sp = desc.build_product(rt, gpu_build=seed % 2 == 1)
+    sp.upload_to_device()
+    check(sp, so, "as uploaded")
+    sp.refit_mesh(0, b)
+    o.mesh_refit(desc.oracle_meshes[0], b)
+    check(sp, so, "refitted")
+    so.close()
+    sp.rebuild_mesh(0, c)
+    desc_c = sd.SceneDesc(desc.materials, [("tris", c)] + list(desc.meshes[1:]), desc.instances)
+    so = desc_c.build_oracle(orc)
+    check(sp, so, "rebuilt")
+    so.close()
+
+
 def test_million_triangle_mesh(rt, orc, scenes, tmp_path):
     """Scale check: a 999 680-triangle blob (1.9 M BVH nodes, 32 levels -- the builder's depth cap, so deep leaves hold
     several triangles and the traversal stack spills).  GPU-built tree == host-built tree; a 24-row band of the 1080p

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off campaign of the ADVERSARIAL differential fuzz on the GPU box: tests/test_gpu_parity.py::test_fuzz_adversarial_scenes with N
 seeds (numpy default_rng(31000 + seed): awkward mesh kinds x instance forms x cameras, every parity plane against the CPU oracle) and
-::test_fuzz_adversarial_extension_modes with N // 3 seeds (default_rng(47000 + seed)).  Writes seeds and result as JSON
+::test_fuzz_adversarial_extension_modes (default_rng(47000 + seed)) and ::test_fuzz_adversarial_refit_and_rebuild (default_rng(59000 + seed))
+with N // 3 seeds each.  Writes seeds and result as JSON
 (profiles/rNN_experiments/fuzz_adversarial_*.json).
    python tools/fuzz_adversarial_campaign.py <n_seeds> <out.json> [first_seed]"""
 import importlib, json, os, re, subprocess, sys, threading, time
@@ -35,6 +36,8 @@ res = {"campaign": "adversarial differential fuzz, HIP path vs CPU oracle: awkwa
        "test_fuzz_adversarial_scenes": {"seeds": [first, first + n], "rng": "numpy.random.default_rng(31000 + seed)", "gpu_built_tree": "seed % 3 == 2",
                                         "checked": "RGB + hit ids of the production kernel, six planes of the instrumented kernel, a batch of four frames through view records"},
        "test_fuzz_adversarial_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(47000 + seed)", "checked": "RGB + total pops; the default form, then the two-launch form (even seeds) or the wavefront form (odd seeds)"},
+       "test_fuzz_adversarial_refit_and_rebuild": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(59000 + seed)",
+                                                   "checked": "all planes as uploaded, after a refit to another awkward mesh, after a device rebuild from a third"},
        "cases": passed + len(failed), "passed": passed, "failed": failed, "pytest_exit_code": proc.returncode, "pytest_summary": summary,
        "seconds": round(time.time() - t0, 1)}
 json.dump(res, open(out, "w"), indent=1)
