@@ -31,7 +31,8 @@ public:
     BVHTree bvh_top;
     d_MeshPrimitive* to_device();                               // MeshPrimitive.h:36: this mesh's records on the current device
     const std::vector<TrianglePrimitive>& triangle_array() const { return triangles; }
-    // deformation with fixed connectivity: replaces the triangles (same count) and refits the BVH bounds; false if the count differs.
+    // deformation with fixed connectivity: replaces the triangles' vertices and normals (same count; uv_coords stay as they are) and
+    // refits the BVH bounds; false if the count differs.
     // defer_tree = true leaves bvh_top's bounds as they are until sync_tree() -- Scene::refit_mesh does that for an uploaded
     // scene, whose device copy is refitted by the GPU at once: walking the host tree costs twenty times the device refit
     // and is only needed if the mesh is uploaded again or bvh_top is read (call sync_tree() first).

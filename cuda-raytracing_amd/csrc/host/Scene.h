@@ -32,8 +32,8 @@ public:
     void update_mesh_instance(int index, MeshInstance mesh_instance);   // rt_scene_update_instance (Scene.cpp:67-74)
     // the same, ordered on a stream instead of synchronising (rt_scene_update_instance_async): for per-frame animation
     void update_mesh_instance(int index, MeshInstance mesh_instance, void* stream);
-    // A mesh deforms (same triangle count and order): host copy and device copy get the moved triangles and refitted
-    // bounds; no rebuild, no re-upload of anything else.  Ordered on `stream` like update_mesh_instance(.., stream).
+    // A mesh deforms (same triangle count and order): host copy and device copy get the moved vertices and normals and refitted
+    // bounds -- texture coordinates stay; no rebuild, no re-upload of anything else.  Ordered on `stream` like update_mesh_instance(.., stream).
     void refit_mesh(int mesh_index, std::vector<TrianglePrimitive> moved, void* stream = nullptr);
     // A mesh changes beyond what a refit can follow (large motion, or other triangles): the device copy gets a NEW tree, built on
     // the GPU straight into the scene's arrays (rt_scene_rebuild_mesh_device), the host copy rebuilds its tree when it is next

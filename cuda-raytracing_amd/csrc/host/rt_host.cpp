@@ -482,6 +482,11 @@ void Scene::upload_to_device()
 bool MeshPrimitive::refit(std::vector<TrianglePrimitive> moved, bool defer_tree)
 {
     if ((int)moved.size() != num_triangles) return false;
+    // A refit moves vertices and normals; texture coordinates stay (rt_scene_refit_mesh takes none -- "uvs and the tree's topology
+    // stay", rt_hip.h): whatever uv_coords the caller's triangles carry, the host copy keeps the ones it has, so that a later
+    // upload_to_device() sends what the refitted device copy renders with.
+    for (size_t i = 0; i < moved.size(); i++)
+        for (int k = 0; k < 3; k++) moved[i].uv_coords[k] = triangles[i].uv_coords[k];
     triangles = std::move(moved);
     tree_stale = true;
     if (!defer_tree) sync_tree();

@@ -1733,6 +1733,8 @@ def test_fuzz_adversarial_refit_and_rebuild(rt, orc, scenes, seed):
     n0 = len(desc.meshes[0][1])
     kind_b, b = _adversarial_mesh(o, rng)
     b = b[np.arange(n0) % len(b)]                               # the same count, in some order (a refit is any new set of n triangles)
+    b_kept = b.copy()                                           # ... of which vertices and normals count: texture coordinates stay (rt_hip.h),
+    b_kept[:, 12:18] = desc.meshes[0][1][:, 12:18]              # whatever the caller's triangles carry (here: other random values)
     kind_c, c = _adversarial_mesh(o, rng)
     c = c[:n0]
     print("seed", seed, info, "refit to", kind_b, "rebuild from", kind_c, len(c))
@@ -1752,8 +1754,10 @@ def test_fuzz_adversarial_refit_and_rebuild(rt, orc, scenes, seed):
     sp.upload_to_device()
     check(sp, so, "as uploaded")
     sp.refit_mesh(0, b)
-    o.mesh_refit(desc.oracle_meshes[0], b)
+    o.mesh_refit(desc.oracle_meshes[0], b_kept)
     check(sp, so, "refitted")
+    sp.upload_to_device()                                       # the host copy was refitted too, and kept its texture coordinates as well
+    check(sp, so, "uploaded again after the refit")
     so.close()
     sp.rebuild_mesh(0, c)
     desc_c = sd.SceneDesc(desc.materials, [("tris", c)] + list(desc.meshes[1:]), desc.instances)
