@@ -1724,8 +1724,8 @@ def test_fuzz_adversarial_extension_modes(rt, orc, scenes, seed, monkeypatch):
 def test_fuzz_adversarial_refit_and_rebuild(rt, orc, scenes, seed):
     """An awkward scene whose first mesh is then (a) REFITTED to the triangles of another awkward mesh of the same count (the tree keeps its
     topology, every node gets the bounds of whatever its triangles became: flat, infinite, NaN -- the mesh flag of the octant loops is
-    decided anew) and (b) REBUILT on the device from a third one with at most as many triangles: all planes against the oracle after each
-    step (orc_mesh_refit on the same tree; a fresh oracle mesh for the rebuild)."""
+    decided anew), (b) REBUILT on the device from a third one with at most as many triangles, and whose instances (c) all get another awkward
+    pose and scale: all planes against the oracle after each step (orc_mesh_refit on the same tree; a fresh oracle mesh for the rebuild)."""
     import orc as orc_mod
     o = orc_mod.oracle()
     rng = np.random.default_rng(59000 + seed)
@@ -1763,6 +1763,14 @@ def test_fuzz_adversarial_refit_and_rebuild(rt, orc, scenes, seed):
     desc_c = sd.SceneDesc(desc.materials, [("tris", c)] + list(desc.meshes[1:]), desc.instances)
     so = desc_c.build_oracle(orc)
     check(sp, so, "rebuilt")
+    # (c) every instance gets another awkward form (Scene::update_mesh_instance, Scene.cpp:67-74), alternately synchronising and ordered
+    # on the default stream: the flags the loops branch on (identity / unit inverse pose) are decided anew per update
+    other = _adversarial_scene(scenes, np.random.default_rng(61000 + seed))[0].instances
+    for i, (mesh, mat, _, _) in enumerate(desc.instances):
+        pose, scale = other[i % len(other)][2], other[i % len(other)][3]
+        sp.update_mesh_instance(i, mesh, mat, pose, scale, stream=False if i % 2 == 0 else None)
+        so.update_instance(i, mesh, mat, pose, scale)
+    check(sp, so, "instances updated")
     so.close()
 
 
