@@ -1774,6 +1774,127 @@ def test_fuzz_adversarial_refit_and_rebuild(rt, orc, scenes, seed):
     so.close()
 
 
+@pytest.mark.parametrize("seed", range(_ADV_FIRST, _ADV_FIRST + max(4, int(os.environ.get("RT_FUZZ_ADV_SEEDS", 12)) // 3)))
+def test_fuzz_adversarial_api_sequences(rt, orc, scenes, seed):
+    """Stateful differential fuzzing of the boundary: a random SEQUENCE of the calls that change an uploaded scene -- refit of a mesh
+    (other texture coordinates passed on purpose: they stay), rebuild of a mesh on the device (fewer triangles, as many, or more than it
+    was uploaded with: the scene is uploaded again), update of an instance (pose, scale, mesh and material; synchronising or ordered on
+    the default stream), upload_to_device() again -- over awkward scenes, and after EVERY call a frame through a randomly chosen
+    entry point against the oracle, which mirrors the sequence (orc_mesh_refit on the same tree, a fresh mesh for a rebuild): the
+    instrumented kernel's planes, the production kernel's hit ids, a batch of four frames with two poses (view records), stripes of
+    2-5 virtual ranks put back by rt_unstripe, two default-stream frames into two images (rt_render_overlapped)."""
+    import ctypes as C
+    import orc as orc_mod
+    o = orc_mod.oracle()
+    h = rt.libs()[0]
+    rng = np.random.default_rng(67000 + seed)
+    desc, W, H, K, cam_pose, info = _adversarial_scene(scenes, rng)
+    pose2 = tuple(np.asarray(cam_pose, np.float64) + np.concatenate([rng.uniform(-0.2, 0.2, 3), rng.uniform(-0.1, 0.1, 3)]))
+    meshes = [dict(tris=t.copy(), h=o.mesh_from_triangles(t)) for _, t in desc.meshes]
+    instances = [list(i) for i in desc.instances]
+    mats = desc.materials
+    sp = desc.build_product(rt, gpu_build=bool(rng.integers(2)))
+    sp.upload_to_device()
+    cam = rt.Camera(W, H, K, scenes.D_REF)
+    log = [info]
+
+    def oracle_frames(poses):
+        so = orc_mod.OracleScene(o)
+        for m in mats:
+            so.add_material(m[0], m[1])
+        for m in meshes:
+            so.add_mesh(m["h"])
+        for mesh, mat, pose, scale in instances:
+            so.add_instance(mesh, mat, pose, scale)
+        out = [so.render(W, H, K, scenes.D_REF, p, threads=4) for p in poses]
+        so.close()
+        return out
+
+    def check(step):
+        via = str(rng.choice(["planes", "ids", "batch", "stripes", "default_stream"]))
+        log.append("check via " + via)
+        what = "seed %d step %d: %s" % (seed, step, "; ".join(log))
+        cam.set_pose(cam_pose)
+        if via == "planes":
+            ref, = oracle_frames([cam_pose])
+            dbg = rt.render_debug(sp, cam)
+            for n in ("img",) + PLANES:
+                assert np.array_equal(dbg[n], ref[n]), (n, what)
+        elif via == "ids":
+            ref, = oracle_frames([cam_pose])
+            ids = rt.render_ids(sp, cam)
+            for n in ("img", "hit_tri", "hit_inst"):
+                assert np.array_equal(ids[n], ref[n]), (n, what)
+        elif via == "batch":
+            ref = oracle_frames([cam_pose, pose2])
+            bufs = [rt.DeviceBuffer(width_bytes=W * 3, height=H) for _ in range(4)]
+            cam.render_scene_batch(sp, [cam_pose, pose2, pose2, cam_pose], [b.ptr for b in bufs], bufs[0].pitch, synchronize=True)
+            for k, b in enumerate(bufs):
+                assert np.array_equal(b.to_host().reshape(H, W, 3), ref[(0, 1, 1, 0)[k]]["img"]), ("frame %d" % k, what, sp.view_stats())
+                b.free()
+        elif via == "stripes":
+            ref, = oracle_frames([cam_pose])
+            nr, stripe = int(rng.integers(2, 6)), int(rng.choice([3, 4, 8, 16]))
+            rows = []
+            for r in range(nr):
+                n = C.c_int32(0)
+                rt.check(h.rt_stripe_rows(H, stripe, r, nr, C.byref(n)))
+                rows.append(n.value)
+            maxr, pitch = max(max(rows), 1), W * 3
+            gathered = rt.DeviceBuffer(nbytes=nr * maxr * pitch)
+            for r in range(nr):
+                cam.render_scene_stripes(sp, gathered.ptr.value + r * maxr * pitch, pitch, stripe, r, nr, synchronize=True)
+            out = rt.DeviceBuffer(width_bytes=W * 3, height=H)
+            rt.check(h.rt_unstripe(gathered.ptr, pitch, maxr * pitch, out.ptr, out.pitch, W, H, stripe, nr, None))
+            rt.check(h.rt_device_synchronize())
+            assert np.array_equal(out.to_host().reshape(H, W, 3), ref["img"]), ("%d ranks, %d-row stripes" % (nr, stripe), what)
+            gathered.free(); out.free()
+        else:
+            ref = oracle_frames([cam_pose, pose2])
+            a, b = rt.DeviceBuffer(width_bytes=W * 3, height=H), rt.DeviceBuffer(width_bytes=W * 3, height=H)
+            cam.render_scene(sp, a.ptr, a.pitch)                   # the reference's loop: two frames on the default stream, then a synchronise
+            cam.set_pose(pose2)
+            cam.render_scene(sp, b.ptr, b.pitch)
+            rt.check(h.rt_device_synchronize())
+            assert np.array_equal(a.to_host().reshape(H, W, 3), ref[0]["img"]) and np.array_equal(b.to_host().reshape(H, W, 3), ref[1]["img"]), what
+            a.free(); b.free()
+
+    check(0)
+    for step in range(1, 7):
+        op = str(rng.choice(["refit", "rebuild", "instance", "instance", "upload"]))
+        if op == "refit":
+            i = int(rng.integers(len(meshes)))
+            n = len(meshes[i]["tris"])
+            kind, t = _adversarial_mesh(o, rng)
+            t = t[np.arange(n) % len(t)]
+            kept = t.copy()
+            kept[:, 12:18] = meshes[i]["tris"][:, 12:18]
+            log.append("refit mesh %d to %s" % (i, kind))
+            sp.refit_mesh(i, t)
+            o.mesh_refit(meshes[i]["h"], kept)
+            meshes[i]["tris"] = kept
+        elif op == "rebuild":
+            i = int(rng.integers(len(meshes)))
+            kind, t = _adversarial_mesh(o, rng)
+            n = len(meshes[i]["tris"])
+            if rng.random() < 0.75:
+                t = t[:max(1, int(rng.integers(1, n + 1)))]
+            log.append("rebuild mesh %d from %s, %d -> %d triangles" % (i, kind, n, len(t)))
+            sp.rebuild_mesh(i, t)
+            meshes[i] = dict(tris=t.copy(), h=o.mesh_from_triangles(t))
+        elif op == "instance":
+            i = int(rng.integers(len(instances)))
+            src = _adversarial_scene(scenes, np.random.default_rng(int(rng.integers(1 << 30))))[0].instances[0]
+            new = [int(rng.integers(len(meshes))), int(rng.integers(len(mats))), src[2], src[3]]
+            log.append("instance %d -> mesh %d material %d pose %s scale %s" % (i, new[0], new[1], new[2], new[3]))
+            sp.update_mesh_instance(i, *new, stream=False if rng.random() < 0.5 else None)
+            instances[i] = new
+        else:
+            log.append("upload again")
+            sp.upload_to_device()
+        check(step)
+
+
 def test_million_triangle_mesh(rt, orc, scenes, tmp_path):
     """Scale check: a 999 680-triangle blob (1.9 M BVH nodes, 32 levels -- the builder's depth cap, so deep leaves hold
     several triangles and the traversal stack spills).  GPU-built tree == host-built tree; a 24-row band of the 1080p

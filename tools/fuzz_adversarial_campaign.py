@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """One-off campaign of the ADVERSARIAL differential fuzz on the GPU box: tests/test_gpu_parity.py::test_fuzz_adversarial_scenes with N
 seeds (numpy default_rng(31000 + seed): awkward mesh kinds x instance forms x cameras, every parity plane against the CPU oracle) and
-::test_fuzz_adversarial_extension_modes (default_rng(47000 + seed)) and ::test_fuzz_adversarial_refit_and_rebuild (default_rng(59000 + seed))
-with N // 3 seeds each.  Writes seeds and result as JSON
+::test_fuzz_adversarial_extension_modes (default_rng(47000 + seed)), ::test_fuzz_adversarial_refit_and_rebuild (default_rng(59000 + seed))
+and ::test_fuzz_adversarial_api_sequences (default_rng(67000 + seed)) with N // 3 seeds each.  Writes seeds and result as JSON
 (profiles/rNN_experiments/fuzz_adversarial_*.json).
    python tools/fuzz_adversarial_campaign.py <n_seeds> <out.json> [first_seed]"""
 import importlib, json, os, re, subprocess, sys, threading, time
@@ -38,6 +38,9 @@ res = {"campaign": "adversarial differential fuzz, HIP path vs CPU oracle: awkwa
        "test_fuzz_adversarial_extension_modes": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(47000 + seed)", "checked": "RGB + total pops; the default form, then the two-launch form (even seeds) or the wavefront form (odd seeds)"},
        "test_fuzz_adversarial_refit_and_rebuild": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(59000 + seed)",
                                                    "checked": "all planes as uploaded, after a refit to another awkward mesh, after a device rebuild from a third"},
+       "test_fuzz_adversarial_api_sequences": {"seeds": [first, first + max(4, n // 3)], "rng": "numpy.random.default_rng(67000 + seed)",
+                                               "checked": "six random scene-changing calls (refit / rebuild incl. growth / instance update / upload again), after each a frame "
+                                                          "through a random entry point (planes, hit ids, batch of four with two poses, stripes + rt_unstripe, two default-stream frames)"},
        "cases": passed + len(failed), "passed": passed, "failed": failed, "pytest_exit_code": proc.returncode, "pytest_summary": summary,
        "seconds": round(time.time() - t0, 1)}
 json.dump(res, open(out, "w"), indent=1)
