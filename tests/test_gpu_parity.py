@@ -1790,7 +1790,16 @@ def test_fuzz_adversarial_api_sequences(rt, orc, scenes, seed):
     rng = np.random.default_rng(67000 + seed)
     desc, W, H, K, cam_pose, info = _adversarial_scene(scenes, rng)
     pose2 = tuple(np.asarray(cam_pose, np.float64) + np.concatenate([rng.uniform(-0.2, 0.2, 3), rng.uniform(-0.1, 0.1, 3)]))
-    meshes = [dict(tris=t.copy(), h=o.mesh_from_triangles(t)) for _, t in desc.meshes]
+    # per mesh: its triangles, the oracle's mesh, how many triangles its part of the device arrays holds, and whether it was rebuilt --
+    # the host copy of a rebuilt mesh has no tree of its own (the device built it), so EVERY later upload of the scene builds that
+    # mesh's tree anew from the triangles it has then (refits since the rebuild included), where an un-rebuilt mesh keeps its topology
+    meshes = [dict(tris=t.copy(), h=o.mesh_from_triangles(t), cap=len(t), rebuilt=False) for _, t in desc.meshes]
+
+    def uploaded_again():
+        for m in meshes:
+            m["cap"] = len(m["tris"])
+            if m["rebuilt"]:
+                m["h"] = o.mesh_from_triangles(m["tris"])
     instances = [list(i) for i in desc.instances]
     mats = desc.materials
     sp = desc.build_product(rt, gpu_build=bool(rng.integers(2)))
@@ -1814,6 +1823,7 @@ def test_fuzz_adversarial_api_sequences(rt, orc, scenes, seed):
         via = str(rng.choice(["planes", "ids", "batch", "stripes", "default_stream"]))
         log.append("check via " + via)
         what = "seed %d step %d: %s" % (seed, step, "; ".join(log))
+        print(what.split("; ")[-2] if step else what, "|", log[-1])
         cam.set_pose(cam_pose)
         if via == "planes":
             ref, = oracle_frames([cam_pose])
@@ -1879,9 +1889,12 @@ def test_fuzz_adversarial_api_sequences(rt, orc, scenes, seed):
             n = len(meshes[i]["tris"])
             if rng.random() < 0.75:
                 t = t[:max(1, int(rng.integers(1, n + 1)))]
-            log.append("rebuild mesh %d from %s, %d -> %d triangles" % (i, kind, n, len(t)))
+            log.append("rebuild mesh %d from %s, %d -> %d triangles (room for %d)" % (i, kind, n, len(t), meshes[i]["cap"]))
             sp.rebuild_mesh(i, t)
-            meshes[i] = dict(tris=t.copy(), h=o.mesh_from_triangles(t))
+            grows = len(t) > meshes[i]["cap"]
+            meshes[i] = dict(tris=t.copy(), h=o.mesh_from_triangles(t), cap=meshes[i]["cap"], rebuilt=True)
+            if grows:                                               # more triangles than its part of the arrays holds: the scene is uploaded again
+                uploaded_again()
         elif op == "instance":
             i = int(rng.integers(len(instances)))
             src = _adversarial_scene(scenes, np.random.default_rng(int(rng.integers(1 << 30))))[0].instances[0]
@@ -1892,6 +1905,7 @@ def test_fuzz_adversarial_api_sequences(rt, orc, scenes, seed):
         else:
             log.append("upload again")
             sp.upload_to_device()
+            uploaded_again()
         check(step)
 
 
