@@ -26,7 +26,8 @@ public:
     // (rt_scene_upload with num_nodes = 0) -- the shortest way from an OBJ file to a renderable scene.  bvh_top stays empty
     // until sync_tree() builds it on the host (print_stats, or anything else that reads the host tree, needs that first).
     static MeshPrimitive for_device_build(std::vector<TrianglePrimitive> triangles);
-    bool builds_at_upload() const { return tree_needs_rebuild; }
+    // (a mesh that was refitted since its device build goes through sync_tree() instead: the tree it is rendered with, not a new one)
+    bool builds_at_upload() const { return tree_needs_rebuild && built_from.empty(); }
     int num_triangles;
     BVHTree bvh_top;
     d_MeshPrimitive* to_device();                               // MeshPrimitive.h:36: this mesh's records on the current device
@@ -46,5 +47,6 @@ public:
 private:
     MeshPrimitive() : num_triangles(0) {}
     std::vector<TrianglePrimitive> triangles;
+    std::vector<TrianglePrimitive> built_from;                  // see refit(): the triangles a pending tree is to be built from, once refits have moved them
     bool tree_stale = false, tree_needs_rebuild = false;
 };

@@ -487,6 +487,11 @@ bool MeshPrimitive::refit(std::vector<TrianglePrimitive> moved, bool defer_tree)
     // upload_to_device() sends what the refitted device copy renders with.
     for (size_t i = 0; i < moved.size(); i++)
         for (int k = 0; k < 3; k++) moved[i].uv_coords[k] = triangles[i].uv_coords[k];
+    // A mesh whose tree is still to be built on the host (rebuilt on the device, or made for a device build): the tree the device copy
+    // has was built from the triangles as they are NOW, and this refit keeps its topology -- remember them, so that the host tree, when
+    // it is built at last, is that tree refitted and not a new one over the moved triangles (an upload must not change what is rendered:
+    // among exactly coincident triangles the one reported depends on the topology).
+    if (tree_needs_rebuild && built_from.empty()) built_from = triangles;
     triangles = std::move(moved);
     tree_stale = true;
     if (!defer_tree) sync_tree();
@@ -497,6 +502,7 @@ void MeshPrimitive::replace(std::vector<TrianglePrimitive> tris, bool defer_tree
 {
     triangles = std::move(tris);
     num_triangles = (int)triangles.size();
+    built_from.clear();
     tree_stale = tree_needs_rebuild = true;
     if (!defer_tree) sync_tree();
 }
@@ -504,7 +510,14 @@ void MeshPrimitive::replace(std::vector<TrianglePrimitive> tris, bool defer_tree
 void MeshPrimitive::sync_tree()
 {
     if (!tree_stale) return;
-    if (tree_needs_rebuild) bvh_top.build(triangles.data(), num_triangles);       // MeshPrimitive.cpp:38-56
+    if (tree_needs_rebuild && !built_from.empty()) {
+        // built on the device from `built_from`, refitted since: the same tree here (the GPU builder when there is a device -- the two
+        // builders give the same tree --, the host builder otherwise), then the bounds of the triangles as they are now
+        if (bvh_top.build_on_device(built_from.data(), num_triangles, 32) != RT_OK) bvh_top.build(built_from.data(), num_triangles);
+        bvh_top.refit(triangles.data(), num_triangles);
+        std::vector<TrianglePrimitive>().swap(built_from);
+    }
+    else if (tree_needs_rebuild) bvh_top.build(triangles.data(), num_triangles);  // MeshPrimitive.cpp:38-56
     else bvh_top.refit(triangles.data(), num_triangles);
     tree_stale = tree_needs_rebuild = false;
 }

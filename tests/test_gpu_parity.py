@@ -1790,16 +1790,15 @@ def test_fuzz_adversarial_api_sequences(rt, orc, scenes, seed):
     rng = np.random.default_rng(67000 + seed)
     desc, W, H, K, cam_pose, info = _adversarial_scene(scenes, rng)
     pose2 = tuple(np.asarray(cam_pose, np.float64) + np.concatenate([rng.uniform(-0.2, 0.2, 3), rng.uniform(-0.1, 0.1, 3)]))
-    # per mesh: its triangles, the oracle's mesh, how many triangles its part of the device arrays holds, and whether it was rebuilt --
-    # the host copy of a rebuilt mesh has no tree of its own (the device built it), so EVERY later upload of the scene builds that
-    # mesh's tree anew from the triangles it has then (refits since the rebuild included), where an un-rebuilt mesh keeps its topology
-    meshes = [dict(tris=t.copy(), h=o.mesh_from_triangles(t), cap=len(t), rebuilt=False) for _, t in desc.meshes]
+    # per mesh: its triangles, the oracle's mesh, how many triangles its part of the device arrays holds.  An upload never changes the
+    # tree a mesh is rendered with: the host copy of a mesh that was rebuilt on the device and refitted since builds, when it is needed
+    # at last, the tree of the rebuild refitted -- not a new one over the moved triangles (MeshPrimitive::refit / sync_tree), which
+    # would report another one of several exactly coincident triangles
+    meshes = [dict(tris=t.copy(), h=o.mesh_from_triangles(t), cap=len(t)) for _, t in desc.meshes]
 
     def uploaded_again():
         for m in meshes:
             m["cap"] = len(m["tris"])
-            if m["rebuilt"]:
-                m["h"] = o.mesh_from_triangles(m["tris"])
     instances = [list(i) for i in desc.instances]
     mats = desc.materials
     sp = desc.build_product(rt, gpu_build=bool(rng.integers(2)))
@@ -1892,7 +1891,7 @@ def test_fuzz_adversarial_api_sequences(rt, orc, scenes, seed):
             log.append("rebuild mesh %d from %s, %d -> %d triangles (room for %d)" % (i, kind, n, len(t), meshes[i]["cap"]))
             sp.rebuild_mesh(i, t)
             grows = len(t) > meshes[i]["cap"]
-            meshes[i] = dict(tris=t.copy(), h=o.mesh_from_triangles(t), cap=meshes[i]["cap"], rebuilt=True)
+            meshes[i] = dict(tris=t.copy(), h=o.mesh_from_triangles(t), cap=meshes[i]["cap"])
             if grows:                                               # more triangles than its part of the arrays holds: the scene is uploaded again
                 uploaded_again()
         elif op == "instance":
