@@ -707,19 +707,22 @@ def test_scene_upload_builds_the_tree_on_the_device(rt, orc, scenes, blob5k, tmp
     dbg = rt.render_debug(a, cam)
     for n in ("img",) + PLANES:
         assert np.array_equal(dbg[n], ref[n]), ("refit", n)
-    a.upload_to_device()                                        # (the deferred mesh is built on the device again, from the moved triangles)
-    so2 = orc_mod.OracleScene(o)
-    so2.add_material((0.9, 0.5, 0.2))
-    so2.add_mesh(o.mesh_from_triangles(tris))
-    so2.add_mesh(o.mesh_from_triangles(soup))
-    so2.add_mesh(o.mesh_from_triangles(soup[:1]))
-    so2.add_instance(0, 0, *inst0)
-    so2.add_instance(1, 0, *inst1)
-    so2.add_instance(2, 0, (0, 0, 1.5, 0, 0, 0), (1, 1, 1))
-    ref = so2.render(W, H, K, scenes.D_REF, pose, threads=8)
+    # An upload never changes the tree a mesh is rendered with (round 6, third session; found by test_fuzz_adversarial_api_sequences): the
+    # deferred mesh was refitted since its device build, so its host tree -- built now, at last -- is the tree of that build refitted, not
+    # a new one over the moved triangles (which this test used to expect): the frame and every count stay what they were before the upload
+    a.upload_to_device()
     dbg = rt.render_debug(a, cam)
     for n in ("img",) + PLANES:
         assert np.array_equal(dbg[n], ref[n]), ("re-upload", n)
+    fresh = orc_mod.OracleScene(o)                              # (a new tree over the moved triangles would have shown: its visit counts differ)
+    fresh.add_material((0.9, 0.5, 0.2))
+    for m in (o.mesh_from_triangles(tris), o.mesh_from_triangles(soup), o.mesh_from_triangles(soup[:1])):
+        fresh.add_mesh(m)
+    fresh.add_instance(0, 0, *inst0)
+    fresh.add_instance(1, 0, *inst1)
+    fresh.add_instance(2, 0, (0, 0, 1.5, 0, 0, 0), (1, 1, 1))
+    assert not np.array_equal(fresh.render(W, H, K, scenes.D_REF, pose, threads=8)["pops"], ref["pops"])
+    fresh.close()
     # a mesh in the middle of the record array (index 1, host-built at upload) is rebuilt in place; its new triangles carry a uv
     # value that is not an ordinary number, which switches the mesh to per-candidate uv interpolation (raycast.cu:96)
     soup2 = sd.random_triangles(300, seed=9, spread=0.7, size=0.35)
@@ -727,7 +730,7 @@ def test_scene_upload_builds_the_tree_on_the_device(rt, orc, scenes, blob5k, tmp
     a.rebuild_mesh(1, soup2)
     so3 = orc_mod.OracleScene(o)
     so3.add_material((0.9, 0.5, 0.2))
-    so3.add_mesh(o.mesh_from_triangles(tris))
+    so3.add_mesh(blob)                                          # (mesh 0 as it is rendered: the first tree, refitted)
     so3.add_mesh(o.mesh_from_triangles(soup2))
     so3.add_mesh(o.mesh_from_triangles(soup[:1]))
     so3.add_instance(0, 0, *inst0)
@@ -738,7 +741,6 @@ def test_scene_upload_builds_the_tree_on_the_device(rt, orc, scenes, blob5k, tmp
     for n in ("img",) + PLANES:
         assert np.array_equal(dbg[n], ref[n]), ("rebuild of mesh 1", n)
     so.close()
-    so2.close()
     so3.close()
 
 
@@ -819,8 +821,9 @@ def test_device_resident_rebuild_of_a_mesh(rt, orc, scenes, blob5k):
         check(sp, so, "instance update after rebuild %d" % step)
         sp.update_mesh_instance(0, 0, 0, *inst)
         so.close()
-    # a re-upload sends the host copy, whose tree is rebuilt on the host when it is needed
-    so, om = oracle_scene(m2)
+    # a re-upload sends the host copy, whose tree is built when it is needed: the tree of the last rebuild, refitted as the mesh was since
+    so, om = oracle_scene(moved)
+    o.mesh_refit(om, m2)
     sp.upload_to_device()
     check(sp, so, "re-upload")
     so.close()
